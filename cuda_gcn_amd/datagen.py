@@ -1,0 +1,194 @@
+"""Seeded synthetic stand-ins for the reference's datasets.
+
+The reference ships no data (its ``data.tgz`` is absent and there is no
+network), so every configuration runs on shape-matched synthetic graphs.  The
+in-memory layout is exactly what the reference's loader produces
+(``src/common/parser.cpp:20-103`` of the reference): graph CSR with the self
+loop stored FIRST in every row, feature CSR + values, one label and one split
+code (1 train / 2 val / 3 test / 0 unused) per node.  ``write_text`` emits the
+three text files (``<name>.graph/.split/.svmlight``) the reference reads.
+
+Definitions follow SURVEY.md §8(d); generator seed 20191210 unless stated.
+"""
+from __future__ import annotations
+
+import os
+import numpy as np
+
+DEFAULT_SEED = 20191210
+
+# name -> (N, F, C, undirected edges, nnz/row (0 = dense), n_train, n_val, n_test)
+SHAPES = {
+    "cora-syn": (2708, 1433, 7, 5429, 18, 140, 500, 1000),
+    "citeseer-syn": (3327, 3703, 6, 4732, 32, 120, 500, 1000),
+    "pubmed-syn": (19717, 500, 3, 44338, 50, 60, 500, 1000),
+    "reddit-syn": (232965, 602, 41, 11606919, 0, -1, -1, -1),
+    "reddit-mini": (23296, 602, 41, 1160692, 0, -1, -1, -1),
+    "tiny-syn": (97, 23, 5, 211, 6, 30, 25, 30),
+}
+
+
+def _unique_undirected(u, v, n):
+    """drop self loops and duplicate pairs; return (lo, hi) arrays"""
+    lo = np.minimum(u, v).astype(np.int64)
+    hi = np.maximum(u, v).astype(np.int64)
+    keep = lo != hi
+    key = np.unique(lo[keep] * n + hi[keep])
+    return (key // n).astype(np.int64), (key % n).astype(np.int64)
+
+
+def _sample_edges(rng, n, m, weights=None):
+    """m distinct undirected edges; endpoints uniform or ∝ weights (Chung-Lu)"""
+    if weights is not None:
+        cdf = np.cumsum(weights, dtype=np.float64)
+        cdf /= cdf[-1]
+    lo = np.empty(0, np.int64)
+    hi = np.empty(0, np.int64)
+    while lo.size < m:
+        need = int((m - lo.size) * 1.15) + 64
+        if weights is None:
+            u = rng.integers(0, n, need)
+            v = rng.integers(0, n, need)
+        else:
+            u = np.searchsorted(cdf, rng.random(need), side="right").clip(0, n - 1)
+            v = np.searchsorted(cdf, rng.random(need), side="right").clip(0, n - 1)
+        a, b = _unique_undirected(np.concatenate([lo, np.minimum(u, v)]),
+                                  np.concatenate([hi, np.maximum(u, v)]), n)
+        lo, hi = a, b
+    if lo.size > m:
+        sel = np.sort(rng.choice(lo.size, m, replace=False))
+        lo, hi = lo[sel], hi[sel]
+    return lo, hi
+
+
+def csr_with_self_loops(lo, hi, n):
+    """symmetrise and put the self loop first in every row (parser.cpp:30-42)"""
+    src = np.concatenate([lo, hi])
+    dst = np.concatenate([hi, lo])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    deg = np.bincount(src, minlength=n).astype(np.int64) + 1
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    indices = np.empty(indptr[-1], np.int32)
+    indices[indptr[:-1]] = np.arange(n, dtype=np.int32)
+    # position of each neighbour = row start + 1 + rank inside the row
+    rank = np.arange(src.size, dtype=np.int64) - (indptr[src] - src)  # indptr[src]-src = edges before row (no self loops)
+    indices[indptr[src] + 1 + rank] = dst.astype(np.int32)
+    assert indptr[-1] < 2 ** 31
+    return indptr.astype(np.int32), indices
+
+
+def _rmat_edges(rng, scale, edge_factor, a=0.57, b=0.19, c=0.19):
+    n = 1 << scale
+    m = n * edge_factor
+    u = np.zeros(m, np.int64)
+    v = np.zeros(m, np.int64)
+    for _ in range(scale):
+        r = rng.random(m)
+        bit_u = (r >= a + b).astype(np.int64)
+        bit_v = (((r >= a) & (r < a + b)) | (r >= a + b + c)).astype(np.int64)
+        u = (u << 1) | bit_u
+        v = (v << 1) | bit_v
+    return _unique_undirected(u, v, n)
+
+
+def make_dataset(name: str, seed: int = DEFAULT_SEED, rows: slice | None = None):
+    """Build a dataset dict.  ``name``: a key of SHAPES or ``rmat-<scale>[-<feats>]``."""
+    rng = np.random.default_rng(seed)
+    if name.startswith("rmat-"):
+        parts = name.split("-")
+        scale = int(parts[1])
+        F = int(parts[2]) if len(parts) > 2 else 256
+        C = 41
+        lo, hi = _rmat_edges(rng, scale, 16)
+        N = 1 << scale
+        nnz_row = 0
+        n_train = n_val = n_test = -2
+    else:
+        N, F, C, M, nnz_row, n_train, n_val, n_test = SHAPES[name]
+        if name.startswith("reddit"):
+            # Chung-Lu, power-law expected degrees (exponent ~2.3), capped
+            w = (np.arange(1, N + 1, dtype=np.float64)) ** (-1.0 / 1.3)
+            rng.shuffle(w)
+            cap = 2.0e4 * w.sum() / (2.0 * M)
+            w = np.minimum(w, cap)
+            lo, hi = _sample_edges(rng, N, M, w)
+        else:
+            lo, hi = _sample_edges(rng, N, M)
+    g_indptr, g_indices = csr_with_self_loops(lo, hi, N)
+
+    label = rng.integers(0, C, N).astype(np.int32)
+    label[:C] = np.arange(C, dtype=np.int32)       # every class occurs (loader: output_dim = max label + 1)
+
+    if nnz_row == 0:
+        # dense standardised features with a class-dependent shift (learnable signal)
+        f_val = rng.standard_normal((N, F), dtype=np.float32)
+        f_val[np.arange(N), label % F] += np.float32(0.5 if name.startswith("rmat") else 1.5)
+        f_indptr = (np.arange(N + 1, dtype=np.int64) * F).astype(np.int32)
+        f_indices = np.tile(np.arange(F, dtype=np.int32), N)
+        f_val = f_val.reshape(-1)
+    else:
+        # nnz_row distinct columns per row; half of them from a class-specific band
+        band = max(nnz_row, F // C)
+        cols = np.empty((N, nnz_row), np.int64)
+        half = nnz_row // 2
+        for i in range(N):
+            b0 = (int(label[i]) * (F // C)) % max(1, F - band + 1)
+            own = b0 + rng.choice(band, half, replace=False)
+            rest = rng.choice(F, nnz_row, replace=False)
+            rest = rest[~np.isin(rest, own)][: nnz_row - half]
+            cols[i] = np.sort(np.concatenate([own, rest]))
+        cols[0, -1] = F - 1                          # input_dim = max index + 1
+        cols[0] = np.sort(cols[0])
+        if np.unique(cols[0]).size != nnz_row:       # keep row 0 duplicate-free
+            cols[0] = np.sort(np.concatenate([rng.choice(F - 1, nnz_row - 1, replace=False), [F - 1]]))
+        f_indices = cols.reshape(-1).astype(np.int32)
+        f_indptr = (np.arange(N + 1, dtype=np.int64) * nnz_row).astype(np.int32)
+        if name.startswith("pubmed"):
+            f_val = rng.uniform(0.0, 0.2, N * nnz_row).astype(np.float32)   # TF-IDF-like
+        else:
+            f_val = np.full(N * nnz_row, np.float32(1.0) / np.float32(nnz_row), np.float32)
+
+    split = np.zeros(N, np.int32)
+    perm = rng.permutation(N)
+    if n_train == -1:                                # reddit: 66 % / 10 % / 24 %
+        a, b = int(0.66 * N), int(0.76 * N)
+        split[perm[:a]] = 1
+        split[perm[a:b]] = 2
+        split[perm[b:]] = 3
+    elif n_train == -2:                              # rmat: all train except 1 % val, 1 % test
+        split[:] = 1
+        k = max(1, N // 100)
+        split[perm[:k]] = 2
+        split[perm[k:2 * k]] = 3
+    else:
+        split[perm[:n_train]] = 1
+        split[perm[n_train:n_train + n_val]] = 2
+        split[perm[n_train + n_val:n_train + n_val + n_test]] = 3
+
+    return dict(name=name, num_nodes=N, input_dim=F, output_dim=C,
+                g_indptr=g_indptr, g_indices=g_indices,
+                f_indptr=f_indptr, f_indices=f_indices, f_val=f_val,
+                label=label, split=split)
+
+
+def write_text(ds, root: str, name: str | None = None):
+    """Write ``root/<name>.graph/.split/.svmlight`` in the reference's formats
+    (parser.cpp:20-103).  Values are printed with 9 significant digits so they
+    round-trip through strtof bit-exactly."""
+    name = name or ds["name"]
+    os.makedirs(root, exist_ok=True)
+    N = ds["num_nodes"]
+    gp, gi = ds["g_indptr"], ds["g_indices"]
+    with open(os.path.join(root, name + ".graph"), "w") as f:
+        for i in range(N):
+            f.write(" ".join(map(str, gi[gp[i] + 1:gp[i + 1]].tolist())) + "\n")   # self loop is implicit
+    fp, fi, fv = ds["f_indptr"], ds["f_indices"], ds["f_val"]
+    with open(os.path.join(root, name + ".svmlight"), "w") as f:
+        for i in range(N):
+            toks = ["%d:%.9g" % (k, v) for k, v in zip(fi[fp[i]:fp[i + 1]].tolist(), fv[fp[i]:fp[i + 1]].tolist())]
+            f.write(str(int(ds["label"][i])) + (" " if toks else "") + " ".join(toks) + "\n")
+    with open(os.path.join(root, name + ".split"), "w") as f:
+        for s in ds["split"].tolist():
+            f.write("%d\n" % s)

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """the CPU oracle (oracle/liboracle.so), built on demand"""
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """the reference's own objects (oracle/_ref/libref.so); build container only"""
+    from oracle.pyoracle import Ref, build
+    if not Ref.available() and os.path.isdir("/root/reference/src"):
+        build()
+    if not Ref.available():
+        pytest.skip("oracle/_ref not built (reference tree absent on this box)")
+    return Ref()

@@ -1,0 +1,209 @@
+"""Pin the CPU oracle (oracle/gcn_oracle.c) bit-for-bit.
+
+(1) against the committed fixtures in tests/golden/ — produced by the
+    reference's own objects (tests/golden/make_golden.py);
+(2) against oracle/_ref/libref.so itself on fresh seeded inputs, when the
+    reference tree is present (build container only).
+CPU only; everything here is exact equality (==), no tolerance.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from cuda_gcn_amd import datagen
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    return np.load(os.path.join(GOLD, "modules.npz"))
+
+
+@pytest.fixture(scope="module")
+def traces():
+    return np.load(os.path.join(GOLD, "traces.npz"))
+
+
+@pytest.fixture(scope="module")
+def parse_gold():
+    return np.load(os.path.join(GOLD, "parser.npz"))
+
+
+def eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                          b.view(np.uint32) if b.dtype == np.float32 else b)
+
+
+# ------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("g", ["karate", "tiny", "ragged"])
+@pytest.mark.parametrize("dim", [1, 7, 16, 41])
+def test_graphsum_golden(oracle, mods, g, dim):
+    gp, gi = mods[f"gs_{g}_indptr"], mods[f"gs_{g}_indices"]
+    out = oracle.graphsum(gp, gi, mods[f"gs_{g}_d{dim}_in"], dim)
+    eq(out, mods[f"gs_{g}_d{dim}_out"])
+    eq(out, mods[f"gs_{g}_d{dim}_bwd"])      # backward is the same operator (module.cpp:103-119)
+
+
+@pytest.mark.parametrize("shape", [(34, 16, 7), (97, 128, 41), (5, 3, 2), (1, 1, 1)])
+def test_matmul_golden(oracle, mods, shape):
+    m, n, p = shape
+    k = f"mm_{m}x{n}x{p}"
+    eq(oracle.matmul_fwd(mods[k + "_a"], mods[k + "_b"], m, n, p), mods[k + "_c"])
+    ag, bg = oracle.matmul_bwd(mods[k + "_a"], mods[k + "_b"], mods[k + "_cg"], m, n, p)
+    eq(ag, mods[k + "_ag"])
+    eq(bg, mods[k + "_bg"])
+
+
+@pytest.mark.parametrize("p", [16, 8, 3])
+def test_spmm_golden(oracle, mods, p):
+    fp, fi, F = mods["sp_tiny_indptr"], mods["sp_tiny_indices"], int(mods["sp_tiny_F"])
+    k = f"sp_tiny_p{p}"
+    eq(oracle.spmm_fwd(fp, fi, mods[k + "_val"], mods[k + "_w"], p), mods[k + "_c"])
+    eq(oracle.spmm_bwd(fp, fi, mods[k + "_val"], mods[k + "_cg"], F, p), mods[k + "_wg"])
+
+
+def test_xent_golden(oracle, mods):
+    lg, tr = mods["ce_logits"], mods["ce_truth"]
+    for training in (0, 1):
+        loss, shifted, grad = oracle.xent_fwd(lg, tr, lg.shape[1], bool(training))
+        assert np.float32(loss) == mods[f"ce_loss_t{training}"]
+        eq(shifted, mods[f"ce_shifted_t{training}"])
+        if training:
+            eq(grad, mods["ce_grad"])
+
+
+def test_relu_dropout_golden(oracle, mods):
+    y, mask = oracle.relu_fwd(mods["relu_x"])
+    eq(y, mods["relu_y"])
+    eq(oracle.relu_bwd(mods["relu_g"], mask), mods["relu_gb"])
+    s0, s1 = (int(v) for v in mods["drop_state"])
+    for p in (0.5, 0.0, 0.9):
+        oracle.rand_set_state(s0, s1)
+        y, mask = oracle.dropout_fwd(mods["drop_x"], p)
+        eq(y, mods[f"drop_p{p}_y"])
+        eq(oracle.dropout_bwd(mods["drop_g"], mask, p), mods[f"drop_p{p}_gb"])
+
+
+def test_rng_glorot_adam_golden(oracle, mods):
+    oracle.rand_seed_time(42)
+    assert tuple(int(v) for v in mods["rng_seed42_state"]) == oracle.rand_get_state()
+    eq(oracle.rand_stream(64), mods["rng_seed42_first64"])
+    oracle.rand_seed_time(7)
+    eq(oracle.glorot(600, 30, 20), mods["glorot_seed7_30x20"])
+    eq(oracle.adam_steps(mods["adam_w0"], mods["adam_grads"], 1, 0.01, 5e-4)[0], mods["adam_w_decay"])
+    eq(oracle.adam_steps(mods["adam_w0"], mods["adam_grads"], 0, 0.01, 5e-4)[0], mods["adam_w_nodecay"])
+
+
+def _ds_digest(ds):
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "label", "split"):
+        h.update(np.ascontiguousarray(ds[k]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name,seeds,epochs", [("tiny-syn", (1, 2, 3), 100), ("cora-syn", (1, 2, 3), 100),
+                                               ("citeseer-syn", (1,), 30), ("pubmed-syn", (1,), 20)])
+def test_trace_golden(oracle, traces, name, seeds, epochs):
+    """100-epoch loss/accuracy traces, bit-exact, dropout 0.5 and 0"""
+    ds = datagen.make_dataset(name)
+    assert _ds_digest(ds) == str(traces[f"{name}_digest"]), "synthetic generator drifted"
+    for seed in seeds:
+        for dropout in (0.5, 0.0):
+            k = f"{name}_s{seed}_d{dropout}"
+            m = oracle.model(ds, seed_time=seed, hidden_dim=16, dropout=dropout, epochs=epochs)
+            tr = np.zeros((epochs, 4), np.float32)
+            for e in range(epochs):
+                tr[e, 0], tr[e, 1] = m.train_epoch()
+                tr[e, 2], tr[e, 3] = m.eval(2)
+            eq(tr, traces[k + "_trace"])
+            eq(np.array(m.eval(3), np.float32), traces[k + "_test"])
+            assert np.float64(m.var(2).astype(np.float64).sum()) == traces[k + "_w1sum"]
+            assert np.float64(m.var(5).astype(np.float64).sum()) == traces[k + "_w2sum"]
+            if (k + "_w1") in traces:
+                eq(m.var(2), traces[k + "_w1"])
+                eq(m.var(5), traces[k + "_w2"])
+            m.close()
+
+
+@pytest.mark.parametrize("case", ["noeol", "ragged", "plain"])
+def test_parser_golden(oracle, parse_gold, case):
+    with tempfile.TemporaryDirectory() as td:
+        for ext, key in ((".graph", "graph_txt"), (".svmlight", "svm_txt"), (".split", "split_txt")):
+            with open(os.path.join(td, case + ext), "w") as f:
+                f.write(str(parse_gold[f"parse_{case}_{key}"]))
+        ds = oracle.parse(td, case)
+    assert ds is not None
+    for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
+        eq(ds[k], parse_gold[f"parse_{case}_{k}"])
+    assert [ds["num_nodes"], ds["input_dim"], ds["output_dim"]] == parse_gold[f"parse_{case}_dims"].tolist()
+
+
+def test_parser_missing_file(oracle):
+    with tempfile.TemporaryDirectory() as td:
+        assert oracle.parse(td, "nothing") is None
+
+
+def test_text_roundtrip(oracle):
+    ds = datagen.make_dataset("tiny-syn")
+    with tempfile.TemporaryDirectory() as td:
+        datagen.write_text(ds, td, "tiny-syn")
+        back = oracle.parse(td, "tiny-syn")
+    for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
+        eq(back[k], ds[k])
+
+
+# ------------------------------------------------- live against the reference
+def test_live_modules_vs_reference(oracle, ref):
+    rng = np.random.default_rng(99)
+    ds = datagen.make_dataset("tiny-syn", seed=5)
+    gp, gi, N = ds["g_indptr"], ds["g_indices"], ds["num_nodes"]
+    for dim in (3, 32, 128):
+        x = rng.standard_normal((N, dim)).astype(np.float32)
+        eq(oracle.graphsum(gp, gi, x, dim), ref.graphsum(gp, gi, x, dim))
+    m, n, p = 61, 33, 17
+    a, b, cg = (rng.standard_normal(s).astype(np.float32) for s in ((m, n), (n, p), (m, p)))
+    eq(oracle.matmul_fwd(a, b, m, n, p), ref.matmul_fwd(a, b, m, n, p))
+    o1, r1 = oracle.matmul_bwd(a, b, cg, m, n, p), ref.matmul_bwd(a, b, cg, m, n, p)
+    eq(o1[0], r1[0]); eq(o1[1], r1[1])
+    fp, fi, F = ds["f_indptr"], ds["f_indices"], ds["input_dim"]
+    val = rng.standard_normal(fi.size).astype(np.float32)
+    w = rng.standard_normal((F, 9)).astype(np.float32)
+    eq(oracle.spmm_fwd(fp, fi, val, w, 9), ref.spmm_fwd(fp, fi, val, w, F, 9))
+    cg = rng.standard_normal((N, 9)).astype(np.float32)
+    eq(oracle.spmm_bwd(fp, fi, val, cg, F, 9), ref.spmm_bwd(fp, fi, val, cg, F, 9))
+    for t in (3, 1000, 2 ** 31 - 1):
+        oracle.rand_seed_time(t); ref.rand_seed_time(t)
+        assert oracle.rand_get_state() == ref.rand_get_state()
+        eq(oracle.rand_stream(100), ref.rand_stream(100))
+
+
+def test_live_model_vs_reference(oracle, ref):
+    ds = datagen.make_dataset("tiny-syn", seed=77)
+    for hidden, dropout in ((16, 0.5), (32, 0.25), (8, 0.0)):
+        mo = oracle.model(ds, seed_time=9, hidden_dim=hidden, dropout=dropout)
+        mr = ref.model(ds, seed_time=9, hidden_dim=hidden, dropout=dropout)
+        for _ in range(25):
+            assert mo.train_epoch() == mr.train_epoch()
+            assert mo.eval(2) == mr.eval(2)
+        assert mo.eval(3) == mr.eval(3)
+        for k in range(7):
+            eq(mo.var(k), mr.var(k))
+            if k:
+                eq(mo.var(k, True), mr.var(k, True))
+        mo.close(); mr.close()
+
+
+def test_live_parser_vs_reference(oracle, ref):
+    ds = datagen.make_dataset("tiny-syn", seed=3)
+    with tempfile.TemporaryDirectory() as td:
+        datagen.write_text(ds, os.path.join(td, "data"), "t")
+        a = oracle.parse(os.path.join(td, "data"), "t")
+        b = ref.parse(td, "t")
+    for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
+        eq(a[k], b[k])
