@@ -1,0 +1,129 @@
+"""ctypes loader for the in-tree native libraries.
+
+There is no fallback: if libgcnhip.so (hand-written HIP for gfx950 behind the
+C-ABI of include/gcnhip.h) is missing or does not load, importing an op fails
+loudly.  Build with ``make kernels host`` or ``__graft_entry__.build()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(HERE, "lib")
+
+_cache = {}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def _load(name: str) -> C.CDLL:
+    if name in _cache:
+        return _cache[name]
+    path = os.path.join(LIBDIR, name)
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            f"{path} not found: the HIP extension is not built. Run `make kernels host` "
+            f"(or __graft_entry__.build()); there is no CPU fallback.")
+    try:
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryMissing(f"cannot load {path}: {e}") from e
+    _cache[name] = lib
+    return lib
+
+
+def gcnhip() -> C.CDLL:
+    lib = _load("libgcnhip.so")
+    if not getattr(lib, "_typed", False):
+        _declare_gcnhip(lib)
+        lib._typed = True
+    return lib
+
+
+def gcnhost() -> C.CDLL:
+    gcnhip()
+    lib = _load("libgcnhost.so")
+    if not getattr(lib, "_typed", False):
+        _declare_gcnhost(lib)
+        lib._typed = True
+    return lib
+
+
+P = C.c_void_p
+I = C.c_int
+I64 = C.c_int64
+U64 = C.c_uint64
+F = C.c_float
+
+
+class AdamVar(C.Structure):
+    _fields_ = [("w", P), ("g", P), ("m", P), ("v", P), ("n", I64), ("decay", I)]
+
+
+# every symbol of include/gcnhip.h: name -> (restype, argtypes)
+GCNHIP_SYMBOLS = {
+    "gcnhip_device_count": (I, [C.POINTER(I)]),
+    "gcnhip_ctx_create": (I, [C.POINTER(P), I, P]),
+    "gcnhip_ctx_destroy": (I, [P]),
+    "gcnhip_ctx_sync": (I, [P]),
+    "gcnhip_ctx_stream": (P, [P]),
+    "gcnhip_error_string": (C.c_char_p, [I]),
+    "gcnhip_version": (C.c_char_p, []),
+    "gcnhip_malloc": (I, [P, C.POINTER(P), C.c_size_t]),
+    "gcnhip_free": (I, [P, P]),
+    "gcnhip_memset_async": (I, [P, P, I, C.c_size_t]),
+    "gcnhip_h2d": (I, [P, P, P, C.c_size_t]),
+    "gcnhip_d2h": (I, [P, P, P, C.c_size_t]),
+    "gcnhip_d2d_async": (I, [P, P, P, C.c_size_t]),
+    "gcnhip_graph_create": (I, [P, C.POINTER(P), P, P, I, I, P]),
+    "gcnhip_graph_destroy": (I, [P, P]),
+    "gcnhip_graph_arrays": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
+    "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),
+    "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
+    "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
+    "gcnhip_feat_destroy": (I, [P, P]),
+    "gcnhip_feat_is_dense": (I, [P]),
+    "gcnhip_feat_values": (P, [P]),
+    "gcnhip_feat_nnz": (I64, [P]),
+    "gcnhip_spmm_fwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
+    "gcnhip_spmm_bwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
+    "gcnhip_matmul_fwd": (I, [P, P, I, P, I, P, I, I, I, I]),
+    "gcnhip_matmul_bwd": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I]),
+    "gcnhip_matmul_bwd_fused": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F]),
+    "gcnhip_relu_fwd": (I, [P, P, P, I64, I]),
+    "gcnhip_relu_bwd": (I, [P, P, P, I64]),
+    "gcnhip_dropout_fwd": (I, [P, P, P, I64, F, U64, P, U64, P]),
+    "gcnhip_dropout_bwd": (I, [P, P, P, I64, F]),
+    "gcnhip_relu_dropout_bwd": (I, [P, P, I, P, I, I, I, F]),
+    "gcnhip_xent_fwd": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P]),
+    "gcnhip_accuracy": (I, [P, P, I, P, I, I, P]),
+    "gcnhip_set_truth": (I, [P, P, P, P, I, I]),
+    "gcnhip_sumsq": (I, [P, P, I64, P]),
+    "gcnhip_adam_step": (I, [P, C.POINTER(AdamVar), I, F, P, P, F, F, F, F, P]),
+    "gcnhip_counter_add": (I, [P, P, C.c_uint32]),
+    "gcnhip_metrics_record": (I, [P, P, I, I, P, P, P, P]),
+    "gcnhip_event_create": (I, [C.POINTER(P)]),
+    "gcnhip_event_destroy": (I, [P]),
+    "gcnhip_event_record": (I, [P, P]),
+    "gcnhip_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),
+}
+
+
+def _declare_gcnhip(lib):
+    for name, (res, args) in GCNHIP_SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+
+
+GCNHOST_SYMBOLS = {}
+
+
+def _declare_gcnhost(lib):
+    for name, (res, args) in GCNHOST_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args

@@ -1,0 +1,288 @@
+// ctx.hip — context, memory, prepared adjacency / feature objects, events.
+// Host-side preparation happens ONCE per dataset (the reference re-derives
+// degrees per edge per call and re-uploads X every epoch).
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+extern "C" {
+
+int gcnhip_device_count(int *count) {
+    GCNHIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+const char *gcnhip_error_string(int code) {
+    if (code == -1) return "gcnhip: invalid argument";
+    return hipGetErrorString((hipError_t)code);
+}
+
+const char *gcnhip_version(void) { return "gcnhip 0.1 (gfx950)"; }
+
+int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
+    if (!out) return -1;
+    GCNHIP_TRY(hipSetDevice(device));
+    gcnhip_ctx *c = new gcnhip_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return (int)e; }
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    GCNHIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    GCNHIP_TRY(hipMalloc((void **)&c->red_f, RED_SLOTS * 4 * sizeof(float)));
+    GCNHIP_TRY(hipMalloc((void **)&c->red_i, RED_SLOTS * 4 * sizeof(int32_t)));
+    GCNHIP_TRY(hipMalloc((void **)&c->ticket, 64 * sizeof(uint32_t)));
+    GCNHIP_TRY(hipMemset(c->ticket, 0, 64 * sizeof(uint32_t)));
+    c->slab = nullptr;
+    c->slab_bytes = 0;
+    *out = c;
+    return 0;
+}
+
+int gcnhip_ctx_destroy(gcnhip_ctx *c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipFree(c->red_f);
+    hipFree(c->red_i);
+    hipFree(c->ticket);
+    if (c->slab) hipFree(c->slab);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int gcnhip_ctx_sync(gcnhip_ctx *c) { GCNHIP_TRY(hipStreamSynchronize(c->stream)); return 0; }
+void *gcnhip_ctx_stream(gcnhip_ctx *c) { return (void *)c->stream; }
+
+int gcnhip_malloc(gcnhip_ctx *c, void **ptr, size_t bytes) {
+    GCNHIP_TRY(hipSetDevice(c->device));
+    GCNHIP_TRY(hipMalloc(ptr, bytes ? bytes : 16));
+    return 0;
+}
+int gcnhip_free(gcnhip_ctx *c, void *ptr) {
+    if (!ptr) return 0;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    GCNHIP_TRY(hipFree(ptr));
+    return 0;
+}
+int gcnhip_memset_async(gcnhip_ctx *c, void *ptr, int byte, size_t bytes) {
+    if (bytes) GCNHIP_TRY(hipMemsetAsync(ptr, byte, bytes, c->stream));
+    return 0;
+}
+int gcnhip_h2d(gcnhip_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes) GCNHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gcnhip_d2h(gcnhip_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes) GCNHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gcnhip_d2d_async(gcnhip_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes) GCNHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int gcnhip_event_create(void **ev) { GCNHIP_TRY(hipEventCreate((hipEvent_t *)ev)); return 0; }
+int gcnhip_event_destroy(void *ev) { GCNHIP_TRY(hipEventDestroy((hipEvent_t)ev)); return 0; }
+int gcnhip_event_record(gcnhip_ctx *c, void *ev) { GCNHIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream)); return 0; }
+int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms) {
+    GCNHIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    GCNHIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- adjacency
+// coef(e) for every edge, computed once.  One thread per row walks its edges
+// (one-time cost; the per-call kernels then stream coef[] coalesced).
+__global__ void edge_coef_kernel(const int *__restrict__ indptr, const int *__restrict__ indices,
+                                 const int *__restrict__ col_deg, float *__restrict__ coef, int n_rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int e0 = indptr[r], e1 = indptr[r + 1];
+    const int64_t ds = e1 - e0;
+    for (int e = e0; e < e1; e++) {
+        const int d = indices[e];
+        const int64_t dd = col_deg ? col_deg[d] : (indptr[d + 1] - indptr[d]);
+        // module.cpp:91-93: float sqrtf of the integer product, divide in double, narrow
+        coef[e] = (float)(1.0 / (double)sqrtf((float)(ds * dd)));
+    }
+}
+
+constexpr int SPLIT_EDGES = 1024;   // rows longer than this are cut into segments
+
+extern "C" {
+
+int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, const int *h_indices,
+                        int n_rows, int n_cols, const int *h_col_deg) {
+    if (!c || !out || !h_indptr || n_rows < 0) return -1;
+    if (!h_col_deg && n_cols != n_rows) return -1;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    const int nnz = h_indptr[n_rows];
+    for (int e = 0; e < nnz; e++)
+        if (h_indices[e] < 0 || h_indices[e] >= n_cols) return -1;    // a bad column would fault the gather
+    gcnhip_graph *g = new gcnhip_graph();
+    memset(g, 0, sizeof *g);
+    g->n_rows = n_rows; g->n_cols = n_cols; g->nnz = nnz;
+    GCNHIP_TRY(hipMalloc((void **)&g->indptr, (size_t)(n_rows + 1) * sizeof(int)));
+    GCNHIP_TRY(hipMalloc((void **)&g->indices, (size_t)std::max(nnz, 1) * sizeof(int)));
+    GCNHIP_TRY(hipMalloc((void **)&g->coef, (size_t)std::max(nnz, 1) * sizeof(float)));
+    GCNHIP_TRY(hipMemcpy(g->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (nnz) GCNHIP_TRY(hipMemcpy(g->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    int *d_col_deg = nullptr;
+    if (h_col_deg) {
+        GCNHIP_TRY(hipMalloc((void **)&d_col_deg, (size_t)std::max(n_cols, 1) * sizeof(int)));
+        GCNHIP_TRY(hipMemcpy(d_col_deg, h_col_deg, (size_t)n_cols * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (n_rows) {
+        edge_coef_kernel<<<ceil_div(n_rows, 256), 256, 0, c->stream>>>(g->indptr, g->indices, d_col_deg, g->coef, n_rows);
+        GCNHIP_LAUNCH_CHECK();
+    }
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
+    if (d_col_deg) GCNHIP_TRY(hipFree(d_col_deg));
+
+    // long-row splitting: segments of SPLIT_EDGES edges, heavy tasks first
+    int n_long = 0, n_slots = 0;
+    for (int r = 0; r < n_rows; r++) {
+        const int d = h_indptr[r + 1] - h_indptr[r];
+        if (d > SPLIT_EDGES) { n_long++; n_slots += (d + SPLIT_EDGES - 1) / SPLIT_EDGES; }
+    }
+    if (n_long) {
+        std::vector<int4> tasks, srows;
+        tasks.reserve((size_t)n_rows + n_slots);
+        int slot = 0;
+        for (int r = 0; r < n_rows; r++) {
+            const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
+            if (e1 - e0 <= SPLIT_EDGES) continue;
+            const int ns = (e1 - e0 + SPLIT_EDGES - 1) / SPLIT_EDGES;
+            srows.push_back(make_int4(r, slot, ns, 0));
+            for (int s = 0; s < ns; s++)
+                tasks.push_back(make_int4(r, e0 + s * SPLIT_EDGES, std::min(e1, e0 + (s + 1) * SPLIT_EDGES), slot + s));
+            slot += ns;
+        }
+        for (int r = 0; r < n_rows; r++) {
+            const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
+            if (e1 - e0 <= SPLIT_EDGES) tasks.push_back(make_int4(r, e0, e1, -1));
+        }
+        g->n_tasks = (int)tasks.size();
+        g->n_split_rows = (int)srows.size();
+        g->n_slots = n_slots;
+        GCNHIP_TRY(hipMalloc((void **)&g->tasks, tasks.size() * sizeof(int4)));
+        GCNHIP_TRY(hipMemcpy(g->tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
+        GCNHIP_TRY(hipMalloc((void **)&g->split_rows, srows.size() * sizeof(int4)));
+        GCNHIP_TRY(hipMemcpy(g->split_rows, srows.data(), srows.size() * sizeof(int4), hipMemcpyHostToDevice));
+        g->part_ld = 0;       // partial buffer sized lazily for the widest dim seen
+        g->partials = nullptr;
+    }
+    *out = g;
+    return 0;
+}
+
+int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
+    if (!g) return 0;
+    hipSetDevice(c->device);
+    hipFree(g->indptr); hipFree(g->indices); hipFree(g->coef);
+    if (g->tasks) hipFree(g->tasks);
+    if (g->split_rows) hipFree(g->split_rows);
+    if (g->partials) hipFree(g->partials);
+    delete g;
+    return 0;
+}
+
+int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int **d_indices,
+                        const float **d_coef, int *n_rows, int *nnz) {
+    if (!g) return -1;
+    if (d_indptr) *d_indptr = g->indptr;
+    if (d_indices) *d_indices = g->indices;
+    if (d_coef) *d_coef = g->coef;
+    if (n_rows) *n_rows = g->n_rows;
+    if (nnz) *nnz = g->nnz;
+    return 0;
+}
+
+// ---------------------------------------------------------------- features
+int gcnhip_feat_create(gcnhip_ctx *c, gcnhip_feat **out, const int *h_indptr, const int *h_indices,
+                       const float *h_values, int n_rows, int n_cols) {
+    if (!c || !out || !h_indptr || !h_values || n_rows < 0 || n_cols <= 0) return -1;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    gcnhip_feat *f = new gcnhip_feat();
+    memset(f, 0, sizeof *f);
+    f->n_rows = n_rows; f->n_cols = n_cols;
+    const int64_t nnz = h_indptr[n_rows];
+    f->nnz = nnz;
+    // dense <=> every row is exactly 0..n_cols-1 in order (h_indices == NULL asserts it)
+    bool dense = (nnz == (int64_t)n_rows * n_cols) && n_rows > 0;
+    if (dense && h_indices) {
+        for (int r = 0; r < n_rows && dense; r++) {
+            if (h_indptr[r + 1] - h_indptr[r] != n_cols) { dense = false; break; }
+            const int *row = h_indices + (size_t)r * n_cols;
+            for (int k = 0; k < n_cols; k++)
+                if (row[k] != k) { dense = false; break; }
+        }
+    }
+    if (!h_indices && !dense) { delete f; return -1; }
+    f->dense = dense;
+    GCNHIP_TRY(hipMalloc((void **)&f->indptr, (size_t)(n_rows + 1) * sizeof(int)));
+    GCNHIP_TRY(hipMemcpy(f->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+    GCNHIP_TRY(hipMalloc((void **)&f->values, (size_t)std::max<int64_t>(nnz, 4) * sizeof(float)));
+    if (nnz) GCNHIP_TRY(hipMemcpy(f->values, h_values, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    if (!dense) {
+        for (int64_t e = 0; e < nnz; e++)
+            if (h_indices[e] < 0 || h_indices[e] >= n_cols) { return -1; }
+        GCNHIP_TRY(hipMalloc((void **)&f->indices, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
+        if (nnz) GCNHIP_TRY(hipMemcpy(f->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+        // CSC by counting sort; entries of a column stay in row order, so the
+        // gather-form weight gradient adds them in the reference's order
+        // (src/seq/module.cpp:68-74 visits rows ascending).
+        std::vector<int> ptr((size_t)n_cols + 1, 0), row((size_t)nnz), pos((size_t)nnz);
+        for (int64_t e = 0; e < nnz; e++) ptr[h_indices[e] + 1]++;
+        for (int k = 0; k < n_cols; k++) ptr[k + 1] += ptr[k];
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+        for (int r = 0; r < n_rows; r++)
+            for (int e = h_indptr[r]; e < h_indptr[r + 1]; e++) {
+                const int q = fill[h_indices[e]]++;
+                row[q] = r;
+                pos[q] = e;
+            }
+        GCNHIP_TRY(hipMalloc((void **)&f->csc_ptr, ptr.size() * sizeof(int)));
+        GCNHIP_TRY(hipMalloc((void **)&f->csc_row, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
+        GCNHIP_TRY(hipMalloc((void **)&f->csc_pos, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
+        GCNHIP_TRY(hipMemcpy(f->csc_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (nnz) {
+            GCNHIP_TRY(hipMemcpy(f->csc_row, row.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+            GCNHIP_TRY(hipMemcpy(f->csc_pos, pos.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    *out = f;
+    return 0;
+}
+
+int gcnhip_feat_destroy(gcnhip_ctx *c, gcnhip_feat *f) {
+    if (!f) return 0;
+    hipSetDevice(c->device);
+    hipFree(f->indptr); hipFree(f->values);
+    if (f->indices) hipFree(f->indices);
+    if (f->csc_ptr) hipFree(f->csc_ptr);
+    if (f->csc_row) hipFree(f->csc_row);
+    if (f->csc_pos) hipFree(f->csc_pos);
+    delete f;
+    return 0;
+}
+int gcnhip_feat_is_dense(const gcnhip_feat *f) { return f && f->dense ? 1 : 0; }
+float *gcnhip_feat_values(gcnhip_feat *f) { return f ? f->values : nullptr; }
+int64_t gcnhip_feat_nnz(const gcnhip_feat *f) { return f ? f->nnz : 0; }
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// dense_kernels.h — f32 MFMA building blocks shared by matmul.hip and spmm.hip.
+//
+// gfx950 has an exact-f32 matrix instruction, v_mfma_f32_16x16x4_f32 (one f32
+// VGPR per operand per lane; result bit-identical to a k-ordered fmaf chain).
+// Operand maps (cdna guide §3):  A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15],  D[row = 4*(lane>>4)+reg][col = lane&15].
+//
+// Two kernels:
+//  * gemm_rowstream: C[m x Nc] = A[m x K] . Bs[K x Nc], m huge, K and Nc small.
+//    Bs lives in LDS for the whole (persistent) workgroup; A streams from HBM
+//    once, 16 rows per wave step, 16 B per lane along K.  Serves Matmul
+//    forward (Bs = W2) and dA (Bs = W2^T), optional ReLU/dropout-backward
+//    epilogue.
+//  * gemm_atb: S[n x p] = A^T . Bm with the long dimension m as K.  Each wave
+//    is an independent split-K worker over a row range; a lane's vector load
+//    of VA (VB) consecutive columns feeds VA x VB MFMAs whose outputs are the
+//    column-interleaved 16x16 tiles {VA*i+s, VB*c+u}.  Workers write partial
+//    slabs; a second kernel sums them in worker order (bitwise reproducible,
+//    no float atomics — the reference's CUDA scatter races here,
+//    cuda_kernel.cu:112-122).  Serves dW2 = H1^T.dZ0 and dW1 = X~^T.dH0 for
+//    dense X, with the input dropout re-derived on the fly.
+#pragma once
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------ gemm_rowstream
+struct RowStreamArgs {
+    const float *A; int lda;
+    const float *B; int ldb; int transB;     // Bs[k][c] = transB ? B[c*ldb+k] : B[k*ldb+c]
+    float *C; int ldc;
+    int m, K, Nc;
+    // epilogue: C = H > 0 ? scale*C : 0
+    const float *H; int ldh; float scale;
+};
+
+template <int NT, bool VEC, bool FUSE>
+__global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];
+    constexpr int NCLD = NT * 16 + 4;        // +4: the four k-groups of a wave hit disjoint banks
+    const int Kp = (a.K + 15) / 16 * 16;
+    const int c_base = blockIdx.y * NT * 16;
+    for (int idx = threadIdx.x; idx < Kp * NT * 16; idx += blockDim.x) {
+        const int k = idx / (NT * 16), c = idx % (NT * 16);
+        const int gc = c_base + c;
+        float v = 0.f;
+        if (k < a.K && gc < a.Nc) v = a.transB ? a.B[(size_t)gc * a.ldb + k] : a.B[(size_t)k * a.ldb + gc];
+        Bs[k * NCLD + c] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int n_tiles = (a.m + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + li;
+        const bool valid = row < a.m;
+        const float *ap = a.A + (size_t)row * a.lda;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < Kp; k0 += 16) {
+            const int kk = k0 + 4 * kq;
+            float av[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid && kk < a.K) {
+                if (VEC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(ap + kk);
+                    av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) if (kk + s < a.K) av[s] = ap[kk + s];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++) if (kk + s >= a.K) av[s] = 0.f;   // pad columns may hold anything
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const float b = Bs[(kk + s) * NCLD + t * 16 + li];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int col = c_base + t * 16 + li;
+            if (col >= a.Nc) continue;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = tile * 16 + 4 * kq + i;
+                if (r >= a.m) continue;
+                float v = acc[t][i];
+                if (FUSE) v = a.H[(size_t)r * a.ldh + col] > 0.f ? v * a.scale : 0.f;
+                a.C[(size_t)r * a.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ gemm_atb
+struct AtbArgs {
+    const float *A; int lda;      // m x n
+    const float *Bm; int ldb;     // m x p
+    float *slab;                  // [workers][n][p_ld]
+    int m, n, p, p_ld;
+    int rows_per_worker, n_workers;
+    // dropout on A (the input dropout of a dense X): element index = row*n + col
+    int drop; int thr; float scale;
+    uint64_t seed, off; const uint32_t *d_epoch; const uint8_t *keep_mask;
+};
+
+template <int V>
+__device__ inline void load_vec(const float *p, int valid_cols, float out[V]) {
+    // p is aligned to V floats; valid_cols = how many of the V columns exist
+    if (valid_cols >= V) {
+        if (V == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+        else if (V == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); out[0] = v.x; out[1] = v.y; }
+        else out[0] = *p;
+    } else {
+#pragma unroll
+        for (int s = 0; s < V; s++) out[s] = s < valid_cols ? p[s] : 0.f;
+    }
+}
+
+template <int VA, int VB>
+__global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int worker = blockIdx.x * 4 + wave;
+    if (worker >= a.n_workers) return;
+    const int colA = blockIdx.y * 16 * VA + VA * li;       // this lane's first A column
+    const int colB = blockIdx.z * 16 * VB + VB * li;
+    const int r0 = worker * a.rows_per_worker;
+    const int r1 = min(a.m, r0 + a.rows_per_worker);
+    const uint32_t epoch = (a.drop && a.d_epoch) ? *a.d_epoch : 0u;
+    f32x4 acc[VA][VB];
+#pragma unroll
+    for (int s = 0; s < VA; s++)
+#pragma unroll
+        for (int u = 0; u < VB; u++) acc[s][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int validA = a.n - colA, validB = a.p - colB;
+#pragma unroll 2
+    for (int k0 = r0; k0 < r1; k0 += 4) {
+        const int row = k0 + kq;
+        float av[VA], bv[VB];
+#pragma unroll
+        for (int s = 0; s < VA; s++) av[s] = 0.f;
+#pragma unroll
+        for (int u = 0; u < VB; u++) bv[u] = 0.f;
+        if (row < r1) {
+            if (validA > 0) load_vec<VA>(a.A + (size_t)row * a.lda + colA, validA, av);
+            if (validB > 0) load_vec<VB>(a.Bm + (size_t)row * a.ldb + colB, validB, bv);
+            if (a.drop && validA > 0) {
+                const uint64_t e0 = (uint64_t)row * a.n + colA;
+                uint32_t bits = 0;
+                if (a.keep_mask) {
+#pragma unroll
+                    for (int s = 0; s < VA; s++) bits |= (s < validA && a.keep_mask[e0 + s] != 0 ? 1u : 0u) << s;
+                } else if (((a.off + e0) & (VA - 1)) == 0) {
+                    bits = keepv<VA>(a.off + e0, epoch, a.seed, a.thr);       // one Philox block for the vector
+                } else {
+#pragma unroll
+                    for (int s = 0; s < VA; s++) bits |= (keep1(a.off + e0 + s, epoch, a.seed, a.thr) ? 1u : 0u) << s;
+                }
+#pragma unroll
+                for (int s = 0; s < VA; s++) av[s] *= (bits >> s & 1u) ? a.scale : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < VA; s++)
+#pragma unroll
+            for (int u = 0; u < VB; u++)
+                acc[s][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[u], acc[s][u], 0, 0, 0);
+    }
+    // D_{s,u}[i][c] = S[blockA + VA*i + s][blockB + VB*c + u]
+    float *slab = a.slab + (size_t)worker * a.n * a.p_ld;
+#pragma unroll
+    for (int s = 0; s < VA; s++)
+#pragma unroll
+        for (int u = 0; u < VB; u++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int nidx = blockIdx.y * 16 * VA + VA * (4 * kq + reg) + s;
+                const int pidx = blockIdx.z * 16 * VB + VB * li + u;
+                if (nidx < a.n && pidx < a.p) slab[(size_t)nidx * a.p_ld + pidx] = acc[s][u][reg];
+            }
+}
+
+// out[nidx][pidx] = sum over workers, in worker order
+static __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *slab, int n_workers, int n, int p, int p_ld,
+                                                          float *out, int ld_out) {
+    const int64_t total = (int64_t)n * p;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / p), c = (int)(i % p);
+        const float *s = slab + (size_t)r * p_ld + c;
+        float acc = 0.f;
+        for (int w = 0; w < n_workers; w++) acc += s[(size_t)w * n * p_ld];
+        out[(size_t)r * ld_out + c] = acc;
+    }
+}
+
+static inline int ensure_slab(gcnhip_ctx *c, size_t bytes) {
+    if (c->slab_bytes >= bytes) return 0;
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->slab) GCNHIP_TRY(hipFree(c->slab));
+    c->slab = nullptr; c->slab_bytes = 0;
+    GCNHIP_TRY(hipMalloc((void **)&c->slab, bytes));
+    c->slab_bytes = bytes;
+    return 0;
+}
+
+// S[n x p] = A^T . Bm   (A: m x n, Bm: m x p), optional dropout on A
+static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, int ldb, float *out, int ld_out,
+                      int m, int n, int p, int drop, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                      uint64_t off, const uint8_t *keep_mask) {
+    AtbArgs a;
+    a.A = A; a.lda = lda; a.Bm = Bm; a.ldb = ldb;
+    a.m = m; a.n = n; a.p = p; a.p_ld = (p + 3) / 4 * 4;
+    a.drop = drop; a.thr = dropout_threshold(p_drop); a.scale = drop ? 1 / (1 - p_drop) : 1.f;
+    a.seed = seed; a.off = off; a.d_epoch = d_epoch; a.keep_mask = keep_mask;
+    const int VA = (lda % 4 == 0 && aligned16(A)) ? 4 : ((lda % 2 == 0 && ((uintptr_t)A & 7) == 0) ? 2 : 1);
+    const int VB = (ldb % 4 == 0 && aligned16(Bm)) ? 4 : ((ldb % 2 == 0 && ((uintptr_t)Bm & 7) == 0) ? 2 : 1);
+    const int gy = ceil_div(n, 16 * VA), gz = ceil_div(p, 16 * VB);
+    // enough split-K workers to fill the chip (~8 waves per CU), at least 64 rows each
+    int workers = ceil_div((int64_t)c->n_cu * 8, (int64_t)gy * gz);
+    if (workers > ceil_div(m, 64)) workers = ceil_div(m, 64);
+    if (workers < 1) workers = 1;
+    workers = (workers + 3) / 4 * 4;
+    a.rows_per_worker = (ceil_div(m, workers) + 3) / 4 * 4;
+    a.n_workers = ceil_div(m, a.rows_per_worker);
+    const int rc = ensure_slab(c, (size_t)a.n_workers * n * a.p_ld * sizeof(float));
+    if (rc) return rc;
+    a.slab = c->slab;
+    dim3 grid(ceil_div(a.n_workers, 4), gy, gz);
+#define ATB(VA_, VB_) gemm_atb_kernel<VA_, VB_><<<grid, 256, 0, c->stream>>>(a)
+    if (VA == 4 && VB == 4) ATB(4, 4);
+    else if (VA == 4 && VB == 2) ATB(4, 2);
+    else if (VA == 4 && VB == 1) ATB(4, 1);
+    else if (VA == 2 && VB == 4) ATB(2, 4);
+    else if (VA == 2 && VB == 2) ATB(2, 2);
+    else if (VA == 2 && VB == 1) ATB(2, 1);
+    else if (VA == 1 && VB == 4) ATB(1, 4);
+    else if (VA == 1 && VB == 2) ATB(1, 2);
+    else ATB(1, 1);
+#undef ATB
+    GCNHIP_LAUNCH_CHECK();
+    int rb = ceil_div((int64_t)n * p, 256);
+    if (rb > 2048) rb = 2048;
+    slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(a.slab, a.n_workers, n, p, a.p_ld, out, ld_out);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// C[m x Nc] = A[m x K] . Bs  (Bs from B, optionally transposed), optional epilogue
+static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float *B, int ldb, int transB,
+                            float *C, int ldc, int m, int K, int Nc, const float *H, int ldh, float scale) {
+    RowStreamArgs a;
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.transB = transB; a.C = C; a.ldc = ldc;
+    a.m = m; a.K = K; a.Nc = Nc; a.H = H; a.ldh = ldh; a.scale = scale;
+    const bool vec = lda % 4 == 0 && aligned16(A);
+    const int nt_total = ceil_div(Nc, 16);
+    const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 3 ? 4 : nt_total));
+    const int gy = ceil_div(nt_total, NT);
+    const int Kp = (K + 15) / 16 * 16;
+    const size_t lds = (size_t)Kp * (NT * 16 + 4) * sizeof(float);
+    if (lds > 156 * 1024) return -1;          // K too long for an LDS-resident operand (gfx950: 160 KiB per CU)
+    int gx = ceil_div(ceil_div(m, 16), 4);
+    const int cap = c->n_cu * (lds > 76 * 1024 ? 1 : (lds > 32 * 1024 ? 2 : 4));
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, gy);
+#define RS1(NT_, V_, F_)                                                                                  \
+    do {                                                                                                  \
+        auto kern = gemm_rowstream_kernel<NT_, V_, F_>;                                                   \
+        if (lds > 64 * 1024)                                                                              \
+            GCNHIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<grid, 256, lds, c->stream>>>(a);                                                           \
+    } while (0)
+#define RS(NT_)                                                                                           \
+    do {                                                                                                  \
+        if (H) {                                                                                          \
+            if (vec) RS1(NT_, true, true); else RS1(NT_, false, true);                                    \
+        } else {                                                                                          \
+            if (vec) RS1(NT_, true, false); else RS1(NT_, false, false);                                  \
+        }                                                                                                 \
+    } while (0)
+    switch (NT) {
+        case 1: RS(1); break;
+        case 2: RS(2); break;
+        case 3: RS(3); break;
+        case 4: RS(4); break;
+        default: RS(8); break;
+    }
+#undef RS
+#undef RS1
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,251 @@
+// elementwise.hip — ReLU, Dropout, set_truth, sum of squares, Adam and the
+// small device utilities.  All HBM-bound streaming kernels: 16-byte lane
+// accesses where alignment allows, grid capped at 2048 blocks with a
+// grid-stride loop (cdna guide, Guideline 11/13).  Reductions go through
+// per-block partials summed in block order by a one-block kernel, so every
+// result is bitwise reproducible (no float atomics).
+#include "common.h"
+
+static inline int stream_grid(int64_t n_items, int per_block) {
+    int64_t b = (n_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ ReLU
+// src/seq/module.cpp:175-194, src/cuda/cuda_kernel.cu:204-219
+__global__ __launch_bounds__(256) void relu_fwd_kernel(float *x, uint8_t *mask, int64_t n, int training) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = x[i];
+        const bool keep = v > 0.f;
+        if (training) mask[i] = keep ? 1 : 0;
+        if (!keep) x[i] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float *g, const uint8_t *mask, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (!mask[i]) g[i] = 0.f;
+}
+
+// --------------------------------------------------------------- Dropout
+// src/seq/module.cpp:207-233, src/cuda/cuda_kernel.cu:223-240
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(float *x, int32_t *mask, int64_t n, int thr, float scale,
+                                                          uint64_t seed, const uint32_t *d_epoch, uint64_t off,
+                                                          const uint8_t *keep_in) {
+    const uint32_t epoch = d_epoch ? *d_epoch : 0u;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool keep = keep_in ? keep_in[i] != 0 : keep1(off + (uint64_t)i, epoch, seed, thr);
+        x[i] *= keep ? scale : 0.f;
+        if (mask) mask[i] = keep ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(float *g, const int32_t *mask, int64_t n, float scale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        g[i] *= mask[i] ? scale : 0.f;
+}
+// fused ReLU+Dropout backward: the forward output h is > 0 exactly where both kept
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(float *g, int ldg, const float *h, int ldh,
+                                                               int n_rows, int dim, float scale) {
+    const int64_t total = (int64_t)n_rows * dim;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / dim;
+        const int c = (int)(i - r * dim);
+        float *gp = g + r * ldg + c;
+        *gp = h[r * ldh + c] > 0.f ? *gp * scale : 0.f;
+    }
+}
+
+// -------------------------------------------------------------- set_truth
+// src/seq/gcn.cpp:78-81, src/cuda/cuda_kernel.cu:283-288
+__global__ __launch_bounds__(256) void set_truth_kernel(int32_t *truth, const int32_t *split, const int32_t *label, int n, int s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) truth[i] = split[i] == s ? label[i] : -1;
+}
+
+// ------------------------------------------------------------ reductions
+__device__ inline float block_sum(float v, float *sh) {   // 256 threads
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *x, int64_t n, float *partial) {
+    __shared__ float sh[4];
+    // contiguous chunk per block: the summation tree is a function of n only
+    const int64_t chunk = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = min(n, b0 + chunk);
+    float acc = 0.f;
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) { const float v = x[i]; acc += v * v; }
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *partial, int n, float *out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// ------------------------------------------------------------------- Adam
+// src/seq/optim.cpp:24-37, src/cuda/cuda_kernel.cu:270-281
+struct AdamArgs {
+    gcnhip_adam_var v[4];
+    int64_t start[5];           // element offset of each variable in the fused index space
+    int n_vars;
+    float step_size, beta1, beta2, eps, wd;
+    const float *d_step_sizes;
+    const uint32_t *d_epoch;
+    float *partial;             // per-block sum of w0^2 after the update (or NULL)
+};
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    __shared__ float sh[4];
+    const float step = a.d_step_sizes ? a.d_step_sizes[*a.d_epoch] : a.step_size;
+    const double omb1 = 1.0 - (double)a.beta1, omb2 = 1.0 - (double)a.beta2;   // "(1.0 - beta)" in double
+    const int64_t total = a.start[a.n_vars];
+    const int64_t chunk = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = min(total, b0 + chunk);
+    float sq = 0.f;
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 4; q++) if (q < a.n_vars && i >= a.start[q]) k = q;
+        const gcnhip_adam_var &v = a.v[k];
+        const int64_t j = i - a.start[k];
+        float w = v.w[j];
+        float grad = v.g[j];
+        if (v.decay) grad += a.wd * w;
+        const float m = (float)((double)(a.beta1 * v.m[j]) + omb1 * (double)grad);
+        const float vv = (float)((double)(a.beta2 * v.v[j]) + omb2 * (double)grad * (double)grad);
+        v.m[j] = m;
+        v.v[j] = vv;
+        w -= step * m / (sqrtf(vv) + a.eps);
+        v.w[j] = w;
+        if (k == 0) sq += w * w;
+    }
+    if (a.partial) {
+        const float s = block_sum(sq, sh);
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+    }
+}
+
+// ----------------------------------------------------------- small utilities
+__global__ void counter_add_kernel(uint32_t *c, uint32_t inc) { *c += inc; }
+__global__ void metrics_record_kernel(float *ring, int capacity, int slot, const uint32_t *d_epoch,
+                                      const float *res, const int32_t *res_i, const float *sumsq) {
+    const uint32_t e = d_epoch ? *d_epoch : 0u;
+    float *row = ring + ((size_t)(e % (uint32_t)capacity) * 2 + slot) * 8;
+    row[0] = res[0];
+    row[1] = res[1];
+    row[2] = (float)res_i[0];
+    row[3] = (float)res_i[1];
+    row[4] = sumsq ? *sumsq : 0.f;
+    row[5] = (float)e;
+    row[6] = 0.f;
+    row[7] = 0.f;
+}
+
+extern "C" {
+
+int gcnhip_relu_fwd(gcnhip_ctx *c, float *x, uint8_t *mask, int64_t n, int training) {
+    if (!c || !x || (training && !mask)) return -1;
+    if (n <= 0) return 0;
+    relu_fwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(x, mask, n, training);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_relu_bwd(gcnhip_ctx *c, float *grad, const uint8_t *mask, int64_t n) {
+    if (!c || !grad || !mask) return -1;
+    if (n <= 0) return 0;
+    relu_bwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(grad, mask, n);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_dropout_fwd(gcnhip_ctx *c, float *x, int32_t *mask, int64_t n, float p,
+                       uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset, const uint8_t *keep_in) {
+    if (!c || !x || !(p >= 0.f && p < 1.f)) return -1;
+    if (n <= 0) return 0;
+    dropout_fwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(x, mask, n, dropout_threshold(p), 1 / (1 - p),
+                                                                    seed, d_epoch, elem_offset, keep_in);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_dropout_bwd(gcnhip_ctx *c, float *grad, const int32_t *mask, int64_t n, float p) {
+    if (!c || !grad) return -1;
+    if (!mask || n <= 0) return 0;               // module.cpp:224: no mask, no-op
+    dropout_bwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(grad, mask, n, 1 / (1 - p));
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_relu_dropout_bwd(gcnhip_ctx *c, float *grad, int ld_grad, const float *h, int ld_h,
+                            int n_rows, int dim, float scale) {
+    if (!c || !grad || !h || ld_grad < dim || ld_h < dim) return -1;
+    if (n_rows <= 0 || dim <= 0) return 0;
+    relu_dropout_bwd_kernel<<<stream_grid((int64_t)n_rows * dim, 1024), 256, 0, c->stream>>>(grad, ld_grad, h, ld_h, n_rows, dim, scale);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_set_truth(gcnhip_ctx *c, int32_t *truth, const int32_t *split, const int32_t *label, int n, int s) {
+    if (!c || !truth || !split || !label) return -1;
+    if (n <= 0) return 0;
+    set_truth_kernel<<<ceil_div(n, 256), 256, 0, c->stream>>>(truth, split, label, n, s);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_sumsq(gcnhip_ctx *c, const float *x, int64_t n, float *d_out) {
+    if (!c || !x || !d_out) return -1;
+    const int blocks = stream_grid(n, 4096) > 1024 ? 1024 : stream_grid(n, 4096);
+    sumsq_partial_kernel<<<blocks, 256, 0, c->stream>>>(x, n, c->red_f);
+    GCNHIP_LAUNCH_CHECK();
+    sum_partials_kernel<<<1, 256, 0, c->stream>>>(c->red_f, blocks, d_out);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_adam_step(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, float step_size,
+                     const float *d_step_sizes, const uint32_t *d_epoch,
+                     float beta1, float beta2, float eps, float weight_decay, float *d_sumsq) {
+    if (!c || !vars || n_vars < 1 || n_vars > 4) return -1;
+    if (d_step_sizes && !d_epoch) return -1;
+    AdamArgs a;
+    a.n_vars = n_vars;
+    a.start[0] = 0;
+    for (int k = 0; k < n_vars; k++) { a.v[k] = vars[k]; a.start[k + 1] = a.start[k] + vars[k].n; }
+    for (int k = n_vars; k < 4; k++) { a.v[k] = vars[0]; a.start[k + 1] = a.start[n_vars]; }
+    a.step_size = step_size; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.d_step_sizes = d_step_sizes; a.d_epoch = d_epoch;
+    int blocks = stream_grid(a.start[n_vars], 1024);
+    if (blocks > 1024) blocks = 1024;
+    a.partial = d_sumsq ? c->red_f + 1024 : nullptr;       // second quarter of the scratch
+    adam_kernel<<<blocks, 256, 0, c->stream>>>(a);
+    GCNHIP_LAUNCH_CHECK();
+    if (d_sumsq) {
+        sum_partials_kernel<<<1, 256, 0, c->stream>>>(a.partial, blocks, d_sumsq);
+        GCNHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+int gcnhip_counter_add(gcnhip_ctx *c, uint32_t *d_counter, uint32_t inc) {
+    if (!c || !d_counter) return -1;
+    counter_add_kernel<<<1, 1, 0, c->stream>>>(d_counter, inc);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_metrics_record(gcnhip_ctx *c, float *d_ring, int capacity, int slot_in_row,
+                          const uint32_t *d_epoch, const float *d_result, const int32_t *d_result_i,
+                          const float *d_sumsq) {
+    if (!c || !d_ring || capacity <= 0 || !d_result || !d_result_i || slot_in_row < 0 || slot_in_row > 1) return -1;
+    metrics_record_kernel<<<1, 1, 0, c->stream>>>(d_ring, capacity, slot_in_row, d_epoch, d_result, d_result_i, d_sumsq);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// graphsum.hip — CSR row-gather  out[r,:] = sum_e coef(e) * in[col(e),:]
+// (the reference's GraphSum forward AND backward: src/seq/module.cpp:83-119,
+//  src/cuda/cuda_kernel.cu:126-162).
+//
+// Bound: gather bandwidth (0.5 FLOP/B).  Design for gfx950:
+//  * one wave64 per row task; the wave reads 64 (index, coef) pairs with one
+//    coalesced load each and hands them to its lane groups by cross-lane
+//    shuffle, so the only per-edge memory instruction is the feature-row load;
+//  * a feature row is read with 16-byte lane loads: L = dim/4 lanes per row,
+//    64/L rows per wave instruction (d=128: 2 rows / 1 KiB per instruction),
+//    unrolled so 8 row loads per lane group are in flight;
+//  * partial sums of the lane groups are combined with wave shuffles (no LDS,
+//    no atomics) — results are bitwise reproducible run to run;
+//  * rows longer than SPLIT_EDGES are cut into segments processed by separate
+//    waves (heavy segments dispatched first) and summed in segment order by a
+//    small second kernel, so a hub row does not serialise the tail;
+//  * the ReLU + dropout of the first layer is an optional store epilogue.
+// The reference launches one block per row with `dim` threads and does a
+// global read-modify-write per edge (cuda_kernel.cu:126-143).
+#include "common.h"
+
+struct GsArgs {
+    const int *indptr, *indices;
+    const float *coef;
+    const int4 *tasks;
+    int n_tasks, n_rows;
+    const float *in;
+    float *out;
+    float *partials;
+    int ld_in, ld_out, part_ld, dim;
+    // epilogue
+    int fuse, training, thr;
+    float scale;
+    uint64_t seed, elem_offset;
+    const uint32_t *d_epoch;
+    const uint8_t *keep_mask;
+};
+
+__device__ inline float4 f4_fma(float c, float4 v, float4 a) {
+    a.x += c * v.x; a.y += c * v.y; a.z += c * v.z; a.w += c * v.w;
+    return a;
+}
+__device__ inline float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ inline float4 f4_shfl_xor(float4 v, int m) {
+    return make_float4(__shfl_xor(v.x, m, WAVE), __shfl_xor(v.y, m, WAVE), __shfl_xor(v.z, m, WAVE), __shfl_xor(v.w, m, WAVE));
+}
+
+// ReLU (module.cpp:179-181: keep = x > 0) then dropout on one float4 of row r
+__device__ inline float4 relu_dropout4(float4 v, const GsArgs &a, int64_t r, int col0) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = x[i] > 0.f ? x[i] : 0.f;
+    if (a.training) {
+        const uint32_t epoch = a.d_epoch ? *a.d_epoch : 0u;
+        const int64_t e0 = r * a.dim + col0;          // element index inside this matrix
+        uint32_t bits;
+        if (a.keep_mask) {
+            bits = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) bits |= (col0 + i < a.dim && a.keep_mask[e0 + i] ? 1u : 0u) << i;
+        } else {
+            const uint64_t j0 = a.elem_offset + (uint64_t)e0;
+            if ((j0 & 3) == 0) {
+                bits = keep4(j0 >> 2, epoch, a.seed, a.thr);
+            } else {
+                bits = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) bits |= (keep1(j0 + i, epoch, a.seed, a.thr) ? 1u : 0u) << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] *= (bits >> i & 1u) ? a.scale : 0.f;   // module.cpp:216
+    }
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+// L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
+template <int L>
+__global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
+    constexpr int G = WAVE / L;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nt = a.n_tasks ? a.n_tasks : a.n_rows;
+    if (t >= nt) return;                                   // wave-uniform
+    int row, e0, e1, slot;
+    if (a.n_tasks) {
+        const int4 tk = a.tasks[t];
+        row = tk.x; e0 = tk.y; e1 = tk.z; slot = tk.w;
+    } else {
+        row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
+    }
+    const int g = lane / L, l = lane % L;
+    const int col0 = (blockIdx.y * L + l) * 4;             // first column of this lane's float4
+    const bool active = col0 < a.dim;
+    const float *in = a.in + col0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = e0; base < e1; base += WAVE) {
+        const int cnt = min(WAVE, e1 - base);
+        int my_idx = 0;
+        float my_c = 0.f;
+        if (lane < cnt) { my_idx = a.indices[base + lane]; my_c = a.coef[base + lane]; }
+        const int iters = (cnt + G - 1) / G;
+#pragma unroll 8
+        for (int k = 0; k < iters; k++) {
+            const int src = k * G + g;
+            const int j = __shfl(my_idx, src, WAVE);
+            const float c = __shfl(my_c, src, WAVE);
+            if (active && src < cnt) {                     // a padded lane must not touch memory: 0 * Inf = NaN
+                const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld_in);
+                acc = f4_fma(c, v, acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+    if (g == 0 && active) {
+        if (slot >= 0) {
+            *reinterpret_cast<float4 *>(a.partials + (size_t)slot * a.part_ld + col0) = acc;
+        } else {
+            if (a.fuse) acc = relu_dropout4(acc, a, row, col0);
+            float *o = a.out + (size_t)row * a.ld_out + col0;
+            if (col0 + 4 <= a.dim) {
+                *reinterpret_cast<float4 *>(o) = acc;
+            } else {                                       // ragged tail: dim % 4 != 0
+                const float x[4] = {acc.x, acc.y, acc.z, acc.w};
+                for (int i = 0; col0 + i < a.dim; i++) o[i] = x[i];
+            }
+        }
+    }
+}
+
+// Any ld / alignment: scalar loads, lane l owns columns l, l+L, ...
+template <int L>
+__global__ __launch_bounds__(256) void graphsum_scalar_kernel(GsArgs a) {
+    constexpr int G = WAVE / L;
+    constexpr int MAXC = 4;                                // columns per lane per pass
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nt = a.n_tasks ? a.n_tasks : a.n_rows;
+    if (t >= nt) return;
+    int row, e0, e1, slot;
+    if (a.n_tasks) {
+        const int4 tk = a.tasks[t];
+        row = tk.x; e0 = tk.y; e1 = tk.z; slot = tk.w;
+    } else {
+        row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
+    }
+    const int g = lane / L, l = lane % L;
+    for (int cbase = 0; cbase < a.dim; cbase += L * MAXC) {
+        float acc[MAXC] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = e0; base < e1; base += WAVE) {
+            const int cnt = min(WAVE, e1 - base);
+            int my_idx = 0;
+            float my_c = 0.f;
+            if (lane < cnt) { my_idx = a.indices[base + lane]; my_c = a.coef[base + lane]; }
+            const int iters = (cnt + G - 1) / G;
+#pragma unroll 4
+            for (int k = 0; k < iters; k++) {
+                const int src = k * G + g;
+                const int j = __shfl(my_idx, src, WAVE);
+                const float c = __shfl(my_c, src, WAVE);
+                const float *p = a.in + (size_t)j * a.ld_in + cbase + l;
+                if (src < cnt) {
+#pragma unroll
+                    for (int q = 0; q < MAXC; q++)
+                        if (cbase + l + q * L < a.dim) acc[q] += c * p[q * L];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXC; q++) {
+#pragma unroll
+            for (int m = L; m < WAVE; m <<= 1) acc[q] += __shfl_xor(acc[q], m, WAVE);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int q = 0; q < MAXC; q++) {
+                const int col = cbase + l + q * L;
+                if (col >= a.dim) continue;
+                float v = acc[q];
+                if (slot >= 0) {
+                    a.partials[(size_t)slot * a.part_ld + col] = v;
+                } else {
+                    if (a.fuse) {
+                        v = v > 0.f ? v : 0.f;
+                        if (a.training) {
+                            const int64_t e = (int64_t)row * a.dim + col;
+                            const bool keep = a.keep_mask ? a.keep_mask[e] != 0
+                                                          : keep1(a.elem_offset + (uint64_t)e, a.d_epoch ? *a.d_epoch : 0u, a.seed, a.thr);
+                            v *= keep ? a.scale : 0.f;
+                        }
+                    }
+                    a.out[(size_t)row * a.ld_out + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// sum the segment partials of each split row in segment order, apply the epilogue
+__global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const int4 *split_rows, int n_split_rows) {
+    const int s = blockIdx.x;
+    if (s >= n_split_rows) return;
+    const int4 sr = split_rows[s];
+    const int row = sr.x, first = sr.y, ns = sr.z;
+    for (int col = threadIdx.x; col < a.dim; col += blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < ns; k++) v += a.partials[(size_t)(first + k) * a.part_ld + col];
+        if (a.fuse) {
+            v = v > 0.f ? v : 0.f;
+            if (a.training) {
+                const int64_t e = (int64_t)row * a.dim + col;
+                const bool keep = a.keep_mask ? a.keep_mask[e] != 0
+                                              : keep1(a.elem_offset + (uint64_t)e, a.d_epoch ? *a.d_epoch : 0u, a.seed, a.thr);
+                v *= keep ? a.scale : 0.f;
+            }
+        }
+        a.out[(size_t)row * a.ld_out + col] = v;
+    }
+}
+
+template <int L>
+static void launch_vec(const GsArgs &a, int nt, hipStream_t s) {
+    const int ychunks = ceil_div(a.dim, L * 4);
+    dim3 grid(ceil_div(nt, 4), ychunks);
+    graphsum_vec_kernel<L><<<grid, 256, 0, s>>>(a);
+}
+template <int L>
+static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
+    graphsum_scalar_kernel<L><<<ceil_div(nt, 4), 256, 0, s>>>(a);
+}
+
+static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in, float *out, int ld_out,
+                         int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
+                         uint64_t elem_offset, const uint8_t *keep_mask) {
+    if (!c || !g || !in || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
+    if (g->n_rows == 0) return 0;
+    gcnhip_graph *gm = const_cast<gcnhip_graph *>(g);
+    if (g->n_tasks && g->part_ld < dim) {      // first call at this width: size the segment scratch
+        GCNHIP_TRY(hipStreamSynchronize(c->stream));
+        if (gm->partials) GCNHIP_TRY(hipFree(gm->partials));
+        gm->part_ld = (dim + 3) / 4 * 4;
+        if (gm->part_ld < 256) gm->part_ld = 256;
+        GCNHIP_TRY(hipMalloc((void **)&gm->partials, (size_t)g->n_slots * gm->part_ld * sizeof(float)));
+    }
+    GsArgs a;
+    a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
+    a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows;
+    a.in = in; a.out = out; a.partials = g->partials;
+    a.ld_in = ld_in; a.ld_out = ld_out; a.part_ld = g->part_ld; a.dim = dim;
+    a.fuse = fuse; a.training = training; a.thr = dropout_threshold(p);
+    a.scale = 1 / (1 - p);                                  // module.cpp:212
+    a.seed = seed; a.elem_offset = elem_offset; a.d_epoch = d_epoch; a.keep_mask = keep_mask;
+    const int nt = g->n_tasks ? g->n_tasks : g->n_rows;
+    const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
+    const int d4 = (dim + 3) / 4;
+    if (vec) {
+        if (d4 <= 1) launch_vec<1>(a, nt, c->stream);
+        else if (d4 <= 2) launch_vec<2>(a, nt, c->stream);
+        else if (d4 <= 4) launch_vec<4>(a, nt, c->stream);
+        else if (d4 <= 8) launch_vec<8>(a, nt, c->stream);
+        else if (d4 <= 16) launch_vec<16>(a, nt, c->stream);
+        else if (d4 <= 32) launch_vec<32>(a, nt, c->stream);
+        else launch_vec<64>(a, nt, c->stream);
+    } else {
+        if (dim <= 1) launch_scalar<1>(a, nt, c->stream);
+        else if (dim <= 2) launch_scalar<2>(a, nt, c->stream);
+        else if (dim <= 4) launch_scalar<4>(a, nt, c->stream);
+        else if (dim <= 8) launch_scalar<8>(a, nt, c->stream);
+        else if (dim <= 16) launch_scalar<16>(a, nt, c->stream);
+        else if (dim <= 32) launch_scalar<32>(a, nt, c->stream);
+        else launch_scalar<64>(a, nt, c->stream);
+    }
+    GCNHIP_LAUNCH_CHECK();
+    if (g->n_split_rows) {
+        graphsum_finalize_kernel<<<g->n_split_rows, 256, 0, c->stream>>>(a, g->split_rows, g->n_split_rows);
+        GCNHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" {
+
+int gcnhip_graphsum(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
+                    float *out, int ld_out, int dim) {
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr);
+}
+
+int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
+                                 float *out, int ld_out, int dim, int training, float p,
+                                 uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
+                                 const uint8_t *keep_mask) {
+    if (training && !(p >= 0.f && p < 1.f)) return -1;
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 1, training, p, seed, d_epoch, elem_offset, keep_mask);
+}
+
+}  // extern "C"

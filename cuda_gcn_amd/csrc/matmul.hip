@@ -1,0 +1,50 @@
+// matmul.hip — Matmul forward / backward (src/seq/module.cpp:11-42; the
+// reference's 32x32 shared-memory tiles: src/cuda/cuda_kernel.cu:6-96, whose
+// dB kernel runs 8 blocks that each loop over all N rows serially).
+// All three products are HBM-bound here (N x 128 and N x 41 operands, 21 KB of
+// weights): the small operand sits in LDS, the long one streams once through
+// exact-f32 MFMA tiles (dense_kernels.h).
+#include "dense_kernels.h"
+
+extern "C" {
+
+int gcnhip_matmul_fwd(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                      float *cc, int ldc, int m, int n, int p) {
+    if (!c || !a || !b || !cc || m < 0 || n <= 0 || p <= 0 || lda < n || ldb < p || ldc < p) return -1;
+    if (m == 0) return 0;
+    return launch_rowstream(c, a, lda, b, ldb, 0, cc, ldc, m, n, p, nullptr, 0, 1.f);
+}
+
+static int matmul_bwd_impl(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                           const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                           int m, int n, int p, int fused, float scale) {
+    if (!c || !a || !b || !dc || m < 0 || n <= 0 || p <= 0 || lda < n || ldb < p || lddc < p) return -1;
+    if ((da && ldda < n) || (db && lddb < p)) return -1;
+    if (m == 0) {
+        if (db) for (int j = 0; j < n; j++) GCNHIP_TRY(hipMemsetAsync(db + (size_t)j * lddb, 0, p * sizeof(float), c->stream));
+        return 0;
+    }
+    if (db) {                                 // db = a^T . dc, module.cpp:35 (a is still the forward input here)
+        const int rc = launch_atb(c, a, lda, dc, lddc, db, lddb, m, n, p, 0, 0.f, 0, nullptr, 0, nullptr);
+        if (rc) return rc;
+    }
+    if (da) {                                 // da = dc . b^T, module.cpp:34,37
+        const int rc = launch_rowstream(c, dc, lddc, b, ldb, 1, da, ldda, m, p, n, fused ? a : nullptr, lda, scale);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int gcnhip_matmul_bwd(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                      const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                      int m, int n, int p) {
+    return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, da, ldda, db, lddb, m, n, p, 0, 1.f);
+}
+
+int gcnhip_matmul_bwd_fused(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                            const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                            int m, int n, int p, float relu_dropout_scale) {
+    return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, da, ldda, db, lddb, m, n, p, 1, relu_dropout_scale);
+}
+
+}  // extern "C"

@@ -1,0 +1,380 @@
+// spmm.hip — SparseMatmul: H0 = X~ . W1 and dW1 = X~^T . dH0
+// (src/seq/module.cpp:47-77; CUDA: cuda_kernel.cu:100-122, whose backward is a
+// racy scatter).  X~ = X with the input dropout applied on the fly, so the
+// pristine X stays resident and is never re-uploaded (the reference copies
+// all of X host->device twice per epoch, cuda_gcn.cu:81-83).
+//
+// Two regimes, chosen once in gcnhip_feat_create:
+//  * sparse X (Cora/Citeseer/Pubmed-like): HBM/L2-bound CSR row gather of W1
+//    rows forward, CSC gather of dH0 rows backward (deterministic, no atomics);
+//  * dense X stored as CSR (Reddit: every row has all 602 columns): an
+//    LDS-tiled exact-f32 MFMA GEMM forward, split-K MFMA A^T.B backward
+//    (dense_kernels.h).  Treating it as a gather would move nnz*h*4 bytes
+//    (72 GB) through L2 instead of 0.56 GB from HBM.
+#include "dense_kernels.h"
+
+struct DropSpec {
+    int on, thr;
+    float scale;
+    uint64_t seed, off;
+    const uint32_t *d_epoch;
+    const uint8_t *keep_mask;
+};
+
+__device__ inline float drop_scale(const DropSpec &d, uint64_t e, uint32_t epoch) {
+    if (!d.on) return 1.f;
+    const bool keep = d.keep_mask ? d.keep_mask[e] != 0 : keep1(d.off + e, epoch, d.seed, d.thr);
+    return keep ? d.scale : 0.f;
+}
+
+// ------------------------------------------------------------ sparse forward
+// one wave per row of X; L lanes (float4 each) per row of W
+struct SpFwdArgs {
+    const int *indptr, *indices;
+    const float *vals, *w;
+    float *out;
+    int n_rows, ld_w, ld_out, p;
+    DropSpec d;
+};
+
+template <int L, bool VEC>
+__global__ __launch_bounds__(256) void spmm_csr_fwd_kernel(SpFwdArgs a) {
+    constexpr int G = WAVE / L;
+    constexpr int V = VEC ? 4 : 1;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int g = lane / L, l = lane % L;
+    const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
+    const int e0 = a.indptr[row], e1 = a.indptr[row + 1];
+    for (int cb = blockIdx.y * L * V; cb < a.p; cb += gridDim.y * L * V) {
+        const int col0 = cb + l * V;
+        const bool active = col0 < a.p;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) acc[i] = 0.f;
+        for (int base = e0; base < e1; base += WAVE) {
+            const int cnt = min(WAVE, e1 - base);
+            int my_idx = 0;
+            float my_v = 0.f;
+            if (lane < cnt) {
+                my_idx = a.indices[base + lane];
+                my_v = a.vals[base + lane] * drop_scale(a.d, (uint64_t)(base + lane), epoch);
+            }
+            const int iters = (cnt + G - 1) / G;
+#pragma unroll 4
+            for (int k = 0; k < iters; k++) {
+                const int src = k * G + g;
+                const int j = __shfl(my_idx, src, WAVE);
+                const float c = __shfl(my_v, src, WAVE);
+                if (active && src < cnt) {
+                    const float *wp = a.w + (size_t)j * a.ld_w + col0;
+                    if (VEC) {
+                        const float4 v = *reinterpret_cast<const float4 *>(wp);
+                        acc[0] += c * v.x; acc[1 % V] += c * v.y; acc[2 % V] += c * v.z; acc[3 % V] += c * v.w;
+                    } else {
+                        acc[0] += c * wp[0];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; i++)
+#pragma unroll
+            for (int m = L; m < WAVE; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
+        if (g == 0 && active) {
+            float *o = a.out + (size_t)row * a.ld_out + col0;
+#pragma unroll
+            for (int i = 0; i < V; i++)
+                if (col0 + i < a.p) o[i] = acc[i];
+        }
+    }
+}
+
+// ----------------------------------------------------------- sparse backward
+// one wave per column j of X (row j of dW): dW[j,:] = sum_q X~[pos q] * dout[row q,:]
+struct SpBwdArgs {
+    const int *csc_ptr, *csc_row, *csc_pos;
+    const float *vals, *dout;
+    float *dw;
+    int n_cols, ld_dout, ld_dw, p;
+    DropSpec d;
+};
+
+template <int L, bool VEC>
+__global__ __launch_bounds__(256) void spmm_csc_bwd_kernel(SpBwdArgs a) {
+    constexpr int G = WAVE / L;
+    constexpr int V = VEC ? 4 : 1;
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= a.n_cols) return;
+    const int g = lane / L, l = lane % L;
+    const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
+    const int q0 = a.csc_ptr[col], q1 = a.csc_ptr[col + 1];
+    for (int cb = blockIdx.y * L * V; cb < a.p; cb += gridDim.y * L * V) {
+        const int col0 = cb + l * V;
+        const bool active = col0 < a.p;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) acc[i] = 0.f;
+        for (int base = q0; base < q1; base += WAVE) {
+            const int cnt = min(WAVE, q1 - base);
+            int my_row = 0;
+            float my_v = 0.f;
+            if (lane < cnt) {
+                my_row = a.csc_row[base + lane];
+                const int pos = a.csc_pos[base + lane];
+                my_v = a.vals[pos] * drop_scale(a.d, (uint64_t)pos, epoch);
+            }
+            const int iters = (cnt + G - 1) / G;
+#pragma unroll 4
+            for (int k = 0; k < iters; k++) {
+                const int src = k * G + g;
+                const int j = __shfl(my_row, src, WAVE);
+                const float c = __shfl(my_v, src, WAVE);
+                if (active && src < cnt) {
+                    const float *dp = a.dout + (size_t)j * a.ld_dout + col0;
+                    if (VEC) {
+                        const float4 v = *reinterpret_cast<const float4 *>(dp);
+                        acc[0] += c * v.x; acc[1 % V] += c * v.y; acc[2 % V] += c * v.z; acc[3 % V] += c * v.w;
+                    } else {
+                        acc[0] += c * dp[0];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; i++)
+#pragma unroll
+            for (int m = L; m < WAVE; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
+        if (g == 0 && active) {
+            float *o = a.dw + (size_t)col * a.ld_dw + col0;
+#pragma unroll
+            for (int i = 0; i < V; i++)
+                if (col0 + i < a.p) o[i] = acc[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------- dense forward
+// out[m x p] = X~[m x K] . W[K x p].  Workgroup tile 128 rows x (NT*16) cols,
+// K in chunks of 32 through LDS; wave w owns rows 32w..32w+31 (2 x NT MFMA
+// accumulators).  The next chunk is fetched into registers while the current
+// one is multiplied (global -> reg -> LDS, write after the barrier).
+struct DenseFwdArgs {
+    const float *x; int ldx;        // m x K, row stride ldx (602 for Reddit: 8-byte aligned rows)
+    const float *w; int ldw;
+    float *out; int ldo;
+    int m, K, p;
+    DropSpec d;
+};
+
+constexpr int DF_BM = 128, DF_BK = 32;
+constexpr int DF_ALD = DF_BK + 2;       // A tile row stride: 2*i + kq banks, conflict-free b32 reads
+
+template <int NT, int VX>
+__global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
+    constexpr int BN = NT * 16;
+    constexpr int BLD = BN + 16;        // B tile row stride: k-groups 16 banks apart
+    __shared__ __attribute__((aligned(16))) float As[DF_BM * DF_ALD];
+    __shared__ __attribute__((aligned(16))) float Bs[DF_BK * BLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int row_base = blockIdx.x * DF_BM;
+    const int col_base = blockIdx.y * BN;
+    const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
+
+    // staging maps.  A: 128 x 32 floats = 4096; VX floats per lane per piece.
+    constexpr int A_PIECES = DF_BM * DF_BK / (256 * VX);
+    constexpr int LPR = DF_BK / VX;                       // lanes per A row
+    float areg[A_PIECES][VX];
+    // B: 32 x BN floats, 4 per lane per piece (W rows are 16-byte aligned when ldw % 4 == 0; else scalar)
+    constexpr int B_PIECES = (DF_BK * BN + 1023) / 1024;
+    float breg[B_PIECES][4];
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 256 + tid;
+            const int r = idx / LPR, c = (idx % LPR) * VX;
+            const int row = row_base + r, col = k0 + c;
+#pragma unroll
+            for (int s = 0; s < VX; s++) areg[pc][s] = 0.f;
+            if (row < a.m && col < a.K) {
+                load_vec<VX>(a.x + (size_t)row * a.ldx + col, a.K - col, areg[pc]);
+                if (a.d.on) {
+                    const uint64_t e = (uint64_t)row * a.K + col;
+                    uint32_t bits = 0;
+                    if (a.d.keep_mask) {
+#pragma unroll
+                        for (int s = 0; s < VX; s++) bits |= (col + s < a.K && a.d.keep_mask[e + s] != 0 ? 1u : 0u) << s;
+                    } else if (((a.d.off + e) & (VX - 1)) == 0) {
+                        bits = keepv<VX>(a.d.off + e, epoch, a.d.seed, a.d.thr);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < VX; s++) bits |= (keep1(a.d.off + e + s, epoch, a.d.seed, a.d.thr) ? 1u : 0u) << s;
+                    }
+#pragma unroll
+                    for (int s = 0; s < VX; s++) areg[pc][s] *= (bits >> s & 1u) ? a.d.scale : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int pc = 0; pc < B_PIECES; pc++) {
+            const int idx = (pc * 256 + tid) * 4;
+            const int k = idx / BN, c = idx % BN;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int gk = k0 + k, gc = col_base + c + s;
+                breg[pc][s] = (k < DF_BK && gk < a.K && gc < a.p) ? a.w[(size_t)gk * a.ldw + gc] : 0.f;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 256 + tid;
+            const int r = idx / LPR, c = (idx % LPR) * VX;
+#pragma unroll
+            for (int s = 0; s < VX; s++) As[r * DF_ALD + c + s] = areg[pc][s];
+        }
+#pragma unroll
+        for (int pc = 0; pc < B_PIECES; pc++) {
+            const int idx = (pc * 256 + tid) * 4;
+            const int k = idx / BN, c = idx % BN;
+            if (k < DF_BK) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) Bs[k * BLD + c + s] = breg[pc][s];
+            }
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    for (int k0 = 0; k0 < a.K; k0 += DF_BK) {
+        __syncthreads();                 // previous chunk fully consumed
+        stash();
+        __syncthreads();
+        if (k0 + DF_BK < a.K) fetch(k0 + DF_BK);
+#pragma unroll
+        for (int kk = 0; kk < DF_BK; kk += 4) {
+            float af[2], bf[NT];
+#pragma unroll
+            for (int r = 0; r < 2; r++) af[r] = As[(wave * 32 + r * 16 + li) * DF_ALD + kk + kq];
+#pragma unroll
+            for (int t = 0; t < NT; t++) bf[t] = Bs[(kk + kq) * BLD + t * 16 + li];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bf[t], acc[r][t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int col = col_base + t * 16 + li;
+            if (col >= a.p) continue;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = row_base + wave * 32 + r * 16 + 4 * kq + i;
+                if (row < a.m) a.out[(size_t)row * a.ldo + col] = acc[r][t][i];
+            }
+        }
+}
+
+static DropSpec make_drop(float p_drop, uint64_t seed, const uint32_t *d_epoch, uint64_t off, const uint8_t *keep_mask) {
+    DropSpec d;
+    d.on = p_drop > 0.f || keep_mask != nullptr;
+    d.thr = dropout_threshold(p_drop);
+    d.scale = 1 / (1 - p_drop);
+    d.seed = seed; d.off = off; d.d_epoch = d_epoch; d.keep_mask = keep_mask;
+    return d;
+}
+
+template <int NT>
+static void launch_dense_fwd(const DenseFwdArgs &a, int vx, dim3 grid, hipStream_t s) {
+    if (vx == 4) spmm_dense_fwd_kernel<NT, 4><<<grid, 256, 0, s>>>(a);
+    else if (vx == 2) spmm_dense_fwd_kernel<NT, 2><<<grid, 256, 0, s>>>(a);
+    else spmm_dense_fwd_kernel<NT, 1><<<grid, 256, 0, s>>>(a);
+}
+
+extern "C" {
+
+int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
+                    float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                    uint64_t nnz_offset, const uint8_t *keep_mask) {
+    if (!c || !f || !vals || !w || !out || p <= 0 || ld_w < p || ld_out < p) return -1;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
+    if (f->n_rows == 0) return 0;
+    const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
+    if (f->dense) {
+        DenseFwdArgs a;
+        a.x = vals; a.ldx = f->n_cols; a.w = w; a.ldw = ld_w; a.out = out; a.ldo = ld_out;
+        a.m = f->n_rows; a.K = f->n_cols; a.p = p; a.d = d;
+        const int vx = (f->n_cols % 4 == 0 && aligned16(vals)) ? 4 : ((f->n_cols % 2 == 0 && ((uintptr_t)vals & 7) == 0) ? 2 : 1);
+        const int nt_total = ceil_div(p, 16);
+        const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 2 ? 4 : nt_total));
+        dim3 grid(ceil_div(f->n_rows, DF_BM), ceil_div(nt_total, NT));
+        switch (NT) {
+            case 1: launch_dense_fwd<1>(a, vx, grid, c->stream); break;
+            case 2: launch_dense_fwd<2>(a, vx, grid, c->stream); break;
+            case 4: launch_dense_fwd<4>(a, vx, grid, c->stream); break;
+            default: launch_dense_fwd<8>(a, vx, grid, c->stream); break;
+        }
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    SpFwdArgs a;
+    a.indptr = f->indptr; a.indices = f->indices; a.vals = vals; a.w = w; a.out = out;
+    a.n_rows = f->n_rows; a.ld_w = ld_w; a.ld_out = ld_out; a.p = p; a.d = d;
+    const bool vec = ld_w % 4 == 0 && aligned16(w);
+    const int units = vec ? (p + 3) / 4 : p;              // lanes needed for one row of W
+    dim3 grid(ceil_div(f->n_rows, 4), 1);
+#define SPF(L_)                                                                           \
+    do {                                                                                  \
+        if (vec) spmm_csr_fwd_kernel<L_, true><<<grid, 256, 0, c->stream>>>(a);           \
+        else spmm_csr_fwd_kernel<L_, false><<<grid, 256, 0, c->stream>>>(a);              \
+    } while (0)
+    if (units <= 1) SPF(1); else if (units <= 2) SPF(2); else if (units <= 4) SPF(4);
+    else if (units <= 8) SPF(8); else if (units <= 16) SPF(16); else if (units <= 32) SPF(32); else SPF(64);
+#undef SPF
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
+                    float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                    uint64_t nnz_offset, const uint8_t *keep_mask) {
+    if (!c || !f || !vals || !dout || !dw || p <= 0 || ld_dout < p || ld_dw < p) return -1;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
+    const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
+    if (f->dense)
+        return launch_atb(c, vals, f->n_cols, dout, ld_dout, dw, ld_dw, f->n_rows, f->n_cols, p,
+                          d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask);
+    SpBwdArgs a;
+    a.csc_ptr = f->csc_ptr; a.csc_row = f->csc_row; a.csc_pos = f->csc_pos;
+    a.vals = vals; a.dout = dout; a.dw = dw;
+    a.n_cols = f->n_cols; a.ld_dout = ld_dout; a.ld_dw = ld_dw; a.p = p; a.d = d;
+    const bool vec = ld_dout % 4 == 0 && aligned16(dout);
+    const int units = vec ? (p + 3) / 4 : p;
+    dim3 grid(ceil_div(f->n_cols, 4), 1);
+#define SPB(L_)                                                                           \
+    do {                                                                                  \
+        if (vec) spmm_csc_bwd_kernel<L_, true><<<grid, 256, 0, c->stream>>>(a);           \
+        else spmm_csc_bwd_kernel<L_, false><<<grid, 256, 0, c->stream>>>(a);              \
+    } while (0)
+    if (units <= 1) SPB(1); else if (units <= 2) SPB(2); else if (units <= 4) SPB(4);
+    else if (units <= 8) SPB(8); else if (units <= 16) SPB(16); else if (units <= 32) SPB(32); else SPB(64);
+#undef SPB
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

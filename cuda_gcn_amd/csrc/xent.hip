@@ -1,0 +1,197 @@
+// xent.hip — softmax cross-entropy + accuracy in one pass over the logits.
+// Reference: CrossEntropyLoss::forward (src/seq/module.cpp:124-161) and
+// GCN::get_accuracy (src/seq/gcn.cpp:83-96); CUDA twins cuda_kernel.cu:166-200
+// (one THREAD per block) and cuda_gcn.cu:100-120 (38 MB D2H + host loop).
+// Here: one wave64 per row (lane j holds logit j; C > 64 loops), wave-shuffle
+// max / sum, per-block partials reduced in block order (bitwise reproducible).
+#include "common.h"
+#pragma clang fp contract(off)
+
+struct XentArgs {
+    float *logits;
+    float *grad;
+    const int32_t *truth;
+    int ld, ld_grad, n_rows, C;
+    int training, shift, acc_only;
+    int count;                 // > 0: known number of labelled rows
+    const int32_t *d_count;    // else read here
+    float *part_f;             // [blocks] loss partials
+    int32_t *part_i;           // [blocks*2] {correct, total}
+};
+
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+constexpr int XENT_MAXC_REG = 4;     // up to 256 classes held in registers
+
+__global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
+    __shared__ float sh_f[4];
+    __shared__ int sh_i[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * 4;
+    const int rows_per_wave = (a.n_rows + waves_total - 1) / waves_total;
+    const int gw = blockIdx.x * 4 + wave;
+    const int r0 = gw * rows_per_wave, r1 = min(a.n_rows, r0 + rows_per_wave);
+    const float cnt = (float)(a.count > 0 ? a.count : (a.d_count ? *a.d_count : 0));
+    float loss = 0.f;
+    int correct = 0, total = 0;
+    for (int r = r0; r < r1; r++) {
+        const int t = a.truth[r];
+        float *lg = a.logits + (size_t)r * a.ld;
+        float *gr = a.grad ? a.grad + (size_t)r * a.ld_grad : nullptr;
+        if (t < 0) {                                   // unlabelled: grad row stays 0 (module.cpp:129,132)
+            if (a.training && gr)
+                for (int j = lane; j < a.C; j += WAVE) gr[j] = 0.f;
+            continue;
+        }
+        total++;
+        float v[XENT_MAXC_REG];
+        float mx = -1e30f;                             // module.cpp:135
+#pragma unroll
+        for (int q = 0; q < XENT_MAXC_REG; q++) {
+            const int j = lane + q * WAVE;
+            v[q] = j < a.C ? lg[j] : -INFINITY;
+            if (j < a.C) mx = fmaxf(mx, v[q]);
+        }
+        mx = wave_max(mx);
+        // the true logit, fetched from the lane that holds it
+        float tv = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < XENT_MAXC_REG; q++)
+            if (t / WAVE == q) tv = __shfl(v[q], t % WAVE, WAVE);
+        // gcn.cpp:88-93: wrong iff some logit is strictly above the true one
+        if (!(mx > tv)) correct++;
+        if (a.acc_only) continue;
+        float se = 0.f;
+        float ex[XENT_MAXC_REG];
+#pragma unroll
+        for (int q = 0; q < XENT_MAXC_REG; q++) {
+            const int j = lane + q * WAVE;
+            v[q] -= mx;                                // module.cpp:140
+            ex[q] = j < a.C ? expf(v[q]) : 0.f;
+            se += ex[q];
+            if (a.shift && j < a.C) lg[j] = v[q];
+        }
+        se = wave_sum(se);
+        loss += logf(se) - (tv - mx);                  // module.cpp:143
+        if (a.training && gr) {
+#pragma unroll
+            for (int q = 0; q < XENT_MAXC_REG; q++) {
+                const int j = lane + q * WAVE;
+                if (j < a.C) {
+                    float p = ex[q] / se;              // module.cpp:147
+                    if (j == t) p = (float)((double)p - 1.0);
+                    gr[j] = p / cnt;                   // module.cpp:157
+                }
+            }
+        }
+    }
+    // block partials (lane 0 of each wave carries the wave's totals)
+    if (lane == 0) { sh_f[wave] = loss; sh_i[wave * 2] = correct; sh_i[wave * 2 + 1] = total; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.part_f[blockIdx.x] = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
+        a.part_i[blockIdx.x * 2] = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
+        a.part_i[blockIdx.x * 2 + 1] = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
+    }
+}
+
+__global__ __launch_bounds__(256) void count_labelled_kernel(const int32_t *truth, int n, int32_t *part) {
+    int c = 0;
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int b0 = blockIdx.x * chunk, b1 = min(n, b0 + chunk);
+    for (int i = b0 + threadIdx.x; i < b1; i += 256) c += truth[i] >= 0 ? 1 : 0;
+    c = wave_sum_i(c);
+    __shared__ int sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void sum_int_partials_kernel(const int32_t *part, int n, int32_t *out) {
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) c += part[i];
+    c = wave_sum_i(c);
+    __shared__ int sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// fixed-order final reduction of the block partials
+__global__ __launch_bounds__(256) void xent_finalize_kernel(const float *part_f, const int32_t *part_i, int n,
+                                                            float *res, int32_t *res_i, int acc_only) {
+    __shared__ float shf[4];
+    __shared__ int shi[8];
+    float l = 0.f;
+    int c = 0, t = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { l += part_f[i]; c += part_i[2 * i]; t += part_i[2 * i + 1]; }
+    l = wave_sum(l); c = wave_sum_i(c); t = wave_sum_i(t);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { shf[w] = l; shi[2 * w] = c; shi[2 * w + 1] = t; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int cc = shi[0] + shi[2] + shi[4] + shi[6], tt = shi[1] + shi[3] + shi[5] + shi[7];
+        if (res_i) { res_i[0] = cc; res_i[1] = tt; }
+        if (res && !acc_only) {
+            res[0] = (shf[0] + shf[1]) + (shf[2] + shf[3]);
+            res[1] = (float)tt;
+            res[2] = (float)cc;
+            res[3] = (float)tt;
+        }
+    }
+}
+
+static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_result_i) {
+    if (a.C > XENT_MAXC_REG * WAVE) return -1;
+    int blocks = ceil_div(a.n_rows, 4 * 8);             // ~8 rows per wave
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    a.part_f = c->red_f + 2048;
+    a.part_i = c->red_i;
+    if (!a.acc_only && a.training && a.count <= 0) {    // count first, like module.cpp:127-133
+        int cb = ceil_div(a.n_rows, 4096);
+        if (cb > 1024) cb = 1024;
+        if (cb < 1) cb = 1;
+        count_labelled_kernel<<<cb, 256, 0, c->stream>>>(a.truth, a.n_rows, c->red_i + 4096);
+        GCNHIP_LAUNCH_CHECK();
+        sum_int_partials_kernel<<<1, 256, 0, c->stream>>>(c->red_i + 4096, cb, c->red_i + 8192);
+        GCNHIP_LAUNCH_CHECK();
+        a.d_count = c->red_i + 8192;
+    }
+    xent_kernel<<<blocks, 256, 0, c->stream>>>(a);
+    GCNHIP_LAUNCH_CHECK();
+    xent_finalize_kernel<<<1, 256, 0, c->stream>>>(a.part_f, a.part_i, blocks, d_result, d_result_i, a.acc_only);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+int gcnhip_xent_fwd(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_grad,
+                    const int32_t *truth, int n_rows, int num_classes, int training,
+                    int count, int shift_in_place, float *d_result, int32_t *d_result_i) {
+    if (!c || !logits || !truth || !d_result || num_classes <= 0 || ld < num_classes) return -1;
+    if (training && (!grad || ld_grad < num_classes)) return -1;
+    if (n_rows <= 0) return -1;
+    XentArgs a;
+    a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
+    a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_rows; a.C = num_classes;
+    a.training = training; a.shift = shift_in_place; a.acc_only = 0;
+    a.count = count; a.d_count = nullptr;
+    return xent_launch(c, a, d_result, d_result_i);
+}
+
+int gcnhip_accuracy(gcnhip_ctx *c, const float *logits, int ld, const int32_t *truth,
+                    int n_rows, int num_classes, int32_t *d_result_i) {
+    if (!c || !logits || !truth || !d_result_i || num_classes <= 0 || ld < num_classes || n_rows <= 0) return -1;
+    XentArgs a;
+    a.logits = const_cast<float *>(logits); a.grad = nullptr; a.truth = truth;
+    a.ld = ld; a.ld_grad = 0; a.n_rows = n_rows; a.C = num_classes;
+    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr;
+    return xent_launch(c, a, nullptr, d_result_i);
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+"""numpy front end of the op-level C-ABI (include/gcnhip.h).
+
+Each function mirrors one module of the reference (Matmul, SparseMatmul,
+GraphSum, CrossEntropyLoss, ReLU, Dropout, Adam): same operand meaning, numpy
+arrays in and out.  Arrays are staged through device buffers owned by a
+``Device`` (gcnhip_malloc / h2d / d2h); all compute happens in the HIP kernels.
+There is no CPU path here: without libgcnhip.so and a GPU these calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class GcnHipError(RuntimeError):
+    pass
+
+
+def _ck(lib, code, what):
+    if code != 0:
+        msg = lib.gcnhip_error_string(code)
+        raise GcnHipError(f"{what}: error {code} ({msg.decode() if msg else '?'})")
+
+
+class Buf:
+    """a device allocation with a numpy-ish shape/dtype"""
+
+    def __init__(self, dev: "Device", shape, dtype):
+        self.dev = dev
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _ck(dev.lib, dev.lib.gcnhip_malloc(dev.ctx, C.byref(p), max(self.nbytes, 16)), "gcnhip_malloc")
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, self.dtype)
+        assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
+        _ck(self.dev.lib, self.dev.lib.gcnhip_h2d(self.dev.ctx, self.ptr, arr.ctypes.data, self.nbytes), "gcnhip_h2d")
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, self.dtype)
+        _ck(self.dev.lib, self.dev.lib.gcnhip_d2h(self.dev.ctx, out.ctypes.data, self.ptr, self.nbytes), "gcnhip_d2h")
+        return out
+
+    def fill_bytes(self, byte=0):
+        _ck(self.dev.lib, self.dev.lib.gcnhip_memset_async(self.dev.ctx, self.ptr, byte, self.nbytes), "memset")
+        return self
+
+    def free(self):
+        if self.ptr and self.dev.ctx:            # a closed Device has already released the GPU
+            self.dev.lib.gcnhip_free(self.dev.ctx, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Device:
+    """one GPU context (device + stream + scratch)"""
+
+    def __init__(self, device: int = 0, stream=None):
+        self.lib = _lib.gcnhip()
+        n = C.c_int()
+        _ck(self.lib, self.lib.gcnhip_device_count(C.byref(n)), "gcnhip_device_count")
+        if n.value <= device:
+            raise GcnHipError(f"no GPU {device} (device count {n.value}); this package has no CPU path")
+        ctx = C.c_void_p()
+        _ck(self.lib, self.lib.gcnhip_ctx_create(C.byref(ctx), device, stream), "gcnhip_ctx_create")
+        self.ctx = ctx
+
+    def close(self):
+        if self.ctx:
+            self.lib.gcnhip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        _ck(self.lib, self.lib.gcnhip_ctx_sync(self.ctx), "sync")
+
+    def buf(self, arr_or_shape, dtype=np.float32):
+        if isinstance(arr_or_shape, np.ndarray):
+            return Buf(self, arr_or_shape.shape, arr_or_shape.dtype).upload(arr_or_shape)
+        return Buf(self, arr_or_shape, dtype)
+
+    def padded(self, arr, ld):
+        """upload a 2-D float array into a buffer with leading dimension ld (pad = NaN to catch misuse)"""
+        arr = np.asarray(arr, np.float32)
+        out = np.full((arr.shape[0], ld), np.nan, np.float32)
+        out[:, :arr.shape[1]] = arr
+        return self.buf(out)
+
+    # ---- prepared objects
+    def graph(self, indptr, indices, n_cols=None, col_deg=None):
+        return Graph(self, indptr, indices, n_cols, col_deg)
+
+    def feat(self, indptr, indices, values, n_cols):
+        return Feat(self, indptr, indices, values, n_cols)
+
+    # ---- ops (numpy in, numpy out)
+    def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None):
+        x = np.asarray(x, np.float32)
+        dim = x.shape[1]
+        ld_in = ld_in or dim
+        ld_out = ld_out or dim
+        xin = self.padded(x, ld_in)
+        out = self.buf(np.full((g.n_rows, ld_out), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_graphsum(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim), "gcnhip_graphsum")
+        return out.download()[:, :dim]
+
+    def graphsum_relu_dropout(self, g, x, training, p, seed=0, epoch=0, elem_offset=0, keep_mask=None, ld=None):
+        x = np.asarray(x, np.float32)
+        dim = x.shape[1]
+        ld = ld or dim
+        xin = self.padded(x, ld)
+        out = self.buf(np.full((g.n_rows, ld), np.nan, np.float32))
+        ep = self.buf(np.array([epoch], np.uint32))
+        km = self.buf(np.ascontiguousarray(keep_mask, np.uint8)) if keep_mask is not None else None
+        _ck(self.lib, self.lib.gcnhip_graphsum_relu_dropout(self.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim, int(training), p,
+                                                             seed, ep.ptr, elem_offset, km.ptr if km else None), "graphsum_relu_dropout")
+        return out.download()[:, :dim]
+
+    def spmm_fwd(self, f: "Feat", w, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, keep_mask=None, vals=None, ld_w=None, ld_out=None):
+        w = np.asarray(w, np.float32)
+        p = w.shape[1]
+        ld_w = ld_w or p
+        ld_out = ld_out or p
+        wb = self.padded(w, ld_w)
+        out = self.buf(np.full((f.n_rows, ld_out), np.nan, np.float32))
+        ep = self.buf(np.array([epoch], np.uint32))
+        km = self.buf(np.ascontiguousarray(keep_mask, np.uint8)) if keep_mask is not None else None
+        vb = self.buf(np.ascontiguousarray(vals, np.float32)) if vals is not None else None
+        vptr = vb.ptr if vb else f.values_ptr
+        _ck(self.lib, self.lib.gcnhip_spmm_fwd(self.ctx, f.h, vptr, wb.ptr, ld_w, out.ptr, ld_out, p, p_drop, seed, ep.ptr,
+                                                nnz_offset, km.ptr if km else None), "gcnhip_spmm_fwd")
+        return out.download()[:, :p]
+
+    def spmm_bwd(self, f: "Feat", dout, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, keep_mask=None, vals=None, ld_dout=None, ld_dw=None):
+        dout = np.asarray(dout, np.float32)
+        p = dout.shape[1]
+        ld_dout = ld_dout or p
+        ld_dw = ld_dw or p
+        db = self.padded(dout, ld_dout)
+        dw = self.buf(np.full((f.n_cols, ld_dw), np.nan, np.float32))
+        ep = self.buf(np.array([epoch], np.uint32))
+        km = self.buf(np.ascontiguousarray(keep_mask, np.uint8)) if keep_mask is not None else None
+        vb = self.buf(np.ascontiguousarray(vals, np.float32)) if vals is not None else None
+        vptr = vb.ptr if vb else f.values_ptr
+        _ck(self.lib, self.lib.gcnhip_spmm_bwd(self.ctx, f.h, vptr, db.ptr, ld_dout, dw.ptr, ld_dw, p, p_drop, seed, ep.ptr,
+                                                nnz_offset, km.ptr if km else None), "gcnhip_spmm_bwd")
+        return dw.download()[:, :p]
+
+    def matmul_fwd(self, a, b, lda=None, ldb=None, ldc=None):
+        a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+        m, n = a.shape
+        p = b.shape[1]
+        lda, ldb, ldc = lda or n, ldb or p, ldc or p
+        ab, bb = self.padded(a, lda), self.padded(b, ldb)
+        cb = self.buf(np.full((m, ldc), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_matmul_fwd(self.ctx, ab.ptr, lda, bb.ptr, ldb, cb.ptr, ldc, m, n, p), "gcnhip_matmul_fwd")
+        return cb.download()[:, :p]
+
+    def matmul_bwd(self, a, b, dc, lda=None, ldb=None, lddc=None, fused_scale=None):
+        a, b, dc = (np.asarray(t, np.float32) for t in (a, b, dc))
+        m, n = a.shape
+        p = b.shape[1]
+        lda, ldb, lddc = lda or n, ldb or p, lddc or p
+        ab, bb, dcb = self.padded(a, lda), self.padded(b, ldb), self.padded(dc, lddc)
+        da = self.buf(np.full((m, lda), np.nan, np.float32))
+        db = self.buf(np.full((n, ldb), np.nan, np.float32))
+        if fused_scale is None:
+            _ck(self.lib, self.lib.gcnhip_matmul_bwd(self.ctx, ab.ptr, lda, bb.ptr, ldb, dcb.ptr, lddc, da.ptr, lda, db.ptr, ldb, m, n, p), "gcnhip_matmul_bwd")
+        else:
+            _ck(self.lib, self.lib.gcnhip_matmul_bwd_fused(self.ctx, ab.ptr, lda, bb.ptr, ldb, dcb.ptr, lddc, da.ptr, lda, db.ptr, ldb,
+                                                            m, n, p, fused_scale), "gcnhip_matmul_bwd_fused")
+        return da.download()[:, :n], db.download()[:, :p]
+
+    def relu_fwd(self, x, training=True):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        xb = self.buf(x)
+        mb = self.buf(np.zeros(x.size, np.uint8))
+        _ck(self.lib, self.lib.gcnhip_relu_fwd(self.ctx, xb.ptr, mb.ptr, x.size, int(training)), "gcnhip_relu_fwd")
+        return xb.download(), mb.download()
+
+    def relu_bwd(self, grad, mask):
+        g = self.buf(np.ascontiguousarray(grad, np.float32).reshape(-1))
+        mb = self.buf(np.ascontiguousarray(mask, np.uint8))
+        _ck(self.lib, self.lib.gcnhip_relu_bwd(self.ctx, g.ptr, mb.ptr, g.shape[0]), "gcnhip_relu_bwd")
+        return g.download()
+
+    def dropout_fwd(self, x, p, seed=0, epoch=0, elem_offset=0, keep_in=None, want_mask=True):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        xb = self.buf(x)
+        mb = self.buf(np.zeros(x.size, np.int32)) if want_mask else None
+        ep = self.buf(np.array([epoch], np.uint32))
+        kb = self.buf(np.ascontiguousarray(keep_in, np.uint8)) if keep_in is not None else None
+        _ck(self.lib, self.lib.gcnhip_dropout_fwd(self.ctx, xb.ptr, mb.ptr if mb else None, x.size, p, seed, ep.ptr, elem_offset,
+                                                   kb.ptr if kb else None), "gcnhip_dropout_fwd")
+        return xb.download(), (mb.download() if mb else None)
+
+    def dropout_bwd(self, grad, mask, p):
+        g = self.buf(np.ascontiguousarray(grad, np.float32).reshape(-1))
+        mb = self.buf(np.ascontiguousarray(mask, np.int32))
+        _ck(self.lib, self.lib.gcnhip_dropout_bwd(self.ctx, g.ptr, mb.ptr, g.shape[0], p), "gcnhip_dropout_bwd")
+        return g.download()
+
+    def relu_dropout_bwd(self, grad, h, scale):
+        grad, h = np.asarray(grad, np.float32), np.asarray(h, np.float32)
+        g, hb = self.buf(np.ascontiguousarray(grad)), self.buf(np.ascontiguousarray(h))
+        _ck(self.lib, self.lib.gcnhip_relu_dropout_bwd(self.ctx, g.ptr, grad.shape[1], hb.ptr, h.shape[1], grad.shape[0], grad.shape[1], scale), "relu_dropout_bwd")
+        return g.download()
+
+    def xent_fwd(self, logits, truth, training=True, count=0, shift_in_place=True, ld=None):
+        """returns dict(loss_sum, count, correct, total, logits, grad)"""
+        logits = np.asarray(logits, np.float32)
+        n, c = logits.shape
+        ld = ld or c
+        lb = self.padded(logits, ld)
+        gb = self.buf(np.full((n, ld), np.nan, np.float32))
+        tb = self.buf(np.ascontiguousarray(truth, np.int32))
+        res = self.buf(np.zeros(4, np.float32))
+        resi = self.buf(np.zeros(2, np.int32))
+        _ck(self.lib, self.lib.gcnhip_xent_fwd(self.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, n, c, int(training), int(count),
+                                                int(shift_in_place), res.ptr, resi.ptr), "gcnhip_xent_fwd")
+        r, ri = res.download(), resi.download()
+        return dict(loss_sum=float(r[0]), count=float(r[1]), correct=int(ri[0]), total=int(ri[1]),
+                    logits=lb.download()[:, :c], grad=gb.download()[:, :c] if training else None)
+
+    def accuracy(self, logits, truth, ld=None):
+        logits = np.asarray(logits, np.float32)
+        n, c = logits.shape
+        ld = ld or c
+        lb = self.padded(logits, ld)
+        tb = self.buf(np.ascontiguousarray(truth, np.int32))
+        resi = self.buf(np.zeros(2, np.int32))
+        _ck(self.lib, self.lib.gcnhip_accuracy(self.ctx, lb.ptr, ld, tb.ptr, n, c, resi.ptr), "gcnhip_accuracy")
+        ri = resi.download()
+        return int(ri[0]), int(ri[1])
+
+    def set_truth(self, split, label, s):
+        sb, lb = self.buf(np.ascontiguousarray(split, np.int32)), self.buf(np.ascontiguousarray(label, np.int32))
+        tb = self.buf(np.zeros(sb.shape[0], np.int32))
+        _ck(self.lib, self.lib.gcnhip_set_truth(self.ctx, tb.ptr, sb.ptr, lb.ptr, sb.shape[0], s), "gcnhip_set_truth")
+        return tb.download()
+
+    def sumsq(self, x):
+        xb = self.buf(np.ascontiguousarray(x, np.float32).reshape(-1))
+        ob = self.buf(np.zeros(1, np.float32))
+        _ck(self.lib, self.lib.gcnhip_sumsq(self.ctx, xb.ptr, xb.shape[0], ob.ptr), "gcnhip_sumsq")
+        return float(ob.download()[0])
+
+    def adam_steps(self, ws, grads_per_step, decays, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8):
+        """ws: list of arrays; grads_per_step: list (steps) of lists (vars). Returns (ws, sumsq of ws[0])"""
+        bufs = []
+        for w in ws:
+            w = np.ascontiguousarray(w, np.float32).reshape(-1)
+            bufs.append(dict(w=self.buf(w), g=self.buf(np.zeros_like(w)), m=self.buf(np.zeros_like(w)), v=self.buf(np.zeros_like(w)), n=w.size))
+        arr = (_lib.AdamVar * len(ws))()
+        for k, b in enumerate(bufs):
+            arr[k] = _lib.AdamVar(b["w"].ptr, b["g"].ptr, b["m"].ptr, b["v"].ptr, b["n"], int(decays[k]))
+        sq = self.buf(np.zeros(1, np.float32))
+        b1, b2 = np.float32(beta1), np.float32(beta2)
+        for t, grads in enumerate(grads_per_step, start=1):
+            for k, g in enumerate(grads):
+                bufs[k]["g"].upload(np.ascontiguousarray(g, np.float32).reshape(-1))
+            # optim.cpp:26 in float arithmetic
+            step = np.float32(lr) * np.sqrt(np.float32(1) - np.power(b2, np.float32(t), dtype=np.float32)) / (np.float32(1) - np.power(b1, np.float32(t), dtype=np.float32))
+            _ck(self.lib, self.lib.gcnhip_adam_step(self.ctx, arr, len(ws), float(step), None, None, beta1, beta2, eps, weight_decay, sq.ptr), "gcnhip_adam_step")
+        return [b["w"].download() for b in bufs], float(sq.download()[0])
+
+
+class Graph:
+    def __init__(self, dev: Device, indptr, indices, n_cols=None, col_deg=None):
+        self.dev = dev
+        indptr = np.ascontiguousarray(indptr, np.int32)
+        indices = np.ascontiguousarray(indices, np.int32)
+        self.n_rows = indptr.size - 1
+        self.n_cols = int(n_cols) if n_cols is not None else self.n_rows
+        cd = np.ascontiguousarray(col_deg, np.int32) if col_deg is not None else None
+        h = C.c_void_p()
+        _ck(dev.lib, dev.lib.gcnhip_graph_create(dev.ctx, C.byref(h), indptr.ctypes.data, indices.ctypes.data, self.n_rows, self.n_cols,
+                                                  cd.ctypes.data if cd is not None else None), "gcnhip_graph_create")
+        self.h = h
+
+    def coef(self):
+        pc = C.c_void_p()
+        nr, nnz = C.c_int(), C.c_int()
+        _ck(self.dev.lib, self.dev.lib.gcnhip_graph_arrays(self.h, None, None, C.byref(pc), C.byref(nr), C.byref(nnz)), "graph_arrays")
+        out = np.empty(nnz.value, np.float32)
+        _ck(self.dev.lib, self.dev.lib.gcnhip_d2h(self.dev.ctx, out.ctypes.data, pc, out.nbytes), "d2h")
+        return out
+
+    def free(self):
+        if self.h and self.dev.ctx:
+            self.dev.lib.gcnhip_graph_destroy(self.dev.ctx, self.h)
+        self.h = None
+
+
+class Feat:
+    def __init__(self, dev: Device, indptr, indices, values, n_cols):
+        self.dev = dev
+        indptr = np.ascontiguousarray(indptr, np.int32)
+        indices = np.ascontiguousarray(indices, np.int32) if indices is not None else None
+        values = np.ascontiguousarray(values, np.float32)
+        self.n_rows = indptr.size - 1
+        self.n_cols = int(n_cols)
+        h = C.c_void_p()
+        _ck(dev.lib, dev.lib.gcnhip_feat_create(dev.ctx, C.byref(h), indptr.ctypes.data, indices.ctypes.data if indices is not None else None,
+                                                 values.ctypes.data, self.n_rows, self.n_cols), "gcnhip_feat_create")
+        self.h = h
+        self.values_ptr = dev.lib.gcnhip_feat_values(h)
+        self.dense = bool(dev.lib.gcnhip_feat_is_dense(h))
+
+    def free(self):
+        if self.h and self.dev.ctx:
+            self.dev.lib.gcnhip_feat_destroy(self.dev.ctx, self.h)
+        self.h = None

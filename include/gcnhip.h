@@ -1,0 +1,230 @@
+/*
+ * gcnhip.h — C-ABI of libgcnhip.so: the MI355X (gfx950) kernels of the two-layer
+ * GCN training path, one entry point per kernel-launching wrapper of the
+ * reference (paths below are relative to the reference tree).
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its GPU backend is a
+ * set of host wrappers (src/cuda/cuda_module.cu, cuda_gcn.cu, cuda_variable.cu)
+ * that size a grid and launch a __global__ kernel on raw device pointers
+ * (src/cuda/cuda_kernel.cuh:22-90).  Each function here replaces one of those
+ * wrapper bodies; a `Hip*` module calls it where the `CUDA*` module launches.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - every function returns 0 on success, else a hipError_t (or -1 for an
+ *    argument error); nothing aborts or throws.  gcnhip_error_string() names it.
+ *    (The reference prints and exits: CUDA_CHECK, src/cuda/cuda_kernel.cuh:11-18 —
+ *    that policy belongs to the caller; see GCNHIP_CHECK in host/hip_check.h.)
+ *  - all launches are asynchronous on the context's stream; only functions
+ *    documented as "synchronises" wait.  No allocation happens inside an op:
+ *    scratch lives in the context / graph / feature objects created up front, so
+ *    every op is hipGraph-capturable.
+ *  - all matrices are row-major f32 with an explicit leading dimension `ld`
+ *    (floats).  The reference's layout is ld == number of columns.  Rows that
+ *    are 16-byte aligned (ld % 4 == 0 and a 16-byte aligned base) take the
+ *    vectorised kernels; any other ld takes a slower scalar-load kernel with the
+ *    same results.
+ *  - indices are int32 like the reference (src/seq/sparse.h:12-17).
+ */
+#ifndef GCNHIP_H
+#define GCNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gcnhip_ctx gcnhip_ctx;       /* device + stream + scratch */
+typedef struct gcnhip_graph gcnhip_graph;   /* prepared adjacency (CUDASparseIndex of the graph) */
+typedef struct gcnhip_feat gcnhip_feat;     /* prepared feature matrix (CUDASparseIndex of X + its values) */
+
+/* ---- context / runtime (replaces the implicit null stream + CUDA_CHECK) ---- */
+int  gcnhip_device_count(int *count);
+/* stream == NULL: the context creates and owns a non-blocking stream.
+ * Otherwise `stream` is a hipStream_t owned by the caller. */
+int  gcnhip_ctx_create(gcnhip_ctx **ctx, int device, void *stream);
+int  gcnhip_ctx_destroy(gcnhip_ctx *ctx);
+int  gcnhip_ctx_sync(gcnhip_ctx *ctx);                 /* synchronises the stream */
+void *gcnhip_ctx_stream(gcnhip_ctx *ctx);
+const char *gcnhip_error_string(int code);
+const char *gcnhip_version(void);
+
+/* ---- memory (CUDAVariable ctor/dtor/zero: src/cuda/cuda_variable.cu:3-31) ---- */
+int gcnhip_malloc(gcnhip_ctx *ctx, void **ptr, size_t bytes);
+int gcnhip_free(gcnhip_ctx *ctx, void *ptr);
+int gcnhip_memset_async(gcnhip_ctx *ctx, void *ptr, int byte, size_t bytes);
+int gcnhip_h2d(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronises */
+int gcnhip_d2h(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronises */
+int gcnhip_d2d_async(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* ---- adjacency (CUDASparseIndex(const SparseIndex&): cuda_variable.cu:55-64) --
+ * Copies the CSR of n_rows rows to the device and precomputes, once, the per
+ * edge coefficient the reference recomputes for every edge of every call
+ * (src/seq/module.cpp:91-93, src/cuda/cuda_kernel.cu:136-138):
+ *     coef(e) = (float)(1.0 / sqrtf((float)(deg(src) * deg(dst))))
+ * deg(src) = row length; deg(dst) = col_deg[dst] (col_deg == NULL: the row
+ * length of row dst; then n_cols must equal n_rows).  The product is formed in
+ * 64-bit (the reference's int product overflows above 46 340, module.cpp:92).
+ * col_deg lets a row block of a partitioned graph name global degrees. */
+int gcnhip_graph_create(gcnhip_ctx *ctx, gcnhip_graph **g, const int *h_indptr, const int *h_indices,
+                        int n_rows, int n_cols, const int *h_col_deg);
+int gcnhip_graph_destroy(gcnhip_ctx *ctx, gcnhip_graph *g);
+/* device pointers of the prepared arrays (tests, diagnostics) */
+int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int **d_indices,
+                        const float **d_coef, int *n_rows, int *nnz);
+
+/* ---- GraphSum (CUDAGraphSum::forward/backward: cuda_module.cu:75-103;
+ *      kernels cuda_kernel.cu:126-162; CPU: src/seq/module.cpp:83-119) --------
+ * out[r, 0:dim] = sum_e coef(e) * in[indices[e], 0:dim] over row r's edges.
+ * Forward and backward are this same operator (the reference relies on a
+ * symmetric adjacency, module.cpp:95).  `in` has g->n_cols rows. */
+int gcnhip_graphsum(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int ld_in,
+                    float *out, int ld_out, int dim);
+/* Fused epilogue used by the first layer: GraphSum, then ReLU
+ * (module.cpp:175-185), then Dropout (module.cpp:207-221) on the same rows.
+ * training == 0: ReLU only.  The dropout decision for element (r, c) is
+ * keep(seed, *d_epoch, elem_offset + r*dim + c) (see gcnhip_dropout_fwd), or
+ * keep_mask[r*dim + c] != 0 when keep_mask != NULL.  No mask is stored:
+ * backward recovers it as out > 0 (gcnhip_relu_dropout_bwd). */
+int gcnhip_graphsum_relu_dropout(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int ld_in,
+                                 float *out, int ld_out, int dim, int training, float p,
+                                 uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
+                                 const uint8_t *keep_mask);
+
+/* ---- features (CUDASparseIndex of X + the input CUDAVariable) ----------------
+ * CSR of X with n_rows rows and n_cols (= input_dim) columns.  A matrix whose
+ * every row holds exactly the columns 0..n_cols-1 in order is detected as
+ * dense and its index array is not kept on the device.  A column-major index
+ * (CSC) is built once so the weight gradient is a gather, not the racy
+ * scatter of cuda_kernel.cu:112-122. */
+int gcnhip_feat_create(gcnhip_ctx *ctx, gcnhip_feat **f, const int *h_indptr, const int *h_indices,
+                       const float *h_values, int n_rows, int n_cols);
+int gcnhip_feat_destroy(gcnhip_ctx *ctx, gcnhip_feat *f);
+int gcnhip_feat_is_dense(const gcnhip_feat *f);
+float *gcnhip_feat_values(gcnhip_feat *f);              /* device pointer, nnz floats (pristine X) */
+int64_t gcnhip_feat_nnz(const gcnhip_feat *f);
+
+/* ---- SparseMatmul (CUDASparseMatmul: cuda_module.cu:42-70; kernels
+ *      cuda_kernel.cu:100-122; CPU: src/seq/module.cpp:47-77) ------------------
+ * forward : out[i, 0:p] = sum_jj vals[jj] * w[col(jj), 0:p]
+ * backward: dw[col(jj), 0:p] += dout[i, 0:p] * vals[jj]   (dw is overwritten)
+ * `vals` is the device value array to use (nnz floats): pass
+ * gcnhip_feat_values(f), or a buffer that gcnhip_dropout_fwd has modified the
+ * way the reference's input Dropout modifies v0 (gcn.cpp:23).
+ * Fused input dropout (replaces that Dropout module + the per-epoch
+ * set_input copy of cuda_gcn.cu:81-83): p_drop > 0 applies
+ * vals[jj] * (keep ? 1/(1-p) : 0) on the fly, keep as in gcnhip_dropout_fwd
+ * with element index nnz_offset + jj, or keep_mask[jj] when non-NULL.  The
+ * backward must be called with the same arguments to see the same X~. */
+int gcnhip_spmm_fwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
+                    float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                    uint64_t nnz_offset, const uint8_t *keep_mask);
+int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
+                    float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                    uint64_t nnz_offset, const uint8_t *keep_mask);
+
+/* ---- Matmul (CUDAMatmul: cuda_module.cu:8-34; kernels cuda_kernel.cu:6-96;
+ *      CPU: src/seq/module.cpp:11-42) -------------------------------------------
+ * forward : c[m x p] = a[m x n] . b[n x p]
+ * backward: da = dc . b^T (assigned); db = a^T . dc (assigned) */
+int gcnhip_matmul_fwd(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
+                      float *c, int ldc, int m, int n, int p);
+int gcnhip_matmul_bwd(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
+                      const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                      int m, int n, int p);
+/* da only, with the ReLU+Dropout backward fused into the store:
+ * da[i,j] = (h[i,j] > 0) ? scale * (dc . b^T)[i,j] : 0, h = the forward output
+ * of gcnhip_graphsum_relu_dropout (module.cpp:187-194, 223-233). */
+int gcnhip_matmul_bwd_fused(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
+                            const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                            int m, int n, int p, float relu_dropout_scale);
+
+/* ---- ReLU (CUDAReLU: cuda_module.cu:164-186; cuda_kernel.cu:204-219) ---------
+ * mask: one byte per element, written only when training (module.cpp:180). */
+int gcnhip_relu_fwd(gcnhip_ctx *ctx, float *x, uint8_t *mask, int64_t n, int training);
+int gcnhip_relu_bwd(gcnhip_ctx *ctx, float *grad, const uint8_t *mask, int64_t n);
+
+/* ---- Dropout (CUDADropout: cuda_module.cu:201-227; cuda_kernel.cu:223-240;
+ *      CPU: src/seq/module.cpp:207-233) -----------------------------------------
+ * x[i] *= keep(i) ? 1/(1-p) : 0;  mask[i] = keep(i) when mask != NULL.
+ * keep(i) <=> (r31 >= (int)(p * 0x7fffffff)) with r31 the low 31 bits of word
+ * (j & 3) of Philox4x32-10(counter = {lo32(j>>2), hi32(j>>2), epoch, 0},
+ * key = {lo32(seed), hi32(seed)}), j = elem_offset + i, epoch = d_epoch ?
+ * *d_epoch : 0 (a device word, so a captured graph replays with fresh masks).
+ * This counter-based stream replaces the reference's sequential xorshift128+
+ * (rand.cpp:17-28) and its 1024 shared curand states (cuda_kernel.cu:229); it
+ * is invariant to how rows are partitioned across GPUs.  For bit-parity runs
+ * against the CPU path pass the reference's own decisions in keep_in (one
+ * byte per element); then the RNG is not used. */
+int gcnhip_dropout_fwd(gcnhip_ctx *ctx, float *x, int32_t *mask, int64_t n, float p,
+                       uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
+                       const uint8_t *keep_in);
+int gcnhip_dropout_bwd(gcnhip_ctx *ctx, float *grad, const int32_t *mask, int64_t n, float p);
+/* backward of the fused ReLU+Dropout: grad[i] = h[i] > 0 ? scale * grad[i] : 0 */
+int gcnhip_relu_dropout_bwd(gcnhip_ctx *ctx, float *grad, int ld_grad, const float *h, int ld_h,
+                            int n_rows, int dim, float scale);
+
+/* ---- CrossEntropyLoss + accuracy (CUDACrossEntropyLoss::forward:
+ *      cuda_module.cu:117-147, kernels cuda_kernel.cu:166-200; accuracy:
+ *      cuda_gcn.cu:100-120; CPU: module.cpp:124-161, gcn.cpp:83-96) ------------
+ * One pass over the labelled rows (truth[i] >= 0): max-shift, sum-exp, loss_i,
+ * and — because the max is already in hand — the accuracy test "no logit above
+ * the true one" (ties count as correct).  training: grad = (softmax - onehot)
+ * / count for labelled rows, 0 for the others.  count > 0 is the number of
+ * labelled rows (the caller knows it from the split); count == 0 makes the
+ * kernel count first (second launch), as the reference does.
+ * shift_in_place != 0 also writes logits -= max like the reference
+ * (module.cpp:140).  Results land in d_result[4] = {loss_sum, count,
+ * correct, total} (floats; exact integers up to 2^24 rows per GPU are kept
+ * in the two int words d_result_i[2] = {correct, total}); nothing is copied
+ * to the host: read them with gcnhip_d2h or let gcnhip_metrics_* do it. */
+int gcnhip_xent_fwd(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_grad,
+                    const int32_t *truth, int n_rows, int num_classes, int training,
+                    int count, int shift_in_place, float *d_result, int32_t *d_result_i);
+/* accuracy alone (cuda_gcn.cu:100-120 without the 38 MB D2H) */
+int gcnhip_accuracy(gcnhip_ctx *ctx, const float *logits, int ld, const int32_t *truth,
+                    int n_rows, int num_classes, int32_t *d_result_i);
+/* truth[i] = split[i] == s ? label[i] : -1   (cuda_kernel.cu:283-288) */
+int gcnhip_set_truth(gcnhip_ctx *ctx, int32_t *truth, const int32_t *split, const int32_t *label,
+                     int n, int s);
+/* *d_out = sum x[i]^2   (the thrust transform+reduce of cuda_gcn.cu:122-134) */
+int gcnhip_sumsq(gcnhip_ctx *ctx, const float *x, int64_t n, float *d_out);
+
+/* ---- Adam (CUDAAdam::step: cuda_module.cu:253-263; cuda_kernel.cu:270-281;
+ *      CPU: src/seq/optim.cpp:24-37) ---------------------------------------------
+ * One launch for up to 4 variables.  step_size is
+ * lr*sqrtf(1-beta2^t)/(1-beta1^t) computed by the caller (optim.cpp:26), or
+ * read from d_step_sizes[*d_epoch] when d_step_sizes != NULL (graph replay).
+ * "(1.0 - beta)" is evaluated in double as in the reference.  When
+ * d_sumsq != NULL the kernel also leaves sum(w0^2) of the UPDATED variable 0
+ * there (the L2 penalty the next loss report needs, gcn.cpp:98-105). */
+typedef struct {
+    float *w, *g, *m, *v;
+    int64_t n;
+    int decay;
+} gcnhip_adam_var;
+int gcnhip_adam_step(gcnhip_ctx *ctx, const gcnhip_adam_var *vars, int n_vars, float step_size,
+                     const float *d_step_sizes, const uint32_t *d_epoch,
+                     float beta1, float beta2, float eps, float weight_decay, float *d_sumsq);
+
+/* ---- small device utilities for graph-replayed epochs -------------------------- */
+int gcnhip_counter_add(gcnhip_ctx *ctx, uint32_t *d_counter, uint32_t inc);
+/* metrics ring: record row `*d_epoch % capacity` = {loss_sum, count, correct, total, sumsq, 0,0,0} */
+int gcnhip_metrics_record(gcnhip_ctx *ctx, float *d_ring, int capacity, int slot_in_row,
+                          const uint32_t *d_epoch, const float *d_result, const int32_t *d_result_i,
+                          const float *d_sumsq);
+
+/* ---- timing (replaces the host chrono timers that the CUDA path leaves
+ *      unsynchronised) ---------------------------------------------- */
+int gcnhip_event_create(void **ev);
+int gcnhip_event_destroy(void *ev);
+int gcnhip_event_record(gcnhip_ctx *ctx, void *ev);
+int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

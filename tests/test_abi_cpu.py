@@ -1,0 +1,54 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/gcnhip.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions(path):
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcn(?:hip|host)_\w+)\s*\(", txt)))
+
+
+def test_gcnhip_exports_every_declared_symbol():
+    from cuda_gcn_amd import _lib
+    lib = _lib.gcnhip()
+    names = header_functions(os.path.join(ROOT, "include", "gcnhip.h"))
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gcnhip.h but not exported"
+    # the python binding table covers the header exactly
+    assert sorted(_lib.GCNHIP_SYMBOLS) == names
+
+
+def test_error_strings_without_gpu():
+    from cuda_gcn_amd import _lib
+    lib = _lib.gcnhip()
+    assert b"invalid argument" in lib.gcnhip_error_string(-1)
+    assert lib.gcnhip_version().startswith(b"gcnhip")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from cuda_gcn_amd import _lib
+    monkeypatch.setattr(_lib, "LIBDIR", str(tmp_path))
+    monkeypatch.setattr(_lib, "_cache", {})
+    with pytest.raises(_lib.NativeLibraryMissing):
+        _lib._load("libgcnhip.so")
+
+
+def test_no_gpu_means_error_not_fallback():
+    """on a box without a GPU the product path must raise, never compute on the CPU"""
+    from cuda_gcn_amd import _lib
+    lib = _lib.gcnhip()
+    n = ctypes.c_int(-1)
+    rc = lib.gcnhip_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    from cuda_gcn_amd.ops import Device, GcnHipError
+    with pytest.raises(GcnHipError):
+        Device(0)

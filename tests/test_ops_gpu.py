@@ -1,0 +1,417 @@
+"""GPU parity: every op of the C-ABI (include/gcnhip.h) against the CPU oracle
+on the same seeded inputs, and against the committed golden fixtures.
+
+Tolerances (f32 path): sums differ from the reference only in
+summation order and FMA contraction -> rtol 1e-5 / atol 1e-6 per op output
+(rows up to ~2e4 terms: atol scaled with the row's |terms| sum where noted).
+Pure element-wise ops and integer results are exact (==).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cuda_gcn_amd import datagen
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL, ATOL = 1e-5, 1e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from cuda_gcn_amd.ops import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def mods():
+    return np.load(os.path.join(GOLD, "modules.npz"))
+
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+def close_mag(got, want, mag, k=8.0):
+    """|got - want| <= k * eps_f32 * mag, where mag is the same op evaluated on
+    the absolute values of its inputs (the sum of |terms| of every output): the
+    standard bound for two f32 summations of the same terms in different order
+    (the reference adds sequentially; the GPU adds in a tree / with FMA)."""
+    got, want, mag = (np.asarray(t, np.float64) for t in (got, want, mag))
+    assert got.shape == want.shape == mag.shape
+    assert np.all(np.isfinite(got)), "non-finite output"
+    viol = np.abs(got - want) - (k * EPS * mag + 1e-30)
+    assert viol.max() <= 0, f"max violation {viol.max():.3e} (abs diff {np.abs(got - want).max():.3e})"
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert np.all(np.isfinite(a)), "non-finite output"
+    assert err.max() <= 0, f"max violation {err.max():.3e}, max abs diff {np.abs(a - b).max():.3e}"
+
+
+# --------------------------------------------------------------- Philox (test side)
+def philox_keep(seed, epoch, idx, thr):
+    """keep decisions for element indices idx (uint64 array) — numpy restatement
+    of the documented stream in include/gcnhip.h (gcnhip_dropout_fwd)."""
+    idx = np.asarray(idx, np.uint64)
+    quad = idx >> np.uint64(2)
+    c = [(quad & np.uint64(0xffffffff)).astype(np.uint64), (quad >> np.uint64(32)).astype(np.uint64),
+         np.full(idx.shape, epoch, np.uint64), np.zeros(idx.shape, np.uint64)]
+    k0, k1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask32 = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask32
+        n1 = p1 & mask32
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask32
+        n3 = p0 & mask32
+        c = [n0, n1, n2, n3]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask32
+    words = np.stack(c, axis=-1)
+    r = np.take_along_axis(words, (idx & np.uint64(3)).astype(np.int64)[..., None], axis=-1)[..., 0]
+    return (r & np.uint64(0x7fffffff)).astype(np.int64) >= thr
+
+
+def thr_of(p):
+    return int(np.float32(p) * np.float32(0x7fffffff))
+
+
+def hub_graph(n=3000, hub_deg=2500, seed=3):
+    """a graph with one row above the 1024-edge split threshold"""
+    rng = np.random.default_rng(seed)
+    lo = np.concatenate([np.zeros(hub_deg, np.int64), rng.integers(1, n, 4000)])
+    hi = np.concatenate([np.arange(1, hub_deg + 1), rng.integers(1, n, 4000)])
+    a, b = datagen._unique_undirected(lo, hi, n)
+    return datagen.csr_with_self_loops(a, b, n)
+
+
+# --------------------------------------------------------------------- GraphSum
+def test_edge_coef_bit_exact(dev):
+    ds = datagen.make_dataset("cora-syn")
+    gp, gi = ds["g_indptr"], ds["g_indices"]
+    g = dev.graph(gp, gi)
+    deg = np.diff(gp).astype(np.int64)
+    src = np.repeat(np.arange(gp.size - 1), deg)
+    prod = (deg[src] * deg[gi]).astype(np.float32)
+    want = (1.0 / np.sqrt(prod).astype(np.float64)).astype(np.float32)   # module.cpp:91-93
+    got = g.coef()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    g.free()
+
+
+@pytest.mark.parametrize("gname", ["tiny", "cora", "hub"])
+@pytest.mark.parametrize("dim,ld", [(1, 1), (3, 3), (7, 8), (16, 16), (41, 41), (41, 44), (128, 128), (300, 300), (260, 260)])
+def test_graphsum_vs_oracle(dev, oracle, gname, dim, ld):
+    if gname == "tiny":
+        ds = datagen.make_dataset("tiny-syn"); gp, gi = ds["g_indptr"], ds["g_indices"]
+    elif gname == "cora":
+        ds = datagen.make_dataset("cora-syn"); gp, gi = ds["g_indptr"], ds["g_indices"]
+    else:
+        gp, gi = hub_graph()
+    n = gp.size - 1
+    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
+    g = dev.graph(gp, gi)
+    got = dev.graphsum(g, x, ld_in=ld, ld_out=ld)
+    close_mag(got, oracle.graphsum(gp, gi, x, dim), oracle.graphsum(gp, gi, np.abs(x), dim))
+    g.free()
+
+
+@pytest.mark.parametrize("g", ["karate", "tiny", "ragged"])
+@pytest.mark.parametrize("dim", [1, 7, 16, 41])
+def test_graphsum_golden(dev, mods, g, dim):
+    gr = dev.graph(mods[f"gs_{g}_indptr"], mods[f"gs_{g}_indices"])
+    got = dev.graphsum(gr, mods[f"gs_{g}_d{dim}_in"])
+    close(got, mods[f"gs_{g}_d{dim}_out"])
+    close(got, mods[f"gs_{g}_d{dim}_bwd"])
+    gr.free()
+
+
+def test_graphsum_nan_isolation(dev, oracle):
+    """padding lanes must not read row 0: an Inf in row 0 may only reach its neighbours"""
+    gp, gi = hub_graph(400, 50, 1)
+    n = gp.size - 1
+    x = np.random.default_rng(0).standard_normal((n, 16)).astype(np.float32)
+    x[0] = np.inf                       # padded lanes carry index 0
+    g = dev.graph(gp, gi)
+    from cuda_gcn_amd.ops import _ck
+    xin = dev.padded(x, 16); out = dev.buf(np.zeros((n, 16), np.float32))
+    _ck(dev.lib, dev.lib.gcnhip_graphsum(dev.ctx, g.h, xin.ptr, 16, out.ptr, 16, 16), "graphsum")
+    got = out.download()
+    want = oracle.graphsum(gp, gi, x, 16)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    g.free()
+
+
+@pytest.mark.parametrize("dim,ld", [(16, 16), (128, 128), (41, 44), (41, 41)])
+def test_graphsum_relu_dropout(dev, oracle, dim, ld):
+    gp, gi = hub_graph()
+    n = gp.size - 1
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = dev.graph(gp, gi)
+    base = oracle.graphsum(gp, gi, x, dim)
+    relu = np.where(base > 0, base, 0).astype(np.float32)
+    # eval: ReLU only
+    tol = dict(rtol=1e-5, atol=5e-6)        # hub row: 2 500 terms, outputs scaled by 2
+    got = dev.graphsum_relu_dropout(g, x, training=False, p=0.5, ld=ld)
+    close(got, relu, **tol)
+    # training with injected decisions
+    keep = rng.integers(0, 2, n * dim).astype(np.uint8)
+    scale = np.float32(1) / (np.float32(1) - np.float32(0.5))
+    got = dev.graphsum_relu_dropout(g, x, training=True, p=0.5, keep_mask=keep, ld=ld)
+    close(got, relu * np.where(keep.reshape(n, dim) != 0, scale, np.float32(0)), **tol)
+    # training with the device RNG: decisions must equal the documented Philox stream
+    seed, epoch, off = 0x1234abcd5678, 7, 4 * 1000
+    got = dev.graphsum_relu_dropout(g, x, training=True, p=0.5, seed=seed, epoch=epoch, elem_offset=off, ld=ld)
+    k = philox_keep(seed, epoch, np.arange(n * dim, dtype=np.uint64) + np.uint64(off), thr_of(0.5)).reshape(n, dim)
+    close(got, relu * np.where(k, scale, np.float32(0)), **tol)
+    assert 0.45 < k.mean() < 0.55
+    g.free()
+
+
+# ----------------------------------------------------------------- SparseMatmul
+@pytest.mark.parametrize("name", ["tiny-syn", "cora-syn"])
+@pytest.mark.parametrize("p", [16, 7, 128, 3])
+def test_spmm_sparse_vs_oracle(dev, oracle, name, p):
+    ds = datagen.make_dataset(name)
+    fp, fi, F, N = ds["f_indptr"], ds["f_indices"], ds["input_dim"], ds["num_nodes"]
+    rng = np.random.default_rng(p)
+    vals = rng.standard_normal(fi.size).astype(np.float32)
+    w = rng.standard_normal((F, p)).astype(np.float32)
+    dout = rng.standard_normal((N, p)).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    assert not f.dense
+    def check(vd, **kw):
+        close_mag(dev.spmm_fwd(f, w, **kw), oracle.spmm_fwd(fp, fi, vd, w, p), oracle.spmm_fwd(fp, fi, np.abs(vd), np.abs(w), p))
+        close_mag(dev.spmm_bwd(f, dout, **kw), oracle.spmm_bwd(fp, fi, vd, dout, F, p),
+                  oracle.spmm_bwd(fp, fi, np.abs(vd), np.abs(dout), F, p))
+    check(vals)
+    # fused input dropout with injected decisions == oracle on pre-dropped values
+    keep = rng.integers(0, 2, fi.size).astype(np.uint8)
+    check((vals * np.where(keep != 0, np.float32(2), np.float32(0))).astype(np.float32), p_drop=0.5, keep_mask=keep)
+    # device RNG
+    seed, epoch = 99, 3
+    k = philox_keep(seed, epoch, np.arange(fi.size, dtype=np.uint64), thr_of(0.5))
+    check((vals * np.where(k, np.float32(2), np.float32(0))).astype(np.float32), p_drop=0.5, seed=seed, epoch=epoch)
+    f.free()
+
+
+@pytest.mark.parametrize("N,F,p", [(300, 50, 16), (257, 602, 128), (130, 36, 41), (64, 33, 7)])
+def test_spmm_dense_vs_oracle(dev, oracle, N, F, p):
+    """X stored as CSR with every column present (the Reddit case) takes the MFMA path"""
+    rng = np.random.default_rng(N + F)
+    vals = rng.standard_normal(N * F).astype(np.float32)
+    fp = (np.arange(N + 1) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    w = rng.standard_normal((F, p)).astype(np.float32)
+    dout = rng.standard_normal((N, p)).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    assert f.dense
+    def check(vd, **kw):
+        close_mag(dev.spmm_fwd(f, w, **kw), oracle.spmm_fwd(fp, fi, vd, w, p), oracle.spmm_fwd(fp, fi, np.abs(vd), np.abs(w), p))
+        close_mag(dev.spmm_bwd(f, dout, **kw), oracle.spmm_bwd(fp, fi, vd, dout, F, p),
+                  oracle.spmm_bwd(fp, fi, np.abs(vd), np.abs(dout), F, p))
+    check(vals)
+    keep = rng.integers(0, 2, N * F).astype(np.uint8)
+    check((vals * np.where(keep != 0, np.float32(2), np.float32(0))).astype(np.float32), p_drop=0.5, keep_mask=keep)
+    seed, epoch = 7, 11
+    k = philox_keep(seed, epoch, np.arange(N * F, dtype=np.uint64), thr_of(0.5))
+    check((vals * np.where(k, np.float32(2), np.float32(0))).astype(np.float32), p_drop=0.5, seed=seed, epoch=epoch)
+    f.free()
+
+
+@pytest.mark.parametrize("p", [16, 8, 3])
+def test_spmm_golden(dev, mods, p):
+    fp, fi, F = mods["sp_tiny_indptr"], mods["sp_tiny_indices"], int(mods["sp_tiny_F"])
+    k = f"sp_tiny_p{p}"
+    f = dev.feat(fp, fi, mods[k + "_val"], F)
+    close(dev.spmm_fwd(f, mods[k + "_w"]), mods[k + "_c"], atol=5e-6)
+    close(dev.spmm_bwd(f, mods[k + "_cg"]), mods[k + "_wg"], atol=2e-5)
+    f.free()
+
+
+# ----------------------------------------------------------------------- Matmul
+@pytest.mark.parametrize("m,n,p,pad", [(97, 128, 41, 0), (97, 128, 41, 3), (2708, 16, 7, 0), (2708, 16, 7, 1), (5, 3, 2, 0),
+                                       (1, 1, 1, 0), (1000, 64, 48, 0), (333, 100, 130, 0)])
+def test_matmul_vs_oracle(dev, oracle, m, n, p, pad):
+    rng = np.random.default_rng(m + n + p)
+    a = rng.standard_normal((m, n)).astype(np.float32)
+    b = rng.standard_normal((n, p)).astype(np.float32)
+    dc = rng.standard_normal((m, p)).astype(np.float32)
+    lda, ldb = n + pad, p + pad
+    close_mag(dev.matmul_fwd(a, b, lda=lda, ldb=ldb, ldc=ldb), oracle.matmul_fwd(a, b, m, n, p),
+              oracle.matmul_fwd(np.abs(a), np.abs(b), m, n, p))
+    da, db = dev.matmul_bwd(a, b, dc, lda=lda, ldb=ldb, lddc=ldb)
+    oa, ob = oracle.matmul_bwd(a, b, dc, m, n, p)
+    ma, mb = oracle.matmul_bwd(np.abs(a), np.abs(b), np.abs(dc), m, n, p)
+    close_mag(da, oa, ma)
+    close_mag(db, ob, mb)
+    # fused ReLU+dropout backward epilogue: a plays the forward output h
+    da2, db2 = dev.matmul_bwd(a, b, dc, lda=lda, ldb=ldb, lddc=ldb, fused_scale=2.0)
+    close_mag(da2, np.where(a > 0, oa * np.float32(2), 0), 2 * ma)
+    close_mag(db2, ob, mb)
+
+
+@pytest.mark.parametrize("shape", [(34, 16, 7), (97, 128, 41), (5, 3, 2), (1, 1, 1)])
+def test_matmul_golden(dev, mods, shape):
+    m, n, p = shape
+    k = f"mm_{m}x{n}x{p}"
+    close(dev.matmul_fwd(mods[k + "_a"], mods[k + "_b"]), mods[k + "_c"], rtol=2e-5, atol=2e-5)
+    da, db = dev.matmul_bwd(mods[k + "_a"], mods[k + "_b"], mods[k + "_cg"])
+    close(da, mods[k + "_ag"], rtol=2e-5, atol=2e-5)
+    close(db, mods[k + "_bg"], rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------- ReLU / Dropout
+def test_relu_dropout_exact(dev, oracle, mods):
+    x, g = mods["relu_x"], mods["relu_g"]
+    y, mask = dev.relu_fwd(x)
+    assert np.array_equal(y.view(np.uint32), mods["relu_y"].view(np.uint32))
+    assert np.array_equal(dev.relu_bwd(g, mask).view(np.uint32), mods["relu_gb"].view(np.uint32))
+    # eval mode leaves the mask alone but still clamps (module.cpp:178-181)
+    y2, mask2 = dev.relu_fwd(x, training=False)
+    assert np.array_equal(y2, y) and not mask2.any()
+    # dropout with the reference's own decisions injected: bit-exact vs the golden
+    s0, s1 = (int(v) for v in mods["drop_state"])
+    for p in (0.5, 0.0, 0.9):
+        oracle.rand_set_state(s0, s1)
+        _, omask = oracle.dropout_fwd(mods["drop_x"], p)
+        y, m = dev.dropout_fwd(mods["drop_x"], p, keep_in=omask.astype(np.uint8))
+        assert np.array_equal(y.view(np.uint32), mods[f"drop_p{p}_y"].view(np.uint32))
+        assert np.array_equal(m, omask)
+        gb = dev.dropout_bwd(mods["drop_g"], m, p)
+        assert np.array_equal(gb.view(np.uint32), mods[f"drop_p{p}_gb"].view(np.uint32))
+
+
+def test_dropout_device_rng(dev):
+    n = 100003
+    x = np.ones(n, np.float32)
+    for p in (0.5, 0.1, 0.0):
+        y, m = dev.dropout_fwd(x, p, seed=42, epoch=5, elem_offset=12345)
+        k = philox_keep(42, 5, np.arange(n, dtype=np.uint64) + np.uint64(12345), thr_of(p))
+        assert np.array_equal(m != 0, k)
+        scale = np.float32(1) / (np.float32(1) - np.float32(p))
+        assert np.array_equal(y, np.where(k, scale, np.float32(0)))
+        assert abs(k.mean() - (1 - p)) < 0.01
+    # different epoch / seed -> different masks; partition invariance via elem_offset
+    _, m1 = dev.dropout_fwd(x, 0.5, seed=42, epoch=6, elem_offset=0)
+    _, m2 = dev.dropout_fwd(x, 0.5, seed=42, epoch=5, elem_offset=0)
+    assert (m1 != m2).mean() > 0.4
+    _, ma = dev.dropout_fwd(x[:5000], 0.5, seed=1, epoch=0, elem_offset=0)
+    _, mb = dev.dropout_fwd(x[:3000], 0.5, seed=1, epoch=0, elem_offset=2000)
+    assert np.array_equal(ma[2000:5000], mb)
+
+
+def test_relu_dropout_bwd(dev):
+    rng = np.random.default_rng(8)
+    h = np.maximum(rng.standard_normal((333, 16)), 0).astype(np.float32)
+    g = rng.standard_normal((333, 16)).astype(np.float32)
+    got = dev.relu_dropout_bwd(g, h, 2.0)
+    assert np.array_equal(got, np.where(h > 0, g * np.float32(2), np.float32(0)))
+
+
+# --------------------------------------------------------- CrossEntropy / accuracy
+def np_accuracy(logits, truth):
+    """gcn.cpp:83-96: wrong iff some logit is strictly above the true one"""
+    correct = total = 0
+    for i in range(truth.size):
+        if truth[i] < 0:
+            continue
+        total += 1
+        correct += int(not (logits[i] > logits[i, truth[i]]).any())
+    return correct, total
+
+
+@pytest.mark.parametrize("n,c,ld", [(50, 7, 7), (2708, 7, 8), (5000, 41, 41), (5000, 41, 44), (300, 3, 3), (64, 100, 100)])
+def test_xent_vs_oracle(dev, oracle, n, c, ld):
+    rng = np.random.default_rng(n + c)
+    lg = (rng.standard_normal((n, c)) * 3).astype(np.float32)
+    lg[1] = 1.5                                # all-tie row counts as correct
+    tr = rng.integers(-1, c, n).astype(np.int32)
+    tr[1] = c - 1
+    for training in (True, False):
+        loss, shifted, grad = oracle.xent_fwd(lg, tr, c, training)
+        cnt = int((tr >= 0).sum())
+        for count in (cnt, 0):                 # known count, and counted on device
+            r = dev.xent_fwd(lg, tr, training=training, count=count if training else cnt, ld=ld)
+            assert r["total"] == cnt
+            assert abs(r["loss_sum"] / cnt - loss) <= 1e-5 * max(1.0, abs(loss))
+            close(r["logits"], shifted, rtol=0, atol=0)          # max-shift is exact
+            assert (r["correct"], r["total"]) == np_accuracy(lg, tr)
+            if training:
+                close(r["grad"], grad, rtol=1e-5, atol=1e-8)
+    assert dev.accuracy(lg, tr, ld=ld) == np_accuracy(lg, tr)
+
+
+def test_xent_golden(dev, mods):
+    lg, tr = mods["ce_logits"], mods["ce_truth"]
+    cnt = int((tr >= 0).sum())
+    r = dev.xent_fwd(lg, tr, training=True, count=cnt)
+    assert abs(r["loss_sum"] / cnt - float(mods["ce_loss_t1"])) <= 1e-5 * abs(float(mods["ce_loss_t1"]))
+    close(r["logits"], mods["ce_shifted_t1"], rtol=0, atol=0)
+    close(r["grad"], mods["ce_grad"], rtol=1e-5, atol=1e-8)
+
+
+def test_set_truth_sumsq(dev):
+    rng = np.random.default_rng(1)
+    split = rng.integers(0, 4, 1000).astype(np.int32)
+    label = rng.integers(0, 41, 1000).astype(np.int32)
+    for s in (1, 2, 3):
+        assert np.array_equal(dev.set_truth(split, label, s), np.where(split == s, label, -1))
+    x = rng.standard_normal(77056).astype(np.float32)
+    want = float((x.astype(np.float64) ** 2).sum())
+    assert abs(dev.sumsq(x) - want) <= 1e-5 * want
+
+
+# ------------------------------------------------------------------------- Adam
+def test_adam_vs_oracle(dev, oracle, mods):
+    w0, gs = mods["adam_w0"], mods["adam_grads"]
+    for decay, key in ((1, "adam_w_decay"), (0, "adam_w_nodecay")):
+        (w,), sq = dev.adam_steps([w0], [[g] for g in gs], [decay], 0.01, 5e-4)
+        close(w, mods[key], rtol=2e-6, atol=1e-7)
+        assert abs(sq - float((w.astype(np.float64) ** 2).sum())) <= 1e-5 * sq
+    # two variables in one launch (W1 with decay, W2 without), like gcn.cpp:65
+    rng = np.random.default_rng(3)
+    w1, w2 = rng.standard_normal(2000).astype(np.float32), rng.standard_normal(112).astype(np.float32)
+    g1, g2 = rng.standard_normal((5, 2000)).astype(np.float32), rng.standard_normal((5, 112)).astype(np.float32)
+    (a, b), _ = dev.adam_steps([w1, w2], [[g1[t], g2[t]] for t in range(5)], [1, 0], 0.01, 5e-4)
+    close(a, oracle.adam_steps(w1, g1, 1, 0.01, 5e-4)[0], rtol=2e-6, atol=1e-7)
+    close(b, oracle.adam_steps(w2, g2, 0, 0.01, 5e-4)[0], rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------- full-size properties (BASELINE sizes)
+def test_graphsum_reddit_size_properties(dev):
+    """reddit-syn adjacency (232 965 nodes, 23.4 M stored edges), d = 128:
+    (1) A_hat . 1 equals the per-row coefficient sums (checksum of checksums);
+    (2) <y, A_hat x> == <A_hat y, x> (the operator is symmetric, which is what
+        lets the reference reuse it for backward, module.cpp:95);
+    (3) linearity A(ax + by) = aAx + bAy."""
+    ds = datagen.make_dataset("reddit-syn")
+    gp, gi = ds["g_indptr"], ds["g_indices"]
+    n = gp.size - 1
+    g = dev.graph(gp, gi)
+    coef = g.coef().astype(np.float64)
+    rowsum = np.add.reduceat(coef, gp[:-1].astype(np.int64))
+    ones = np.ones((n, 4), np.float32)
+    got = dev.graphsum(g, ones)
+    assert np.allclose(got[:, 0], rowsum, rtol=1e-5, atol=1e-6)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, 128)).astype(np.float32)
+    y = rng.standard_normal((n, 128)).astype(np.float32)
+    ax, ay = dev.graphsum(g, x), dev.graphsum(g, y)
+    lhs = float((y.astype(np.float64) * ax).sum())
+    rhs = float((ay.astype(np.float64) * x).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0) + 1e-2
+    comb = dev.graphsum(g, (np.float32(0.5) * x + np.float32(2) * y).astype(np.float32))
+    assert np.allclose(comb, 0.5 * ax.astype(np.float64) + 2 * ay, rtol=1e-4, atol=1e-4)
+    # d = 41 with padded rows (ld 44) agrees with the first 41 columns at d = 128? no: own check vs row sums
+    got41 = dev.graphsum(g, np.ones((n, 41), np.float32), ld_in=44, ld_out=44)
+    assert np.allclose(got41[:, 40], rowsum, rtol=1e-5, atol=1e-6)
+    g.free()
