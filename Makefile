@@ -7,7 +7,7 @@ LIBDIR   = $(PKG)/lib
 BINDIR   = $(PKG)/bin
 OBJDIR   = build/obj
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Iinclude
-CXXFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -Iinclude -I$(PKG)/host
+CXXFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -Iinclude -I$(PKG)/host -I/opt/rocm/include -D__HIP_PLATFORM_AMD__
 
 KSRC = $(wildcard $(PKG)/csrc/*.hip)
 KOBJ = $(patsubst $(PKG)/csrc/%.hip,$(OBJDIR)/%.o,$(KSRC))

@@ -119,7 +119,40 @@ def _declare_gcnhip(lib):
         fn.argtypes = args
 
 
-GCNHOST_SYMBOLS = {}
+class HostParams(C.Structure):
+    _fields_ = [("num_nodes", I), ("input_dim", I), ("hidden_dim", I), ("output_dim", I),
+                ("dropout", F), ("learning_rate", F), ("weight_decay", F), ("epochs", I), ("early_stopping", I)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(None, P, C.POINTER(C.c_float), C.c_size_t)
+ALLREDUCE_FN = C.CFUNCTYPE(None, P, C.POINTER(C.c_double), C.c_size_t)
+PP = C.POINTER(P)
+
+GCNHOST_SYMBOLS = {
+    "gcnhost_last_error": (C.c_char_p, []),
+    "gcnhost_params_default": (HostParams, []),
+    "gcnhost_nccl_unique_id": (I, [C.c_char_p]),
+    "gcnhost_model_create": (I, [PP, C.POINTER(HostParams), P, P, P, P, P, P, P, C.c_long, I, I, I, I, C.c_char_p,
+                                 ALLGATHER_FN, ALLREDUCE_FN, P]),
+    "gcnhost_model_destroy": (I, [P]),
+    "gcnhost_model_train_epoch": (I, [P, C.POINTER(F), C.POINTER(F)]),
+    "gcnhost_model_eval": (I, [P, I, C.POINTER(F), C.POINTER(F)]),
+    "gcnhost_model_run_epochs": (I, [P, I, P]),
+    "gcnhost_model_run": (I, [P]),
+    "gcnhost_model_sync": (I, [P]),
+    "gcnhost_model_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
+    "gcnhost_model_get_var": (I, [P, I, I, P, C.POINTER(I), C.POINTER(I)]),
+    "gcnhost_model_set_weights": (I, [P, P, P]),
+    "gcnhost_model_timer": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "gcnhost_model_timers_reset": (I, [P]),
+    "gcnhost_dataset_load": (I, [PP, C.c_char_p, C.c_char_p, C.POINTER(HostParams)]),
+    "gcnhost_dataset_arrays": (I, [P, PP, PP, C.POINTER(I64), PP, PP, PP, C.POINTER(I64), PP, C.POINTER(I64), PP, C.POINTER(I64)]),
+    "gcnhost_dataset_save_binary": (I, [P, C.POINTER(HostParams), C.c_char_p]),
+    "gcnhost_dataset_free": (I, [P]),
+    "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
+    "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
+    "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),
+}
 
 
 def _declare_gcnhost(lib):

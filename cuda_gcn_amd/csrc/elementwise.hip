@@ -143,11 +143,11 @@ __global__ void counter_add_kernel(uint32_t *c, uint32_t inc) { *c += inc; }
 __global__ void metrics_record_kernel(float *ring, int capacity, int slot, const uint32_t *d_epoch,
                                       const float *res, const int32_t *res_i, const float *sumsq) {
     const uint32_t e = d_epoch ? *d_epoch : 0u;
-    float *row = ring + ((size_t)(e % (uint32_t)capacity) * 2 + slot) * 8;
+    float *row = ring + ((size_t)(e % (uint32_t)capacity) * 4 + slot) * 8;
     row[0] = res[0];
     row[1] = res[1];
-    row[2] = (float)res_i[0];
-    row[3] = (float)res_i[1];
+    row[2] = res_i ? (float)res_i[0] : res[2];
+    row[3] = res_i ? (float)res_i[1] : res[3];
     row[4] = sumsq ? *sumsq : 0.f;
     row[5] = (float)e;
     row[6] = 0.f;
@@ -242,7 +242,7 @@ int gcnhip_counter_add(gcnhip_ctx *c, uint32_t *d_counter, uint32_t inc) {
 int gcnhip_metrics_record(gcnhip_ctx *c, float *d_ring, int capacity, int slot_in_row,
                           const uint32_t *d_epoch, const float *d_result, const int32_t *d_result_i,
                           const float *d_sumsq) {
-    if (!c || !d_ring || capacity <= 0 || !d_result || !d_result_i || slot_in_row < 0 || slot_in_row > 1) return -1;
+    if (!c || !d_ring || capacity <= 0 || !d_result || slot_in_row < 0 || slot_in_row > 3) return -1;
     metrics_record_kernel<<<1, 1, 0, c->stream>>>(d_ring, capacity, slot_in_row, d_epoch, d_result, d_result_i, d_sumsq);
     GCNHIP_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,171 @@
+// capi.cpp — extern "C" surface of the host library (include/gcnhost.h).
+#include "gcnhost.h"
+#include <cstring>
+#include <string>
+#include "gcn.h"
+#include "hip_check.h"
+#include "parser.h"
+
+static thread_local std::string g_err;
+
+struct gcnhost_model {
+    GCNData data;
+    HipGCN *gcn = nullptr;
+};
+struct gcnhost_dataset {
+    GCNData data;
+};
+
+#define API_TRY(...)                                    \
+    try {                                               \
+        __VA_ARGS__;                                    \
+        return 0;                                       \
+    } catch (const GcnHipFailure &e) {                  \
+        g_err = e.what();                               \
+        return e.code ? e.code : -1;                    \
+    } catch (const std::exception &e) {                 \
+        g_err = e.what();                               \
+        return -1;                                      \
+    }
+
+extern "C" {
+
+const char *gcnhost_last_error(void) { return g_err.c_str(); }
+
+gcnhost_params gcnhost_params_default(void) {
+    GCNParams d = GCNParams::get_default();
+    gcnhost_params p;
+    memcpy(&p, &d, sizeof p);
+    return p;
+}
+
+int gcnhost_nccl_unique_id(char id[GCNHOST_NCCL_ID_BYTES]) { return rccl_get_unique_id(id); }
+
+int gcnhost_model_create(gcnhost_model **out, const gcnhost_params *p,
+                         const int *g_indptr, const int *g_indices,
+                         const int *f_indptr, const int *f_indices, const float *f_val,
+                         const int *split, const int *label,
+                         long seed, int device, int flags, int rank, int world, const char *nccl_id,
+                         gcnhost_allgather_fn host_ag, gcnhost_allreduce_fn host_ar, void *host_user) {
+    if (!out || !p || !g_indptr || !g_indices || !f_indptr || !f_val || !split || !label) { g_err = "null argument"; return -1; }
+    API_TRY({
+        gcnhost_model *m = new gcnhost_model();
+        const int N = p->num_nodes;
+        m->data.graph.indptr.assign(g_indptr, g_indptr + N + 1);
+        m->data.graph.indices.assign(g_indices, g_indices + g_indptr[N]);
+        m->data.feature_index.indptr.assign(f_indptr, f_indptr + N + 1);
+        if (f_indices) m->data.feature_index.indices.assign(f_indices, f_indices + f_indptr[N]);
+        m->data.feature_value.assign(f_val, f_val + f_indptr[N]);
+        m->data.split.assign(split, split + N);
+        m->data.label.assign(label, label + N);
+        GCNParams gp;
+        static_assert(sizeof(GCNParams) == sizeof(gcnhost_params), "params layout");
+        memcpy(&gp, p, sizeof gp);
+        HipGCNOptions o;
+        o.device = device; o.seed = seed; o.flags = flags; o.rank = rank; o.world = world; o.nccl_id = nccl_id;
+        o.host_allgather = host_ag; o.host_allreduce = host_ar; o.host_user = host_user;
+        try {
+            m->gcn = new HipGCN(gp, &m->data, o);
+        } catch (...) {
+            delete m;
+            throw;
+        }
+        *out = m;
+    })
+}
+
+int gcnhost_model_destroy(gcnhost_model *m) {
+    if (!m) return 0;
+    API_TRY({ delete m->gcn; delete m; })
+}
+int gcnhost_model_train_epoch(gcnhost_model *m, float *loss, float *acc) {
+    API_TRY({ auto r = m->gcn->train_epoch(); *loss = r.first; *acc = r.second; })
+}
+int gcnhost_model_eval(gcnhost_model *m, int split, float *loss, float *acc) {
+    API_TRY({ auto r = m->gcn->eval(split); *loss = r.first; *acc = r.second; })
+}
+int gcnhost_model_run_epochs(gcnhost_model *m, int n, float *trace) { API_TRY({ m->gcn->run_epochs(n, trace); }) }
+int gcnhost_model_run(gcnhost_model *m) { API_TRY({ m->gcn->run(); }) }
+int gcnhost_model_sync(gcnhost_model *m) { API_TRY({ m->gcn->sync(); }) }
+
+int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges) {
+    API_TRY({
+        if (rank) *rank = m->gcn->rank();
+        if (world) *world = m->gcn->world();
+        if (row_start) *row_start = m->gcn->row_start();
+        if (local_rows) *local_rows = m->gcn->local_rows();
+        if (local_edges) *local_edges = m->gcn->n_edges_local();
+    })
+}
+int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *rows, int *cols) {
+    API_TRY({
+        std::vector<float> v;
+        int r, c;
+        m->gcn->get_var(k, grad != 0, v, &r, &c);
+        if (rows) *rows = r;
+        if (cols) *cols = c;
+        if (out) memcpy(out, v.data(), v.size() * sizeof(float));
+    })
+}
+int gcnhost_model_set_weights(gcnhost_model *m, const float *w1, const float *w2) { API_TRY({ m->gcn->set_weights(w1, w2); }) }
+int gcnhost_model_timer(gcnhost_model *m, int id, double *seconds, long *count) {
+    if (id < 0 || id >= __NUM_TMR) { g_err = "bad timer id"; return -1; }
+    API_TRY({ *seconds = m->gcn->device_timers().total((timer_instance)id, count); })
+}
+int gcnhost_model_timers_reset(gcnhost_model *m) { API_TRY({ m->gcn->device_timers().reset(); }) }
+
+int gcnhost_dataset_load(gcnhost_dataset **out, const char *root, const char *name, gcnhost_params *p) {
+    API_TRY({
+        gcnhost_dataset *d = new gcnhost_dataset();
+        GCNParams gp;
+        memcpy(&gp, p, sizeof gp);
+        Parser parser(&gp, &d->data, name, root ? root : "");
+        if (!parser.parse()) { delete d; throw std::runtime_error(std::string("Cannot read input: ") + name); }
+        memcpy(p, &gp, sizeof gp);
+        *out = d;
+    })
+}
+int gcnhost_dataset_arrays(gcnhost_dataset *d, const int **g_indptr, const int **g_indices, int64_t *g_nnz,
+                           const int **f_indptr, const int **f_indices, const float **f_val, int64_t *f_nnz,
+                           const int **split, int64_t *n_split, const int **label, int64_t *n_label) {
+    if (!d) return -1;
+    *g_indptr = d->data.graph.indptr.data(); *g_indices = d->data.graph.indices.data(); *g_nnz = (int64_t)d->data.graph.indices.size();
+    *f_indptr = d->data.feature_index.indptr.data(); *f_indices = d->data.feature_index.indices.data();
+    *f_val = d->data.feature_value.data(); *f_nnz = (int64_t)d->data.feature_value.size();
+    *split = d->data.split.data(); *n_split = (int64_t)d->data.split.size();
+    *label = d->data.label.data(); *n_label = (int64_t)d->data.label.size();
+    return 0;
+}
+int gcnhost_dataset_save_binary(gcnhost_dataset *d, const gcnhost_params *p, const char *path) {
+    GCNParams gp;
+    memcpy(&gp, p, sizeof gp);
+    return Parser::save_binary(path, gp, d->data) ? 0 : -1;
+}
+int gcnhost_dataset_free(gcnhost_dataset *d) { delete d; return 0; }
+
+int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start, int *rows_max) {
+    if (!g_indptr || !start || world < 1) return -1;
+    RowPartition p = make_partition(g_indptr, n_rows, world);
+    for (int q = 0; q <= world; q++) start[q] = p.start[q];
+    if (rows_max) *rows_max = p.rows_max;
+    return 0;
+}
+int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws) {
+    HostRng rng;
+    rng.seed_time((unsigned)seed);
+    for (int i = 0; i < skip_draws; i++) rng.next();
+    Variable v(size, false);
+    v.glorot(in_size, out_size, rng);
+    memcpy(w, v.data.data(), (size_t)size * sizeof(float));
+    return 0;
+}
+int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t skip_draws) {
+    HostRng rng;
+    rng.seed_time((unsigned)seed);
+    for (int64_t i = 0; i < skip_draws; i++) rng.next();
+    const int thr = (int)(p * MY_RAND_MAX);
+    for (int64_t i = 0; i < n; i++) keep[i] = (int)rng.next() >= thr;
+    return 0;
+}
+
+}  // extern "C"

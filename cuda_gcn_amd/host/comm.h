@@ -1,0 +1,41 @@
+// comm.h — the two collectives the row-partitioned epoch needs.
+// The reference has no distributed layer; this is new work for 1..8 MI355X of
+// one node: one process (or thread) per GPU, RCCL over xGMI.
+//   allgather_rows: every rank contributes its block of an [world*block] f32
+//                   buffer IN PLACE (block r lives at base + r*block_elems);
+//   allreduce_sum : in-place f32 sum (weight gradients + loss/accuracy scalars).
+// Both are enqueued on the context's stream: no host synchronisation.
+#pragma once
+#include <cstddef>
+#include "gcnhip.h"
+
+struct Comm {
+    virtual ~Comm() {}
+    virtual int rank() const = 0;
+    virtual int size() const = 0;
+    virtual void allgather_rows(float *base, size_t block_elems) = 0;
+    virtual void allreduce_sum(float *buf, size_t n) = 0;
+    virtual void allreduce_sum_host(double *vals, int n) = 0;   // init-time scalars (synchronises)
+};
+
+// world == 1: nothing to exchange
+struct SelfComm : Comm {
+    int rank() const override { return 0; }
+    int size() const override { return 1; }
+    void allgather_rows(float *, size_t) override {}
+    void allreduce_sum(float *, size_t) override {}
+    void allreduce_sum_host(double *, int) override {}
+};
+
+// RCCL (librccl; "nccl" API) on the context's stream
+#define GCN_NCCL_ID_BYTES 128
+int rccl_get_unique_id(char id[GCN_NCCL_ID_BYTES]);
+Comm *make_rccl_comm(gcnhip_ctx *ctx, int rank, int world, const char id[GCN_NCCL_ID_BYTES]);
+
+// Host-staged comm through caller-supplied callbacks (D2H -> callback -> H2D).
+// Diagnostic / test transport: lets N ranks be driven by any host-side
+// collective (torch.distributed gloo in tests/) without RCCL, e.g. two ranks
+// sharing one GPU.  Never used for timing.
+typedef void (*gcn_host_allgather_fn)(void *user, float *host_full, size_t block_elems);   // in place on host
+typedef void (*gcn_host_allreduce_fn)(void *user, double *host_buf, size_t n);
+Comm *make_host_comm(gcnhip_ctx *ctx, int rank, int world, gcn_host_allgather_fn ag, gcn_host_allreduce_fn ar, void *user);

@@ -1,0 +1,363 @@
+#include "gcn.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <tuple>
+#include "hip_check.h"
+
+GCNParams GCNParams::get_default() { return {2708, 1433, 16, 7, 0.5, 0.01, 5e-4, 100, 0}; }
+
+namespace {
+template <class T>
+T *dev_upload(gcnhip_ctx *ctx, const T *h, size_t n) {
+    void *p;
+    GCNHIP_CHECK(gcnhip_malloc(ctx, &p, (n ? n : 1) * sizeof(T)));
+    if (n) GCNHIP_CHECK(gcnhip_h2d(ctx, p, h, n * sizeof(T)));
+    return (T *)p;
+}
+}  // namespace
+
+HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : params(p), data(input_data), flags(opt.flags) {
+    GCNHIP_CHECK(gcnhip_ctx_create(&env.ctx, opt.device, nullptr));
+    timers.reset(new DeviceTimers(env.ctx));
+    timers->enabled = (flags & HIPGCN_TIMERS) != 0;
+    env.timers = timers.get();
+    if (opt.comm) {
+        env.comm = opt.comm;
+        if (opt.own_comm) owned_comm.reset(opt.comm);
+    } else if (opt.world > 1 && opt.host_allgather) {
+        owned_comm.reset(make_host_comm(env.ctx, opt.rank, opt.world, opt.host_allgather, opt.host_allreduce, opt.host_user));
+        env.comm = owned_comm.get();
+    } else if (opt.world > 1) {
+        if (!opt.nccl_id) throw GcnHipFailure(-1, "world > 1 needs an RCCL unique id");
+        owned_comm.reset(make_rccl_comm(env.ctx, opt.rank, opt.world, opt.nccl_id));
+        env.comm = owned_comm.get();
+    } else {
+        owned_comm.reset(new SelfComm());
+        env.comm = owned_comm.get();
+    }
+    env.seed = (uint64_t)opt.seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    const int world = env.comm->size(), rank = env.comm->rank();
+    const int N = params.num_nodes, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
+
+    // ---- row partition + this rank's slice of the graph, features, labels
+    const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
+    part = make_partition(gp.data(), N, world);
+    const int r0 = part.start[rank], r1 = part.start[rank + 1];
+    n_local = r1 - r0;
+    nnzA_local = (long)gp[r1] - gp[r0];
+    {
+        std::vector<int> lp(n_local + 1), li((size_t)nnzA_local);
+        for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
+        std::vector<int> col_deg;
+        if (world > 1) {
+            col_deg.assign((size_t)world * part.rows_max, 1);
+            for (int j = 0; j < N; j++) col_deg[part.padded(j)] = gp[j + 1] - gp[j];
+            // padded position of every global column, computed once
+            std::vector<int> pad(N);
+            for (int q = 0; q < world; q++)
+                for (int j = part.start[q]; j < part.start[q + 1]; j++) pad[j] = q * part.rows_max + (j - part.start[q]);
+            for (long e = 0; e < nnzA_local; e++) li[e] = pad[gi[gp[r0] + e]];
+            GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lp.data(), li.data(), n_local, world * part.rows_max, col_deg.data()));
+        } else {
+            GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
+        }
+    }
+    const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
+    const long f0 = fp[r0], f1 = fp[r1];
+    {
+        std::vector<int> lp(n_local + 1);
+        for (int r = 0; r <= n_local; r++) lp[r] = fp[r0 + r] - fp[r0];
+        GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &feat, lp.data(), fi.empty() ? nullptr : fi.data() + f0,
+                                        data->feature_value.data() + f0, n_local, F));
+    }
+    // truth per split, once (the reference rebuilds and re-uploads it per call: cuda_gcn.cu:85-97)
+    {
+        int32_t *d_split = dev_upload(env.ctx, data->split.data() + r0, (size_t)n_local);
+        int32_t *d_label = dev_upload(env.ctx, data->label.data() + r0, (size_t)n_local);
+        double cnt[4] = {0, 0, 0, 0};
+        for (int s = 1; s <= 3; s++) {
+            void *t;
+            GCNHIP_CHECK(gcnhip_malloc(env.ctx, &t, (size_t)(n_local ? n_local : 1) * sizeof(int32_t)));
+            d_truth[s] = (int32_t *)t;
+            GCNHIP_CHECK(gcnhip_set_truth(env.ctx, d_truth[s], d_split, d_label, n_local, s));
+            for (int i = r0; i < r1; i++) cnt[s] += data->split[i] == s;
+        }
+        GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
+        gcnhip_free(env.ctx, d_split);
+        gcnhip_free(env.ctx, d_label);
+        env.comm->allreduce_sum_host(cnt, 4);
+        for (int s = 1; s <= 3; s++) split_count[s] = (int)cnt[s];
+    }
+
+    // ---- variables (numbering of gcn.cpp:21-54)
+    variables.resize(7);
+    for (auto &v : variables) v.reset(new HipVariable());
+    const int rm = part.rows_max;
+    if (flags & HIPGCN_MODULAR) {
+        if (H % 4 != 0) throw GcnHipFailure(-1, "modular mode needs hidden_dim % 4 == 0");
+        variables[0]->alloc(env.ctx, 1, (int)(f1 - f0), false);
+        input = variables[0].get();
+        input_vals = input->data;
+    } else {
+        input_vals = gcnhip_feat_values(feat);
+    }
+    variables[1]->alloc(env.ctx, n_local, H, true, true, false, world, rank, rm);    // H0: data gathered
+    variables[3]->alloc(env.ctx, n_local, H, true, false, true, world, rank, rm);    // H1: grad gathered
+    variables[4]->alloc(env.ctx, n_local, C, true, true, false, world, rank, rm);    // Z0: data gathered
+    variables[6]->alloc(env.ctx, n_local, C, true, false, true, world, rank, rm);    // Z : grad gathered
+    output = variables[6].get();
+    HipVariable *W1 = variables[2].get(), *W2 = variables[5].get();
+    W1->alloc(env.ctx, F, H, false);
+    W2->alloc(env.ctx, H, C, false);
+    // both weight gradients and the 4 loss/accuracy scalars share one buffer: one all-reduce per epoch
+    gradbuf_elems = W1->elems() + W2->elems() + 4;
+    {
+        void *q;
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, gradbuf_elems * sizeof(float)));
+        GCNHIP_CHECK(gcnhip_memset_async(env.ctx, q, 0, gradbuf_elems * sizeof(float)));
+        gradbuf = (float *)q;
+        W1->grad = gradbuf; W1->requires_grad = true;
+        W2->grad = gradbuf + W1->elems(); W2->requires_grad = true;
+        d_result = gradbuf + W1->elems() + W2->elems();
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, 2 * sizeof(int32_t)));
+        d_result_i = (int32_t *)q;
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, (size_t)RING * 4 * 8 * sizeof(float)));
+        d_ring = (float *)q;
+        GCNHIP_CHECK(gcnhip_memset_async(env.ctx, q, 0, (size_t)RING * 4 * 8 * sizeof(float)));
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, sizeof(uint32_t)));
+        env.d_epoch = (uint32_t *)q;
+        GCNHIP_CHECK(gcnhip_memset_async(env.ctx, q, 0xFF, sizeof(uint32_t)));   // -1: the first train epoch makes it 0
+    }
+    // Glorot with the reference's RNG and draw order: all of W1, then all of W2 (gcn.cpp:30,49)
+    rng.seed_time((unsigned)opt.seed);
+    {
+        Variable h1(F * H), h2(H * C);
+        h1.glorot(F, H, rng);
+        h2.glorot(H, C, rng);
+        W1->upload(h1.data.data());
+        W2->upload(h2.data.data());
+    }
+    if (flags & HIPGCN_HOST_MASKS) {
+        h_keep0.resize((size_t)(f1 - f0));
+        h_keep1.resize((size_t)n_local * H);
+        void *q;
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, h_keep0.size() + 16)); d_keep0 = (uint8_t *)q;
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, h_keep1.size() + 16)); d_keep1 = (uint8_t *)q;
+        env.keep_input = d_keep0;
+        env.keep_hidden = d_keep1;
+    }
+    build_modules();
+    AdamParams ap = AdamParams::get_default();
+    ap.lr = params.learning_rate;
+    ap.weight_decay = params.weight_decay;
+    optimizer.reset(new HipAdam());
+    optimizer->init(&env, {{W1, true}, {W2, false}}, ap, params.epochs > 0 ? params.epochs + 8 : 8);   // gcn.cpp:62-65
+    GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
+}
+
+void HipGCN::build_modules() {
+    const int N = n_local, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
+    const int rank = env.comm->rank();
+    const uint64_t nnz_off = (uint64_t)data->feature_index.indptr[part.start[rank]];
+    const uint64_t hid_off = (uint64_t)part.start[rank] * H;
+    HipVariable *H0 = variables[1].get(), *W1 = variables[2].get(), *H1 = variables[3].get(),
+                *Z0 = variables[4].get(), *W2 = variables[5].get(), *Z = variables[6].get();
+    const float p = params.dropout;
+    static const uint8_t *const no_mask = nullptr;
+    if (flags & HIPGCN_MODULAR) {
+        // the reference's list, one for one (gcn.cpp:23-59)
+        modules.push_back(new HipDropout(&env, input, p, KEY_INPUT_DROPOUT, nnz_off, (flags & HIPGCN_HOST_MASKS) ? &env.keep_input : &no_mask));
+        modules.push_back(new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, 0.f, nnz_off));
+        modules.push_back(new HipGraphSum(&env, H0, H1, graph, H));
+        modules.push_back(new HipReLU(&env, H1));
+        modules.push_back(new HipDropout(&env, H1, p, KEY_HIDDEN_DROPOUT, hid_off, (flags & HIPGCN_HOST_MASKS) ? &env.keep_hidden : &no_mask));
+        modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C));
+        modules.push_back(new HipGraphSum(&env, Z0, Z, graph, C));
+        modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, true));
+    } else {
+        const float scale = 1 / (1 - p);
+        modules.push_back(new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, p, nnz_off));
+        modules.push_back(new HipGraphSum(&env, H0, H1, graph, H, p, hid_off));
+        modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C, scale));
+        modules.push_back(new HipGraphSum(&env, Z0, Z, graph, C));
+        modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
+    }
+}
+
+HipGCN::~HipGCN() {
+    if (env.ctx) gcnhip_ctx_sync(env.ctx);
+    for (auto m : modules) delete m;
+    // W1/W2 grads live in gradbuf
+    if (variables.size() == 7) { variables[2]->grad = nullptr; variables[5]->grad = nullptr; }
+    variables.clear();
+    optimizer.reset();
+    if (graph) gcnhip_graph_destroy(env.ctx, graph);
+    if (feat) gcnhip_feat_destroy(env.ctx, feat);
+    for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_truth[s]);
+    gcnhip_free(env.ctx, gradbuf);
+    gcnhip_free(env.ctx, d_result_i);
+    gcnhip_free(env.ctx, d_ring);
+    gcnhip_free(env.ctx, env.d_epoch);
+    gcnhip_free(env.ctx, d_keep0);
+    gcnhip_free(env.ctx, d_keep1);
+    timers.reset();
+    owned_comm.reset();
+    gcnhip_ctx_destroy(env.ctx);
+    env.ctx = nullptr;
+}
+
+void HipGCN::sync() { GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx)); }
+
+void HipGCN::set_truth(int s) {                 // gcn.cpp:78-81: here a pointer switch
+    cur_truth = d_truth[s];
+    cur_count = split_count[s];
+}
+
+// replay the reference's RNG consumption for one training epoch: nnzX draws for
+// the input dropout, then N*h draws for the hidden one (module.cpp:207-221;
+// order fixed by the module list, gcn.cpp:23,42).  Every rank walks the whole
+// stream and keeps its slice, so the decisions do not depend on the partition.
+void HipGCN::host_masks_for_epoch() {
+    const int thr = (int)(params.dropout * MY_RAND_MAX);
+    const int rank = env.comm->rank();
+    const long nnz_total = data->feature_index.indptr[params.num_nodes];
+    const long f0 = data->feature_index.indptr[part.start[rank]];
+    for (long i = 0; i < nnz_total; i++) {
+        const bool keep = (int)rng.next() >= thr;
+        if (i >= f0 && i < f0 + (long)h_keep0.size()) h_keep0[i - f0] = keep;
+    }
+    const long H = params.hidden_dim, h0 = (long)part.start[rank] * H, total = (long)params.num_nodes * H;
+    for (long i = 0; i < total; i++) {
+        const bool keep = (int)rng.next() >= thr;
+        if (i >= h0 && i < h0 + (long)h_keep1.size()) h_keep1[i - h0] = keep;
+    }
+    GCNHIP_CHECK(gcnhip_h2d(env.ctx, d_keep0, h_keep0.data(), h_keep0.size()));
+    GCNHIP_CHECK(gcnhip_h2d(env.ctx, d_keep1, h_keep1.data(), h_keep1.size()));
+}
+
+void HipGCN::train_epoch_async() {              // gcn.cpp:107-118
+    GCNHIP_CHECK(gcnhip_counter_add(env.ctx, env.d_epoch, 1u));
+    epochs_done++;
+    if (flags & HIPGCN_MODULAR)                  // set_input (gcn.cpp:73-76): device-to-device, never from the host
+        GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
+    if (flags & HIPGCN_HOST_MASKS) host_masks_for_epoch();
+    set_truth(1);
+    for (auto m : modules) m->forward(true);
+    for (int i = (int)modules.size() - 1; i >= 0; i--) modules[i]->backward();
+    if (env.comm->size() > 1) {
+        timers->start(TMR_COMM);
+        env.comm->allreduce_sum(gradbuf, gradbuf_elems);
+        timers->stop(TMR_COMM);
+    }
+    // loss/accuracy of this forward + the L2 term of the weights it used, then the update
+    GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, 0, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
+    optimizer->step();
+}
+
+void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
+    if (flags & HIPGCN_MODULAR)
+        GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
+    set_truth(s);
+    for (auto m : modules) m->forward(false);
+    if (env.comm->size() > 1) {
+        timers->start(TMR_COMM);
+        env.comm->allreduce_sum(d_result, 4);
+        timers->stop(TMR_COMM);
+    }
+    GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
+}
+
+std::pair<float, float> HipGCN::read_metrics(long epoch_index, int slot) {
+    float row[8];
+    const uint32_t e = (uint32_t)epoch_index;   // epoch_index == -1 (eval before any training) wraps like the device word
+    GCNHIP_CHECK(gcnhip_d2h(env.ctx, row, d_ring + ((size_t)(e % RING) * 4 + slot) * 8, sizeof row));
+    const float loss = row[0] / (int)row[1];                                    // module.cpp:154
+    const float l2 = params.weight_decay * row[4] / 2;                          // gcn.cpp:104
+    const float acc = (float)row[2] / (int)row[3];                              // gcn.cpp:95
+    return {loss + l2, acc};
+}
+
+std::pair<float, float> HipGCN::train_epoch() {
+    train_epoch_async();
+    return read_metrics(epochs_done - 1, 0);
+}
+
+std::pair<float, float> HipGCN::eval(int s) {
+    eval_async(s);
+    return read_metrics(epochs_done - 1, s == 2 ? 1 : 2);
+}
+
+void HipGCN::run_epochs(int n, float *trace) {
+    int done = 0;
+    while (done < n) {
+        const int chunk = std::min(n - done, RING);
+        const long first = epochs_done;
+        for (int i = 0; i < chunk; i++) { train_epoch_async(); eval_async(2); }
+        sync();
+        if (trace) {
+            std::vector<float> ring((size_t)RING * 32);
+            GCNHIP_CHECK(gcnhip_d2h(env.ctx, ring.data(), d_ring, ring.size() * sizeof(float)));
+            for (int i = 0; i < chunk; i++) {
+                const uint32_t e = (uint32_t)(first + i);
+                for (int slot = 0; slot < 2; slot++) {
+                    const float *row = &ring[((size_t)(e % RING) * 4 + slot) * 8];
+                    trace[(size_t)(done + i) * 4 + slot * 2] = row[0] / (int)row[1] + params.weight_decay * row[4] / 2;
+                    trace[(size_t)(done + i) * 4 + slot * 2 + 1] = (float)row[2] / (int)row[3];
+                }
+            }
+        }
+        done += chunk;
+    }
+}
+
+void HipGCN::run() {                            // gcn.cpp:130-158
+    int epoch = 1;
+    std::vector<float> loss_history;
+    double total_train = 0;
+    const bool talk = env.comm->rank() == 0;
+    for (; epoch <= params.epochs; epoch++) {
+        float train_loss, train_acc, val_loss, val_acc;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        train_epoch_async();
+        eval_async(2);
+        std::tie(train_loss, train_acc) = read_metrics(epochs_done - 1, 0);     // one synchronisation per epoch
+        std::tie(val_loss, val_acc) = read_metrics(epochs_done - 1, 1);
+        const float dt = std::chrono::duration_cast<std::chrono::duration<float>>(std::chrono::high_resolution_clock::now() - t0).count();
+        total_train += dt;
+        if (talk)
+            printf("epoch=%d train_loss=%.5f train_acc=%.5f val_loss=%.5f val_acc=%.5f time=%.5f\n",
+                   epoch, train_loss, train_acc, val_loss, val_acc, dt);
+        loss_history.push_back(val_loss);
+        if (params.early_stopping > 0 && epoch >= params.early_stopping) {
+            float recent_loss = 0.0;
+            for (int i = epoch - params.early_stopping; i < epoch; i++) recent_loss += loss_history[i];
+            if (val_loss > recent_loss / params.early_stopping) {
+                if (talk) printf("Early stopping...\n");
+                break;
+            }
+        }
+    }
+    if (talk) printf("total training time=%.5f\n", (float)total_train);
+    float test_loss, test_acc;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::tie(test_loss, test_acc) = eval(3);
+    const float dt = std::chrono::duration_cast<std::chrono::duration<float>>(std::chrono::high_resolution_clock::now() - t0).count();
+    if (talk) printf("test_loss=%.5f test_acc=%.5f time=%.5f\n", test_loss, test_acc, dt);
+}
+
+void HipGCN::get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols) {
+    if (k < 1 || k > 6) throw GcnHipFailure(-1, "get_var: k must be 1..6");
+    HipVariable *v = variables[k].get();
+    out.resize((size_t)v->rows * v->cols);
+    v->download(out.data(), grad);
+    if (rows) *rows = v->rows;
+    if (cols) *cols = v->cols;
+}
+
+void HipGCN::set_weights(const float *w1, const float *w2) {
+    variables[2]->upload(w1);
+    variables[5]->upload(w2);
+    GCNHIP_CHECK(gcnhip_sumsq(env.ctx, variables[2]->data, (int64_t)variables[2]->elems(), optimizer->d_sumsq));
+    sync();
+}

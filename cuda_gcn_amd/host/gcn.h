@@ -1,0 +1,120 @@
+// gcn.h — the model driver.  GCNParams / GCNData are the reference's types
+// (src/seq/gcn.h:9-22); HipGCN has the shape of GCN / CUDAGCN
+// (src/seq/gcn.h:24-44, src/cuda/cuda_gcn.cuh:11-34): constructed from
+// (GCNParams, GCNData*), driven by run().  Everything between the two lives on
+// the GPU; per epoch the host reads back 2 x 8 floats.
+#pragma once
+#include <memory>
+#include <utility>
+#include <vector>
+#include "comm.h"
+#include "module.h"
+#include "optim.h"
+#include "partition.h"
+#include "sparse.h"
+#include "timer.h"
+#include "variable.h"
+
+struct GCNParams {
+    int num_nodes, input_dim, hidden_dim, output_dim;
+    float dropout, learning_rate, weight_decay;
+    int epochs, early_stopping;
+    static GCNParams get_default();          // {2708,1433,16,7, 0.5, 0.01, 5e-4, 100, 0} (gcn.cpp:9-11)
+};
+
+class GCNData {
+public:
+    SparseIndex feature_index, graph;
+    std::vector<int> split;
+    std::vector<int> label;
+    std::vector<float> feature_value;
+};
+
+enum HipGCNFlags {
+    HIPGCN_MODULAR = 1,       // one module per reference module instead of the fused epilogues
+    HIPGCN_HOST_MASKS = 2,    // parity mode: dropout decisions from the reference's host RNG stream
+    HIPGCN_TIMERS = 4,        // record device-event timers per op
+};
+
+struct HipGCNOptions {
+    int device = 0;
+    long seed = 0;            // plays time(NULL) of src/seq/rand.cpp:7
+    int flags = 0;
+    Comm *comm = nullptr;     // NULL: single GPU.  Not owned unless own_comm.
+    bool own_comm = false;
+    // multi-GPU: RCCL unique id (GCN_NCCL_ID_BYTES) and rank/world when comm == NULL and world > 1
+    int rank = 0, world = 1;
+    const char *nccl_id = nullptr;
+    // or a host-staged transport (tests: torch.distributed gloo through callbacks)
+    gcn_host_allgather_fn host_allgather = nullptr;
+    gcn_host_allreduce_fn host_allreduce = nullptr;
+    void *host_user = nullptr;
+};
+
+class HipGCN {
+public:
+    GCNParams params;
+    HipGCN(GCNParams params, GCNData *data, const HipGCNOptions &opt = HipGCNOptions());
+    ~HipGCN();
+    HipGCN(const HipGCN &) = delete;
+
+    void run();                                               // gcn.cpp:130-158, same output lines
+    std::pair<float, float> train_epoch();                    // synchronises to return (loss, acc)
+    std::pair<float, float> eval(int current_split);
+    // enqueue n x (train_epoch + eval(2)) with no host synchronisation in between, then read back
+    // 4 floats per epoch into trace (may be NULL)
+    void run_epochs(int n, float *trace);
+    void sync();
+
+    // introspection for tests / bench
+    int rank() const { return env.comm->rank(); }
+    int world() const { return env.comm->size(); }
+    int local_rows() const { return n_local; }
+    int row_start() const { return part.start[env.comm->rank()]; }
+    const RowPartition &partition() const { return part; }
+    // variable k as in gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z); rows x cols floats, this rank's rows
+    void get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols);
+    void set_weights(const float *w1, const float *w2);       // [F x h], [h x C] row-major
+    DeviceTimers &device_timers() { return *timers; }
+    long n_edges_local() const { return nnzA_local; }
+
+private:
+    GCNData *data;
+    HipEnv env;
+    std::unique_ptr<Comm> owned_comm;
+    std::unique_ptr<DeviceTimers> timers;
+    RowPartition part;
+    int n_local = 0;
+    long nnzA_local = 0;
+    int flags = 0;
+    HostRng rng;
+
+    gcnhip_graph *graph = nullptr;
+    gcnhip_feat *feat = nullptr;
+    std::vector<std::unique_ptr<HipVariable>> variables;       // index = reference variable number
+    HipVariable *input = nullptr, *output = nullptr;
+    const float *input_vals = nullptr;                         // what SparseMatmul reads
+    std::vector<Module *> modules;
+    std::unique_ptr<HipAdam> optimizer;
+
+    float *gradbuf = nullptr;                                  // [W1.grad | W2.grad | result(4)] one all-reduce
+    size_t gradbuf_elems = 0;
+    float *d_result = nullptr;
+    int32_t *d_result_i = nullptr;
+    int32_t *d_truth[4] = {};                                  // per split code 1..3
+    int32_t *cur_truth = nullptr;
+    int split_count[4] = {};
+    int cur_count = 0;
+    float *d_ring = nullptr;
+    static constexpr int RING = 1024;
+    uint8_t *d_keep0 = nullptr, *d_keep1 = nullptr;
+    std::vector<uint8_t> h_keep0, h_keep1;
+    long epochs_done = 0;                                      // host mirror of *d_epoch + 1
+
+    void build_modules();
+    void set_truth(int current_split);
+    void host_masks_for_epoch();
+    void train_epoch_async();
+    void eval_async(int current_split);
+    std::pair<float, float> read_metrics(long epoch_index, int slot);
+};

@@ -1,0 +1,142 @@
+#include "module.h"
+#include "hip_check.h"
+
+// ------------------------------------------------------------------- Matmul
+HipMatmul::HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float s)
+    : env(env), a(a), b(b), c(c), m(m), n(n), p(p), fused_bwd_scale(s) {}
+
+void HipMatmul::forward(bool) {
+    env->timers->start(TMR_MATMUL_FW);
+    GCNHIP_CHECK(gcnhip_matmul_fwd(env->ctx, a->data, a->ld, b->data, b->ld, c->data, c->ld, m, n, p));
+    env->timers->stop(TMR_MATMUL_FW);
+}
+
+void HipMatmul::backward() {
+    env->timers->start(TMR_MATMUL_BW);
+    if (fused_bwd_scale > 0.f)
+        GCNHIP_CHECK(gcnhip_matmul_bwd_fused(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
+                                             a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale));
+    else
+        GCNHIP_CHECK(gcnhip_matmul_bwd(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
+                                       a->grad, a->ld, b->grad, b->ld, m, n, p));
+    env->timers->stop(TMR_MATMUL_BW);
+}
+
+// ------------------------------------------------------------- SparseMatmul
+HipSparseMatmul::HipSparseMatmul(HipEnv *env, const float *const *vals, HipVariable *b, HipVariable *c, gcnhip_feat *sp,
+                                 int m, int n, int p, float fd, uint64_t off)
+    : env(env), vals(vals), b(b), c(c), sp(sp), m(m), n(n), p(p), fused_dropout(fd), nnz_offset(off) {}
+
+void HipSparseMatmul::forward(bool training) {
+    last_training = training;
+    env->timers->start(TMR_SPMATMUL_FW);
+    const float pd = training ? fused_dropout : 0.f;
+    GCNHIP_CHECK(gcnhip_spmm_fwd(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p, pd,
+                                 env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
+                                 pd > 0.f ? env->keep_input : nullptr));
+    env->timers->stop(TMR_SPMATMUL_FW);
+}
+
+void HipSparseMatmul::backward() {
+    env->timers->start(TMR_SPMATMUL_BW);
+    const float pd = last_training ? fused_dropout : 0.f;     // the same X~ the forward saw (module.cpp:72)
+    GCNHIP_CHECK(gcnhip_spmm_bwd(env->ctx, sp, *vals, c->grad, c->ld, b->grad, b->ld, p, pd,
+                                 env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
+                                 pd > 0.f ? env->keep_input : nullptr));
+    env->timers->stop(TMR_SPMATMUL_BW);
+}
+
+// ----------------------------------------------------------------- GraphSum
+HipGraphSum::HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim, float frd, uint64_t off)
+    : env(env), in(in), out(out), graph(graph), dim(dim), fused_relu_dropout(frd), elem_offset(off) {}
+
+void HipGraphSum::forward(bool training) {
+    // rows of `in` named by this rank's columns live on other ranks: gather them first
+    if (env->comm->size() > 1) {
+        env->timers->start(TMR_COMM);
+        env->comm->allgather_rows(in->full, in->full_elems / env->comm->size());
+        env->timers->stop(TMR_COMM);
+    }
+    const float *src = in->full ? in->full : in->data;
+    env->timers->start(TMR_GRAPHSUM_FW);
+    if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+    if (fused_relu_dropout >= 0.f)
+        GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
+                                                  fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
+                                                  training ? env->keep_hidden : nullptr));
+    else
+        GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
+    if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+    env->timers->stop(TMR_GRAPHSUM_FW);
+}
+
+void HipGraphSum::backward() {
+    // same operator on the gradients (symmetric adjacency, module.cpp:103-119); out->grad is gathered
+    if (env->comm->size() > 1) {
+        env->timers->start(TMR_COMM);
+        env->comm->allgather_rows(out->full_grad, out->full_elems / env->comm->size());
+        env->timers->stop(TMR_COMM);
+    }
+    const float *src = out->full_grad ? out->full_grad : out->grad;
+    env->timers->start(TMR_GRAPHSUM_BW);
+    if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+    GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, out->ld, in->grad, in->ld, dim));
+    if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+    env->timers->stop(TMR_GRAPHSUM_BW);
+}
+
+// --------------------------------------------------------- CrossEntropyLoss
+HipCrossEntropyLoss::HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32_t *const *truth, const int *count,
+                                         float *d_result, int32_t *d_result_i, int num_classes, bool shift)
+    : env(env), logits(logits), truth(truth), count(count), d_result(d_result), d_result_i(d_result_i),
+      num_classes(num_classes), shift_in_place(shift) {}
+
+void HipCrossEntropyLoss::forward(bool training) {
+    env->timers->start(TMR_LOSS_FW);
+    GCNHIP_CHECK(gcnhip_xent_fwd(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, logits->rows,
+                                 num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i));
+    env->timers->stop(TMR_LOSS_FW);
+}
+
+// --------------------------------------------------------------------- ReLU
+HipReLU::HipReLU(HipEnv *env, HipVariable *in) : env(env), in(in), mask(nullptr) {
+    void *p;
+    GCNHIP_CHECK(gcnhip_malloc(env->ctx, &p, in->elems()));
+    mask = (uint8_t *)p;
+}
+HipReLU::~HipReLU() { gcnhip_free(env->ctx, mask); }
+void HipReLU::forward(bool training) {
+    env->timers->start(TMR_RELU_FW);
+    GCNHIP_CHECK(gcnhip_relu_fwd(env->ctx, in->data, mask, (int64_t)in->elems(), training ? 1 : 0));
+    env->timers->stop(TMR_RELU_FW);
+}
+void HipReLU::backward() {
+    env->timers->start(TMR_RELU_BW);
+    GCNHIP_CHECK(gcnhip_relu_bwd(env->ctx, in->grad, mask, (int64_t)in->elems()));
+    env->timers->stop(TMR_RELU_BW);
+}
+
+// ------------------------------------------------------------------ Dropout
+HipDropout::HipDropout(HipEnv *env, HipVariable *in, float p, uint64_t key_tweak, uint64_t elem_offset, const uint8_t *const *keep_in)
+    : env(env), in(in), mask(nullptr), p(p), key_tweak(key_tweak), elem_offset(elem_offset), keep_in(keep_in) {
+    if (in->grad) {                                 // module.cpp:199: a mask only when the input has a gradient
+        void *q;
+        GCNHIP_CHECK(gcnhip_malloc(env->ctx, &q, in->elems() * sizeof(int32_t)));
+        mask = (int32_t *)q;
+    }
+}
+HipDropout::~HipDropout() { if (mask) gcnhip_free(env->ctx, mask); }
+void HipDropout::forward(bool training) {
+    if (!training) return;                          // module.cpp:208
+    env->timers->start(TMR_DROPOUT_FW);
+    // modular mode works on ld == cols layouts only (asserted by the model builder)
+    GCNHIP_CHECK(gcnhip_dropout_fwd(env->ctx, in->data, mask, (int64_t)in->rows * in->cols, p, env->seed ^ key_tweak,
+                                    env->d_epoch, elem_offset, *keep_in));
+    env->timers->stop(TMR_DROPOUT_FW);
+}
+void HipDropout::backward() {
+    if (!mask) return;                              // module.cpp:224
+    env->timers->start(TMR_DROPOUT_BW);
+    GCNHIP_CHECK(gcnhip_dropout_bwd(env->ctx, in->grad, mask, (int64_t)in->rows * in->cols, p));
+    env->timers->stop(TMR_DROPOUT_BW);
+}

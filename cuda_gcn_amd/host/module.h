@@ -1,0 +1,124 @@
+// module.h — the op boundary of the reference, kept: an abstract Module with
+// forward(bool training) / backward() whose operands are wired at construction
+// as raw non-owning pointers (src/seq/module.h:6-76; CUDA twin
+// src/cuda/cuda_module.cuh:11-84).  The Hip* modules below hold no kernels:
+// each forward/backward is one or two calls into the C-ABI of libgcnhip.so.
+//
+// Two ways to build the model from them (gcn.cpp):
+//  * modular: the reference's eight modules one for one (Dropout, SparseMatmul,
+//    GraphSum, ReLU, Dropout, Matmul, GraphSum, CrossEntropyLoss);
+//  * fused (default): the input Dropout folds into SparseMatmul, ReLU+Dropout
+//    into GraphSum's store epilogue and into Matmul's backward epilogue.
+#pragma once
+#include <cstdint>
+#include "comm.h"
+#include "gcnhip.h"
+#include "timer.h"
+#include "variable.h"
+
+// what every module needs from the model: context, collectives, RNG keys, the
+// device epoch word (dropout stream + Adam step index) and the device timers
+struct HipEnv {
+    gcnhip_ctx *ctx = nullptr;
+    Comm *comm = nullptr;
+    DeviceTimers *timers = nullptr;
+    uint64_t seed = 0;
+    uint32_t *d_epoch = nullptr;
+    // parity mode: decisions generated on the host with the reference's RNG
+    const uint8_t *keep_input = nullptr;     // [local nnz of X]
+    const uint8_t *keep_hidden = nullptr;    // [local rows * hidden]
+};
+
+class Module {
+public:
+    virtual void forward(bool) = 0;
+    virtual void backward() = 0;
+    virtual ~Module() {}
+};
+
+class HipMatmul : public Module {
+    HipEnv *env;
+    HipVariable *a, *b, *c;
+    int m, n, p;
+    float fused_bwd_scale;          // > 0: da = (a > 0) ? scale * da : 0 (ReLU+Dropout backward folded in)
+public:
+    HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
+    void forward(bool) override;
+    void backward() override;
+};
+
+class HipSparseMatmul : public Module {
+    HipEnv *env;
+    const float *const *vals;       // address of the pointer to the value array in use
+    HipVariable *b, *c;
+    gcnhip_feat *sp;
+    int m, n, p;
+    float fused_dropout;            // > 0: input dropout applied on the fly (training only)
+    uint64_t nnz_offset;            // global index of this rank's first stored value
+    bool last_training = false;
+public:
+    HipSparseMatmul(HipEnv *env, const float *const *vals, HipVariable *b, HipVariable *c, gcnhip_feat *sp,
+                    int m, int n, int p, float fused_dropout, uint64_t nnz_offset);
+    void forward(bool) override;
+    void backward() override;
+};
+
+class HipGraphSum : public Module {
+    HipEnv *env;
+    HipVariable *in, *out;
+    gcnhip_graph *graph;
+    int dim;
+    float fused_relu_dropout;       // >= 0: ReLU (+ dropout with this p when training) in the store epilogue
+    uint64_t elem_offset;           // global element index of this rank's first output element
+    timer_instance fw_extra;
+public:
+    HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
+                float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
+    void forward(bool) override;
+    void backward() override;
+};
+
+class HipCrossEntropyLoss : public Module {
+    HipEnv *env;
+    HipVariable *logits;
+    int32_t *const *truth;          // address of the current truth pointer (set_truth switches splits)
+    const int *count;               // labelled rows of the current split, all ranks
+    float *d_result;                // {loss_sum, count, correct, total}
+    int32_t *d_result_i;
+    int num_classes;
+    bool shift_in_place;
+public:
+    HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32_t *const *truth, const int *count,
+                        float *d_result, int32_t *d_result_i, int num_classes, bool shift_in_place);
+    void forward(bool) override;
+    void backward() override {}
+};
+
+class HipReLU : public Module {
+    HipEnv *env;
+    HipVariable *in;
+    uint8_t *mask;
+public:
+    HipReLU(HipEnv *env, HipVariable *in);
+    ~HipReLU() override;
+    void forward(bool) override;
+    void backward() override;
+};
+
+class HipDropout : public Module {
+    HipEnv *env;
+    HipVariable *in;
+    int32_t *mask;
+    float p;
+    uint64_t key_tweak, elem_offset;
+    const uint8_t *const *keep_in;
+public:
+    HipDropout(HipEnv *env, HipVariable *in, float p, uint64_t key_tweak, uint64_t elem_offset, const uint8_t *const *keep_in);
+    ~HipDropout() override;
+    void forward(bool) override;
+    void backward() override;
+};
+
+// distinct Philox keys for the two dropout sites
+constexpr uint64_t KEY_INPUT_DROPOUT = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t KEY_HIDDEN_DROPOUT = 0xD1B54A32D192ED03ull;

@@ -1,0 +1,67 @@
+#include "variable.h"
+#include <cmath>
+#include <cstring>
+#include "hip_check.h"
+
+void Variable::glorot(int in_size, int out_size, HostRng &rng) {
+    // variable.cpp:11-18: float division by (float)MY_RAND_MAX, "- 0.5" in double
+    float range = sqrtf(6.0f / (in_size + out_size));
+    for (size_t i = 0; i < data.size(); i++) {
+        const float r = (float)((double)((float)rng.next() / (float)MY_RAND_MAX) - 0.5);
+        data[i] = r * range * 2;
+    }
+}
+
+HipVariable::~HipVariable() {
+    if (!ctx) return;
+    if (full) gcnhip_free(ctx, full);
+    else if (data) gcnhip_free(ctx, data);
+    if (full_grad) gcnhip_free(ctx, full_grad);
+    else if (grad) gcnhip_free(ctx, grad);
+}
+
+void HipVariable::alloc(gcnhip_ctx *c, int r, int cl, bool rg, bool gather_data, bool gather_grad,
+                        int world, int rank, int gather_rows_max) {
+    ctx = c; rows = r; cols = cl; requires_grad = rg;
+    ld = (cl + 3) / 4 * 4;
+    const size_t local = (size_t)(rows > 0 ? rows : 1) * ld;
+    const size_t block = (size_t)gather_rows_max * ld;
+    full_elems = block * world;
+    void *p = nullptr;
+    if (gather_data && world > 1) {
+        GCNHIP_CHECK(gcnhip_malloc(ctx, &p, full_elems * sizeof(float)));
+        GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, full_elems * sizeof(float)));
+        full = (float *)p;
+        data = full + block * rank;
+    } else {
+        GCNHIP_CHECK(gcnhip_malloc(ctx, &p, local * sizeof(float)));
+        GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, local * sizeof(float)));
+        data = (float *)p;
+    }
+    if (rg) {
+        if (gather_grad && world > 1) {
+            GCNHIP_CHECK(gcnhip_malloc(ctx, &p, full_elems * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, full_elems * sizeof(float)));
+            full_grad = (float *)p;
+            grad = full_grad + block * rank;
+        } else {
+            GCNHIP_CHECK(gcnhip_malloc(ctx, &p, local * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, local * sizeof(float)));
+            grad = (float *)p;
+        }
+    }
+}
+
+void HipVariable::zero() { GCNHIP_CHECK(gcnhip_memset_async(ctx, data, 0, elems() * sizeof(float))); }
+void HipVariable::zero_grad() { if (grad) GCNHIP_CHECK(gcnhip_memset_async(ctx, grad, 0, elems() * sizeof(float))); }
+
+void HipVariable::upload(const float *h) {
+    std::vector<float> tmp((size_t)rows * ld, 0.f);
+    for (int r = 0; r < rows; r++) memcpy(&tmp[(size_t)r * ld], h + (size_t)r * cols, cols * sizeof(float));
+    GCNHIP_CHECK(gcnhip_h2d(ctx, data, tmp.data(), tmp.size() * sizeof(float)));
+}
+void HipVariable::download(float *h, bool want_grad) const {
+    std::vector<float> tmp((size_t)rows * ld);
+    GCNHIP_CHECK(gcnhip_d2h(ctx, tmp.data(), want_grad ? grad : data, tmp.size() * sizeof(float)));
+    for (int r = 0; r < rows; r++) memcpy(h + (size_t)r * cols, &tmp[(size_t)r * ld], cols * sizeof(float));
+}

@@ -1,0 +1,40 @@
+// variable.h — Variable (host, src/seq/variable.h:4-12) and HipVariable, the
+// device-resident twin (reference: CUDAVariable, src/cuda/cuda_variable.cuh:7-20).
+#pragma once
+#include <cstddef>
+#include <vector>
+#include "gcnhip.h"
+#include "rand.h"
+
+struct Variable {
+    std::vector<float> data, grad;
+    Variable(int size, bool requires_grad = true) : data(size), grad(requires_grad ? size : 0) {}
+    void glorot(int in_size, int out_size, HostRng &rng);     // variable.cpp:11-18
+};
+
+// A row-major [rows x cols] f32 matrix on the GPU with leading dimension ld
+// (multiple of 4 floats: every row 16-byte aligned for the vector kernels).
+// For variables that GraphSum gathers from other ranks, `full` is the base of
+// the [world * rows_max x ld] gather buffer and data/grad point at this
+// rank's block inside it (so the all-gather is in place).
+struct HipVariable {
+    gcnhip_ctx *ctx = nullptr;
+    float *data = nullptr, *grad = nullptr;          // this rank's rows
+    float *full = nullptr, *full_grad = nullptr;     // gather buffers (== data/grad when world == 1)
+    int rows = 0, cols = 0, ld = 0;
+    bool requires_grad = false;
+    size_t full_elems = 0;
+
+    HipVariable() {}
+    HipVariable(const HipVariable &) = delete;
+    HipVariable &operator=(const HipVariable &) = delete;
+    ~HipVariable();
+    // gather_rows_max > 0: allocate world * gather_rows_max rows and place this rank's block at rank * gather_rows_max
+    void alloc(gcnhip_ctx *ctx, int rows, int cols, bool requires_grad, bool gather_data = false,
+               bool gather_grad = false, int world = 1, int rank = 0, int gather_rows_max = 0);
+    size_t elems() const { return (size_t)rows * ld; }
+    void zero();
+    void zero_grad();
+    void upload(const float *host_rowmajor);                 // [rows x cols] contiguous
+    void download(float *host_rowmajor, bool want_grad = false) const;
+};

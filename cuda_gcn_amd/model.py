@@ -1,0 +1,189 @@
+"""Python handle on the C++ host driver (libgcnhost.so: HipGCN and its Hip*
+modules).  Mirrors the reference's GCN class: construct from params + data,
+then train_epoch() / eval(split) / run() (src/seq/gcn.h:24-44).
+
+All compute is in the HIP kernels behind include/gcnhip.h; this file only
+marshals numpy arrays.  No GPU or no built library -> an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+MODULAR, HOST_MASKS, TIMERS = 1, 2, 4
+TIMER_NAMES = ["train", "test", "matmul_fw", "matmul_bw", "spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw",
+               "loss_fw", "relu_fw", "relu_bw", "dropout_fw", "dropout_bw", "adam", "comm", "graphsum_wide"]
+
+
+class GcnHostError(RuntimeError):
+    pass
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _ck(lib, rc, what):
+    if rc != 0:
+        raise GcnHostError(f"{what}: error {rc}: {lib.gcnhost_last_error().decode()}")
+
+
+def default_params(**kw):
+    lib = _lib.gcnhost()
+    p = lib.gcnhost_params_default()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def nccl_unique_id() -> bytes:
+    lib = _lib.gcnhost()
+    buf = C.create_string_buffer(128)
+    _ck(lib, lib.gcnhost_nccl_unique_id(buf), "gcnhost_nccl_unique_id")
+    return buf.raw
+
+
+class HipGCNModel:
+    """ds: dict with num_nodes, input_dim, output_dim, g_indptr, g_indices, f_indptr, f_indices (or None
+    for a dense X), f_val, split, label (the reference's GCNData)"""
+
+    def __init__(self, ds, seed=0, device=0, flags=0, rank=0, world=1, nccl_id: bytes | None = None,
+                 host_allgather=None, host_allreduce=None, **hyper):
+        self.lib = lib = _lib.gcnhost()
+        p = default_params(num_nodes=ds["num_nodes"], input_dim=ds["input_dim"], output_dim=ds["output_dim"], **hyper)
+        self.params = p
+        self._keep = [_i32(ds["g_indptr"]), _i32(ds["g_indices"]), _i32(ds["f_indptr"]),
+                      _i32(ds["f_indices"]) if ds.get("f_indices") is not None else None,
+                      np.ascontiguousarray(ds["f_val"], np.float32), _i32(ds["split"]), _i32(ds["label"])]
+        k = self._keep
+        self._ag = _lib.ALLGATHER_FN(host_allgather) if host_allgather else C.cast(None, _lib.ALLGATHER_FN)
+        self._ar = _lib.ALLREDUCE_FN(host_allreduce) if host_allreduce else C.cast(None, _lib.ALLREDUCE_FN)
+        h = C.c_void_p()
+        rc = lib.gcnhost_model_create(C.byref(h), C.byref(p), k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data,
+                                      k[3].ctypes.data if k[3] is not None else None, k[4].ctypes.data,
+                                      k[5].ctypes.data, k[6].ctypes.data, int(seed), int(device), int(flags),
+                                      int(rank), int(world), nccl_id, self._ag, self._ar, None)
+        _ck(lib, rc, "gcnhost_model_create")
+        self.h = h
+        self._keep = None if world == 1 and False else self._keep   # the C++ side copied everything
+
+    def train_epoch(self):
+        a, b = C.c_float(), C.c_float()
+        _ck(self.lib, self.lib.gcnhost_model_train_epoch(self.h, C.byref(a), C.byref(b)), "train_epoch")
+        return a.value, b.value
+
+    def eval(self, split):
+        a, b = C.c_float(), C.c_float()
+        _ck(self.lib, self.lib.gcnhost_model_eval(self.h, split, C.byref(a), C.byref(b)), "eval")
+        return a.value, b.value
+
+    def run_epochs(self, n, want_trace=True):
+        tr = np.zeros((n, 4), np.float32) if want_trace else None
+        _ck(self.lib, self.lib.gcnhost_model_run_epochs(self.h, n, tr.ctypes.data if tr is not None else None), "run_epochs")
+        return tr
+
+    def run(self):
+        _ck(self.lib, self.lib.gcnhost_model_run(self.h), "run")
+
+    def sync(self):
+        _ck(self.lib, self.lib.gcnhost_model_sync(self.h), "sync")
+
+    def info(self):
+        r, w, s, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        e = C.c_int64()
+        _ck(self.lib, self.lib.gcnhost_model_info(self.h, C.byref(r), C.byref(w), C.byref(s), C.byref(n), C.byref(e)), "info")
+        return dict(rank=r.value, world=w.value, row_start=s.value, local_rows=n.value, local_edges=e.value)
+
+    def var(self, k, grad=False):
+        r, c = C.c_int(), C.c_int()
+        _ck(self.lib, self.lib.gcnhost_model_get_var(self.h, k, int(grad), None, C.byref(r), C.byref(c)), "get_var")
+        out = np.zeros((r.value, c.value), np.float32)
+        _ck(self.lib, self.lib.gcnhost_model_get_var(self.h, k, int(grad), out.ctypes.data, C.byref(r), C.byref(c)), "get_var")
+        return out
+
+    def set_weights(self, w1, w2):
+        w1, w2 = np.ascontiguousarray(w1, np.float32), np.ascontiguousarray(w2, np.float32)
+        _ck(self.lib, self.lib.gcnhost_model_set_weights(self.h, w1.ctypes.data, w2.ctypes.data), "set_weights")
+
+    def timer(self, name_or_id):
+        i = TIMER_NAMES.index(name_or_id) if isinstance(name_or_id, str) else int(name_or_id)
+        s, n = C.c_double(), C.c_long()
+        _ck(self.lib, self.lib.gcnhost_model_timer(self.h, i, C.byref(s), C.byref(n)), "timer")
+        return s.value, n.value
+
+    def timers_reset(self):
+        _ck(self.lib, self.lib.gcnhost_model_timers_reset(self.h), "timers_reset")
+
+    def close(self):
+        if self.h:
+            self.lib.gcnhost_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_dataset(root, name):
+    """the reference's text formats (or a .gcnbin cache) through the C++ Parser"""
+    lib = _lib.gcnhost()
+    p = lib.gcnhost_params_default()
+    h = C.c_void_p()
+    if root and not root.endswith("/"):
+        root += "/"
+    _ck(lib, lib.gcnhost_dataset_load(C.byref(h), root.encode() if root else None, name.encode(), C.byref(p)), "dataset_load")
+    ptrs = [C.c_void_p() for _ in range(7)]
+    ns = [C.c_int64() for _ in range(4)]
+    lib.gcnhost_dataset_arrays(h, C.byref(ptrs[0]), C.byref(ptrs[1]), C.byref(ns[0]), C.byref(ptrs[2]), C.byref(ptrs[3]),
+                               C.byref(ptrs[4]), C.byref(ns[1]), C.byref(ptrs[5]), C.byref(ns[2]), C.byref(ptrs[6]), C.byref(ns[3]))
+
+    def arr(ptr, n, t):
+        if n == 0:
+            return np.zeros(0, t)
+        ct = C.c_float if t == np.float32 else C.c_int
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), (n,)).astype(t).copy()
+    N = p.num_nodes
+    ds = dict(name=name, num_nodes=N, input_dim=p.input_dim, output_dim=p.output_dim,
+              g_indptr=arr(ptrs[0], N + 1, np.int32), g_indices=arr(ptrs[1], ns[0].value, np.int32),
+              f_indptr=arr(ptrs[2], ns[3].value + 1, np.int32), f_indices=arr(ptrs[3], ns[1].value, np.int32),
+              f_val=arr(ptrs[4], ns[1].value, np.float32), split=arr(ptrs[5], ns[2].value, np.int32),
+              label=arr(ptrs[6], ns[3].value, np.int32))
+    ds["_handle"] = (lib, h, p)
+    return ds
+
+
+def save_binary(ds, path):
+    lib, h, p = ds["_handle"]
+    if lib.gcnhost_dataset_save_binary(h, C.byref(p), path.encode()) != 0:
+        raise GcnHostError("save_binary failed")
+
+
+def partition(g_indptr, world):
+    lib = _lib.gcnhost()
+    gp = _i32(g_indptr)
+    start = np.zeros(world + 1, np.int32)
+    rm = C.c_int()
+    rc = lib.gcnhost_partition(gp.ctypes.data, gp.size - 1, world, start.ctypes.data, C.byref(rm))
+    if rc != 0:
+        raise GcnHostError("partition failed")
+    return start, rm.value
+
+
+def glorot(size, in_size, out_size, seed, skip_draws=0):
+    lib = _lib.gcnhost()
+    w = np.zeros(size, np.float32)
+    lib.gcnhost_glorot(w.ctypes.data, size, in_size, out_size, int(seed), int(skip_draws))
+    return w
+
+
+def host_masks(n, p, seed, skip_draws=0):
+    lib = _lib.gcnhost()
+    k = np.zeros(n, np.uint8)
+    lib.gcnhost_host_masks(k.ctypes.data, n, p, int(seed), int(skip_draws))
+    return k

@@ -212,7 +212,9 @@ int gcnhip_adam_step(gcnhip_ctx *ctx, const gcnhip_adam_var *vars, int n_vars, f
 
 /* ---- small device utilities for graph-replayed epochs -------------------------- */
 int gcnhip_counter_add(gcnhip_ctx *ctx, uint32_t *d_counter, uint32_t inc);
-/* metrics ring: record row `*d_epoch % capacity` = {loss_sum, count, correct, total, sumsq, 0,0,0} */
+/* metrics ring [capacity][4 slots][8 floats]: slot `slot_in_row` (0..3) of row `*d_epoch % capacity`
+ * = {loss_sum, count, correct, total, sumsq, epoch, 0, 0}.  correct/total come from d_result_i when it is
+ * non-NULL, else from d_result[2..3] (the all-reduced floats of a multi-GPU run). */
 int gcnhip_metrics_record(gcnhip_ctx *ctx, float *d_ring, int capacity, int slot_in_row,
                           const uint32_t *d_epoch, const float *d_result, const int32_t *d_result_i,
                           const float *d_sumsq);

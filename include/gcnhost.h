@@ -1,0 +1,97 @@
+/*
+ * gcnhost.h — C entry points of libgcnhost.so: the C++ host side of the GCN
+ * training path (HipGCN and its Hip* modules, cuda_gcn_amd/host/) for callers
+ * that are not C++ (bench.py, tests, __graft_entry__.smoke()).
+ *
+ * The host mirrors the reference's driver: GCN(GCNParams, GCNData*) + run()
+ * (src/seq/gcn.h:24-44; CUDA twin src/cuda/cuda_gcn.cuh:11-34).  It reaches
+ * the GPU only through include/gcnhip.h (and RCCL for more than one GPU).
+ * Every function returns 0 on success, else the failing HIP/RCCL code (or -1);
+ * gcnhost_last_error() gives the message.
+ */
+#ifndef GCNHOST_H
+#define GCNHOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gcnhost_model gcnhost_model;
+
+/* GCNParams of the reference (src/seq/gcn.h:9-14), same field order */
+typedef struct {
+    int num_nodes, input_dim, hidden_dim, output_dim;
+    float dropout, learning_rate, weight_decay;
+    int epochs, early_stopping;
+} gcnhost_params;
+
+enum {
+    GCNHOST_MODULAR = 1,      /* one module per reference module (no fused epilogues) */
+    GCNHOST_HOST_MASKS = 2,   /* dropout decisions replayed from the reference's host RNG (parity runs) */
+    GCNHOST_TIMERS = 4        /* per-op device-event timers */
+};
+
+#define GCNHOST_NCCL_ID_BYTES 128
+typedef void (*gcnhost_allgather_fn)(void *user, float *host_full, size_t block_elems);
+typedef void (*gcnhost_allreduce_fn)(void *user, double *host_buf, size_t n);
+
+const char *gcnhost_last_error(void);
+gcnhost_params gcnhost_params_default(void);               /* gcn.cpp:9-11 */
+int gcnhost_nccl_unique_id(char id[GCNHOST_NCCL_ID_BYTES]);   /* rank 0; broadcast it to the others */
+
+/* Build the model from the whole dataset in the reference's in-memory layout
+ * (GCNData, src/seq/gcn.h:16-22: adjacency CSR with the self loop first,
+ * feature CSR + values, split, label); each rank keeps its own row block.
+ * f_indices may be NULL for a dense X (every row = columns 0..input_dim-1).
+ * seed plays time(NULL) of src/seq/rand.cpp:7.  world > 1: nccl_id (from
+ * gcnhost_nccl_unique_id) selects RCCL; or pass host callbacks for a
+ * host-staged transport (tests). */
+int gcnhost_model_create(gcnhost_model **m, const gcnhost_params *p,
+                         const int *g_indptr, const int *g_indices,
+                         const int *f_indptr, const int *f_indices, const float *f_val,
+                         const int *split, const int *label,
+                         long seed, int device, int flags,
+                         int rank, int world, const char *nccl_id,
+                         gcnhost_allgather_fn host_ag, gcnhost_allreduce_fn host_ar, void *host_user);
+int gcnhost_model_destroy(gcnhost_model *m);
+
+int gcnhost_model_train_epoch(gcnhost_model *m, float *loss, float *acc);      /* gcn.cpp:107-118; synchronises */
+int gcnhost_model_eval(gcnhost_model *m, int split, float *loss, float *acc);  /* gcn.cpp:120-128; synchronises */
+/* n x (train_epoch + eval(2)) enqueued back to back, one synchronisation at the
+ * end; trace (may be NULL) gets train_loss, train_acc, val_loss, val_acc per epoch */
+int gcnhost_model_run_epochs(gcnhost_model *m, int n, float *trace);
+int gcnhost_model_run(gcnhost_model *m);                                       /* gcn.cpp:130-158, prints the reference's lines */
+int gcnhost_model_sync(gcnhost_model *m);
+
+/* introspection */
+int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges);
+/* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
+ * out == NULL: only report the shape. */
+int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *rows, int *cols);
+int gcnhost_model_set_weights(gcnhost_model *m, const float *w1, const float *w2);
+/* device-event timer `id` (host/timer.h, ids of src/common/timer.h:5-20 plus 13 Adam, 14 comm,
+ * 15 GraphSum at the hidden width): accumulated seconds and number of intervals */
+int gcnhost_model_timer(gcnhost_model *m, int id, double *seconds, long *count);
+int gcnhost_model_timers_reset(gcnhost_model *m);
+
+/* the text loader (src/common/parser.cpp) — fills caller-visible arrays owned by the returned handle */
+typedef struct gcnhost_dataset gcnhost_dataset;
+int gcnhost_dataset_load(gcnhost_dataset **d, const char *root, const char *name, gcnhost_params *p);
+int gcnhost_dataset_arrays(gcnhost_dataset *d, const int **g_indptr, const int **g_indices, int64_t *g_nnz,
+                           const int **f_indptr, const int **f_indices, const float **f_val, int64_t *f_nnz,
+                           const int **split, int64_t *n_split, const int **label, int64_t *n_label);
+int gcnhost_dataset_save_binary(gcnhost_dataset *d, const gcnhost_params *p, const char *path);
+int gcnhost_dataset_free(gcnhost_dataset *d);
+
+/* host-only helpers, callable without a GPU (CPU tests) */
+int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start /* [world+1] */, int *rows_max);
+int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws);
+int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t skip_draws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

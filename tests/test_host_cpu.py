@@ -1,0 +1,98 @@
+"""CPU-only tests of the C++ host logic in libgcnhost.so (no GPU calls):
+the text loader and binary cache, the Glorot/RNG replay, the row partition."""
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+from cuda_gcn_amd import datagen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+KEYS = ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label")
+
+
+def test_gcnhost_exports_every_declared_symbol():
+    from cuda_gcn_amd import _lib
+    lib = _lib.gcnhost()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gcnhost.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(gcnhost_\w+)\s*\(", txt)) - {"gcnhost_allgather_fn", "gcnhost_allreduce_fn"})
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.GCNHOST_SYMBOLS) == names
+
+
+@pytest.mark.parametrize("case", ["noeol", "ragged", "plain"])
+def test_parser_matches_reference_fixtures(case):
+    """the C++ loader against the arrays the reference's Parser produced (tests/golden/parser.npz)"""
+    from cuda_gcn_amd import model
+    g = np.load(os.path.join(GOLD, "parser.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        for ext, key in ((".graph", "graph_txt"), (".svmlight", "svm_txt"), (".split", "split_txt")):
+            with open(os.path.join(td, case + ext), "w") as f:
+                f.write(str(g[f"parse_{case}_{key}"]))
+        ds = model.load_dataset(td, case)
+    for k in KEYS:
+        want = g[f"parse_{case}_{k}"]
+        assert np.array_equal(ds[k].view(np.uint32) if k == "f_val" else ds[k], want.view(np.uint32) if k == "f_val" else want), k
+    assert [ds["num_nodes"], ds["input_dim"], ds["output_dim"]] == g[f"parse_{case}_dims"].tolist()
+
+
+def test_parser_missing_file_fails():
+    from cuda_gcn_amd import model
+    with tempfile.TemporaryDirectory() as td:
+        with pytest.raises(model.GcnHostError, match="Cannot read input"):
+            model.load_dataset(td, "nothing")
+
+
+def test_parser_vs_oracle_and_binary_cache(oracle):
+    from cuda_gcn_amd import model
+    ds = datagen.make_dataset("tiny-syn", seed=11)
+    with tempfile.TemporaryDirectory() as td:
+        datagen.write_text(ds, td, "t")
+        a = model.load_dataset(td, "t")
+        b = oracle.parse(td, "t")
+        for k in KEYS:
+            assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], ds[k]), k
+        model.save_binary(a, os.path.join(td, "t.gcnbin"))
+        for ext in (".graph", ".split", ".svmlight"):
+            os.remove(os.path.join(td, "t" + ext))
+        c = model.load_dataset(td, "t")             # only the cache is left
+        for k in KEYS:
+            assert np.array_equal(a[k], c[k]), k
+        assert (c["num_nodes"], c["input_dim"], c["output_dim"]) == (ds["num_nodes"], ds["input_dim"], ds["output_dim"])
+
+
+def test_glorot_and_masks_replay_reference_rng(oracle):
+    """the host RNG in the product must reproduce the reference's stream: same seed ->
+    same initial weights as gcn-seq, same dropout decisions in HOST_MASKS mode"""
+    from cuda_gcn_amd import model
+    mods = np.load(os.path.join(GOLD, "modules.npz"))
+    assert np.array_equal(model.glorot(600, 30, 20, seed=7), mods["glorot_seed7_30x20"])
+    for seed in (1, 42, 20191210):
+        oracle.rand_seed_time(seed)
+        w1 = oracle.glorot(23 * 16, 23, 16)
+        w2 = oracle.glorot(16 * 5, 16, 5)
+        assert np.array_equal(model.glorot(23 * 16, 23, 16, seed), w1)
+        assert np.array_equal(model.glorot(16 * 5, 16, 5, seed, skip_draws=23 * 16), w2)
+        # dropout decisions that follow in the stream
+        x = np.ones(1000, np.float32)
+        _, mask = oracle.dropout_fwd(x, 0.5)
+        assert np.array_equal(model.host_masks(1000, 0.5, seed, skip_draws=23 * 16 + 16 * 5), mask.astype(np.uint8))
+
+
+@pytest.mark.parametrize("name,world", [("cora-syn", 1), ("cora-syn", 2), ("cora-syn", 8), ("tiny-syn", 3), ("tiny-syn", 4)])
+def test_partition_covers_and_balances(name, world):
+    from cuda_gcn_amd import model
+    ds = datagen.make_dataset(name)
+    gp = ds["g_indptr"]
+    start, rows_max = model.partition(gp, world)
+    n = gp.size - 1
+    assert start[0] == 0 and start[-1] == n and np.all(np.diff(start) >= 0)
+    assert rows_max == max(1, int(np.diff(start).max()))
+    # work = edges + mean-degree per row, within 25 % of the ideal share (+ one heavy row)
+    cost = np.diff(gp) + gp[-1] / n
+    share = [cost[start[q]:start[q + 1]].sum() for q in range(world)]
+    assert max(share) <= 1.25 * cost.sum() / world + cost.max()

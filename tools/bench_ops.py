@@ -1,0 +1,95 @@
+"""Per-kernel micro-benchmark on reddit-syn shapes (run on the GPU box).
+Times each op with HIP events on the context's stream, reports achieved
+algorithmic GB/s (SURVEY §8d's B_gs / B_sp / Matmul bytes) or TFLOP/s."""
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from cuda_gcn_amd import datagen
+from cuda_gcn_amd.ops import Device, _ck
+
+
+def timeit(dev, fn, iters=20, warmup=3):
+    lib = dev.lib
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.gcnhip_event_create(C.byref(e0)); lib.gcnhip_event_create(C.byref(e1))
+    for _ in range(warmup):
+        fn()
+    dev.sync()
+    lib.gcnhip_event_record(dev.ctx, e0)
+    for _ in range(iters):
+        fn()
+    lib.gcnhip_event_record(dev.ctx, e1)
+    ms = C.c_float()
+    lib.gcnhip_event_elapsed_ms(e0, e1, C.byref(ms))
+    return ms.value / iters
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "reddit-syn"
+    h = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    t0 = time.time()
+    ds = datagen.make_dataset(name)
+    print("dataset", name, "built in %.1fs" % (time.time() - t0), flush=True)
+    N, F, Cc = ds["num_nodes"], ds["input_dim"], ds["output_dim"]
+    nnzA = ds["g_indices"].size
+    dev = Device(0)
+    lib = dev.lib
+    g = dev.graph(ds["g_indptr"], ds["g_indices"])
+    f = dev.feat(ds["f_indptr"], ds["f_indices"], ds["f_val"], F)
+    print("dense X:", f.dense, "nnzA", nnzA, flush=True)
+    rng = np.random.default_rng(0)
+    res = {}
+
+    def gs(dim, ld):
+        x = dev.buf(rng.standard_normal((N, ld)).astype(np.float32))
+        o = dev.buf((N, ld))
+        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, ld, o.ptr, ld, dim), "gs"))
+        bgs = 4 * (N + 1) + 4 * nnzA + 4 * nnzA * dim + 4 * N * dim
+        res[f"graphsum_d{dim}_ld{ld}"] = dict(ms=ms, GBps=bgs / ms / 1e6)
+        print(f"graphsum d={dim} ld={ld}: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
+    gs(h, h)
+    gs(Cc, (Cc + 3) // 4 * 4)
+    gs(Cc, Cc)
+
+    w1 = dev.buf(rng.standard_normal((F, h)).astype(np.float32))
+    h0 = dev.buf((N, h))
+    ep = dev.buf(np.zeros(1, np.uint32))
+    for pd in (0.0, 0.5):
+        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_spmm_fwd(dev.ctx, f.h, f.values_ptr, w1.ptr, h, h0.ptr, h, h, pd, 1, ep.ptr, 0, None), "spf"), iters=10)
+        fl = 2.0 * ds["f_indices"].size * h
+        res[f"spmm_fwd_p{pd}"] = dict(ms=ms, TFLOPs=fl / ms / 1e9)
+        print(f"spmm fwd drop={pd}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+        dw = dev.buf((F, h))
+        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_spmm_bwd(dev.ctx, f.h, f.values_ptr, h0.ptr, h, dw.ptr, h, h, pd, 1, ep.ptr, 0, None), "spb"), iters=10)
+        res[f"spmm_bwd_p{pd}"] = dict(ms=ms, TFLOPs=fl / ms / 1e9)
+        print(f"spmm bwd drop={pd}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+    ldc = (Cc + 3) // 4 * 4
+    w2 = dev.buf(rng.standard_normal((h, ldc)).astype(np.float32))
+    z0 = dev.buf((N, ldc)); dz = dev.buf(rng.standard_normal((N, ldc)).astype(np.float32))
+    dh = dev.buf((N, h)); dw2 = dev.buf((h, ldc))
+    ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_matmul_fwd(dev.ctx, h0.ptr, h, w2.ptr, ldc, z0.ptr, ldc, N, h, Cc), "mm"))
+    by = 4.0 * (N * h + h * Cc + N * Cc)
+    res["matmul_fwd"] = dict(ms=ms, GBps=by / ms / 1e6)
+    print(f"matmul fwd: {ms:.3f} ms {by / ms / 1e6:.0f} GB/s", flush=True)
+    ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_matmul_bwd_fused(dev.ctx, h0.ptr, h, w2.ptr, ldc, dz.ptr, ldc, dh.ptr, h, dw2.ptr, ldc, N, h, Cc, 2.0), "mmb"))
+    by = 4.0 * (2 * N * h + N * Cc + N * h)
+    res["matmul_bwd_fused"] = dict(ms=ms, GBps=by / ms / 1e6)
+    print(f"matmul bwd fused: {ms:.3f} ms {by / ms / 1e6:.0f} GB/s", flush=True)
+
+    tr = dev.buf(np.where(ds["split"] == 1, ds["label"], -1).astype(np.int32))
+    r4 = dev.buf(np.zeros(4, np.float32)); r2 = dev.buf(np.zeros(2, np.int32))
+    cnt = int((ds["split"] == 1).sum())
+    ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_xent_fwd(dev.ctx, z0.ptr, ldc, dz.ptr, ldc, tr.ptr, N, Cc, 1, cnt, 0, r4.ptr, r2.ptr), "xe"))
+    res["xent"] = dict(ms=ms, GBps=8.0 * N * Cc / ms / 1e6)
+    print(f"xent train: {ms:.3f} ms", flush=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
