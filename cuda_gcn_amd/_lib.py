@@ -149,6 +149,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_dataset_arrays": (I, [P, PP, PP, C.POINTER(I64), PP, PP, PP, C.POINTER(I64), PP, C.POINTER(I64), PP, C.POINTER(I64)]),
     "gcnhost_dataset_save_binary": (I, [P, C.POINTER(HostParams), C.c_char_p]),
     "gcnhost_dataset_free": (I, [P]),
+    "gcnhost_rccl_selftest": (I, [I]),
     "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
     "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
     "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),

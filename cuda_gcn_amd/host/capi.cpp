@@ -1,7 +1,9 @@
 // capi.cpp — extern "C" surface of the host library (include/gcnhost.h).
 #include "gcnhost.h"
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 #include "gcn.h"
 #include "hip_check.h"
 #include "parser.h"
@@ -142,6 +144,35 @@ int gcnhost_dataset_save_binary(gcnhost_dataset *d, const gcnhost_params *p, con
     return Parser::save_binary(path, gp, d->data) ? 0 : -1;
 }
 int gcnhost_dataset_free(gcnhost_dataset *d) { delete d; return 0; }
+
+int gcnhost_rccl_selftest(int device) {
+    API_TRY({
+        gcnhip_ctx *ctx = nullptr;
+        GCNHIP_CHECK(gcnhip_ctx_create(&ctx, device, nullptr));
+        char id[GCN_NCCL_ID_BYTES];
+        int rc = rccl_get_unique_id(id);
+        if (rc) throw GcnHipFailure(rc, "ncclGetUniqueId failed");
+        {
+            std::unique_ptr<Comm> comm(make_rccl_comm(ctx, 0, 1, id));
+            std::vector<float> h(1024);
+            for (int i = 0; i < 1024; i++) h[i] = (float)i * 0.5f;
+            void *d;
+            GCNHIP_CHECK(gcnhip_malloc(ctx, &d, h.size() * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_h2d(ctx, d, h.data(), h.size() * sizeof(float)));
+            comm->allgather_rows((float *)d, h.size());
+            comm->allreduce_sum((float *)d, h.size());
+            std::vector<float> back(1024);
+            GCNHIP_CHECK(gcnhip_d2h(ctx, back.data(), d, back.size() * sizeof(float)));
+            gcnhip_free(ctx, d);
+            for (int i = 0; i < 1024; i++)
+                if (back[i] != h[i]) throw GcnHipFailure(-1, "RCCL self-test: data changed in a one-rank collective");
+            double v[2] = {3.0, 4.0};
+            comm->allreduce_sum_host(v, 2);
+            if (v[0] != 3.0 || v[1] != 4.0) throw GcnHipFailure(-1, "RCCL self-test: host reduction");
+        }
+        gcnhip_ctx_destroy(ctx);
+    })
+}
 
 int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start, int *rows_max) {
     if (!g_indptr || !start || world < 1) return -1;

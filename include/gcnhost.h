@@ -86,6 +86,10 @@ int gcnhost_dataset_arrays(gcnhost_dataset *d, const int **g_indptr, const int *
 int gcnhost_dataset_save_binary(gcnhost_dataset *d, const gcnhost_params *p, const char *path);
 int gcnhost_dataset_free(gcnhost_dataset *d);
 
+/* one-rank RCCL round trip on `device` (communicator init, in-place all-gather, all-reduce,
+ * destroy): checks that the RCCL this process loaded works before a multi-GPU job relies on it */
+int gcnhost_rccl_selftest(int device);
+
 /* host-only helpers, callable without a GPU (CPU tests) */
 int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start /* [world+1] */, int *rows_max);
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws);

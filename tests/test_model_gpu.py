@@ -212,3 +212,12 @@ def test_cli_gcn_hip_matches_gcn_seq():
     with tempfile.TemporaryDirectory() as td:
         r = subprocess.run([os.path.join(ROOT, "cuda_gcn_amd", "bin", "gcn-hip"), "nothing"], cwd=td, capture_output=True, text=True)
     assert r.returncode != 0 and "Cannot read input: nothing" in r.stderr
+
+
+def test_rccl_selftest():
+    """the RCCL the process loaded initialises and runs one-rank collectives on this GPU
+    (the N > 1 bench relies on the same calls)"""
+    from cuda_gcn_amd import _lib
+    lib = _lib.gcnhost()
+    rc = lib.gcnhost_rccl_selftest(0)
+    assert rc == 0, lib.gcnhost_last_error()
