@@ -151,6 +151,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_dataset_free": (I, [P]),
     "gcnhost_rccl_selftest": (I, [I]),
     "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
+    "gcnhost_local_graph": (I, [P, P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
     "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),
 }

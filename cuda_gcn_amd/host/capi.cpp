@@ -181,6 +181,19 @@ int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start, in
     if (rows_max) *rows_max = p.rows_max;
     return 0;
 }
+int gcnhost_local_graph(const int *g_indptr, const int *g_indices, int n_rows, int world, int rank,
+                        int *indptr, int *indices, int *col_deg, int *n_local, int *n_cols, int64_t *nnz_local) {
+    if (!g_indptr || !g_indices || world < 1 || rank < 0 || rank >= world) return -1;
+    const RowPartition part = make_partition(g_indptr, n_rows, world);
+    const LocalGraph lg = build_local_graph(g_indptr, g_indices, n_rows, part, rank);
+    if (n_local) *n_local = lg.n_rows;
+    if (n_cols) *n_cols = lg.n_cols;
+    if (nnz_local) *nnz_local = (int64_t)lg.indices.size();
+    if (indptr) memcpy(indptr, lg.indptr.data(), lg.indptr.size() * sizeof(int));
+    if (indices && !lg.indices.empty()) memcpy(indices, lg.indices.data(), lg.indices.size() * sizeof(int));
+    if (col_deg) memcpy(col_deg, lg.col_deg.data(), lg.col_deg.size() * sizeof(int));
+    return 0;
+}
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws) {
     HostRng rng;
     rng.seed_time((unsigned)seed);

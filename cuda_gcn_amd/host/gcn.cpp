@@ -46,22 +46,11 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
     n_local = r1 - r0;
     nnzA_local = (long)gp[r1] - gp[r0];
-    {
-        std::vector<int> lp(n_local + 1), li((size_t)nnzA_local);
-        for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
-        std::vector<int> col_deg;
-        if (world > 1) {
-            col_deg.assign((size_t)world * part.rows_max, 1);
-            for (int j = 0; j < N; j++) col_deg[part.padded(j)] = gp[j + 1] - gp[j];
-            // padded position of every global column, computed once
-            std::vector<int> pad(N);
-            for (int q = 0; q < world; q++)
-                for (int j = part.start[q]; j < part.start[q + 1]; j++) pad[j] = q * part.rows_max + (j - part.start[q]);
-            for (long e = 0; e < nnzA_local; e++) li[e] = pad[gi[gp[r0] + e]];
-            GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lp.data(), li.data(), n_local, world * part.rows_max, col_deg.data()));
-        } else {
-            GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
-        }
+    if (world > 1) {
+        const LocalGraph lg = build_local_graph(gp.data(), gi.data(), N, part, rank);
+        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
+    } else {
+        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
     }
     const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
     const long f0 = fp[r0], f1 = fp[r1];

@@ -38,3 +38,31 @@ inline RowPartition make_partition(const int *indptr, int n_rows, int world, dou
     if (p.rows_max < 1) p.rows_max = 1;
     return p;
 }
+
+// This rank's row block of the adjacency with its column indices rewritten to
+// padded all-gather positions, plus the degree of every padded column (the
+// edge coefficient needs the GLOBAL degree of the neighbour, module.cpp:92).
+struct LocalGraph {
+    std::vector<int> indptr, indices, col_deg;
+    int n_rows = 0, n_cols = 0;
+};
+
+inline LocalGraph build_local_graph(const int *gp, const int *gi, int n_rows, const RowPartition &part, int rank) {
+    LocalGraph lg;
+    const int r0 = part.start[rank], r1 = part.start[rank + 1];
+    lg.n_rows = r1 - r0;
+    lg.n_cols = part.world * part.rows_max;
+    lg.indptr.resize(lg.n_rows + 1);
+    for (int r = 0; r <= lg.n_rows; r++) lg.indptr[r] = gp[r0 + r] - gp[r0];
+    std::vector<int> pad(n_rows);
+    lg.col_deg.assign((size_t)lg.n_cols, 1);
+    for (int q = 0; q < part.world; q++)
+        for (int j = part.start[q]; j < part.start[q + 1]; j++) {
+            pad[j] = q * part.rows_max + (j - part.start[q]);
+            lg.col_deg[pad[j]] = gp[j + 1] - gp[j];
+        }
+    const long nnz = (long)gp[r1] - gp[r0];
+    lg.indices.resize((size_t)nnz);
+    for (long e = 0; e < nnz; e++) lg.indices[e] = pad[gi[gp[r0] + e]];
+    return lg;
+}

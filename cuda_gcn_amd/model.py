@@ -175,6 +175,21 @@ def partition(g_indptr, world):
     return start, rm.value
 
 
+def local_graph(g_indptr, g_indices, world, rank):
+    """(indptr, padded indices, col_deg, n_cols) of `rank`'s row block — host-only"""
+    lib = _lib.gcnhost()
+    gp, gi = _i32(g_indptr), _i32(g_indices)
+    nl, nc, nnz = C.c_int(), C.c_int(), C.c_int64()
+    rc = lib.gcnhost_local_graph(gp.ctypes.data, gi.ctypes.data, gp.size - 1, world, rank, None, None, None,
+                                 C.byref(nl), C.byref(nc), C.byref(nnz))
+    if rc != 0:
+        raise GcnHostError("local_graph failed")
+    ip, ix, cd = np.zeros(nl.value + 1, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nc.value, np.int32)
+    lib.gcnhost_local_graph(gp.ctypes.data, gi.ctypes.data, gp.size - 1, world, rank, ip.ctypes.data, ix.ctypes.data,
+                            cd.ctypes.data, None, None, None)
+    return ip, ix, cd, nc.value
+
+
 def glorot(size, in_size, out_size, seed, skip_draws=0):
     lib = _lib.gcnhost()
     w = np.zeros(size, np.float32)

@@ -92,6 +92,10 @@ int gcnhost_rccl_selftest(int device);
 
 /* host-only helpers, callable without a GPU (CPU tests) */
 int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start /* [world+1] */, int *rows_max);
+/* rank's row block with columns rewritten to padded all-gather positions (what HipGCN feeds to
+ * gcnhip_graph_create when world > 1).  Call once with NULL arrays for the sizes. */
+int gcnhost_local_graph(const int *g_indptr, const int *g_indices, int n_rows, int world, int rank,
+                        int *indptr, int *indices, int *col_deg, int *n_local, int *n_cols, int64_t *nnz_local);
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws);
 int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t skip_draws);
 

@@ -1,0 +1,97 @@
+"""Worker for the multi-rank tests (one process per rank, torch.distributed gloo
+rendezvous on 127.0.0.1).  Modes:
+  cpu  — no GPU: the row partition, the padded all-gather layout and the
+         host-staged callbacks, with the aggregation done in numpy on every
+         rank's block (checked against the single-process CPU oracle);
+  gpu  — every rank drives the HIP path on GPU 0 through HipGCNModel with the
+         host-staged transport (D2H -> gloo -> H2D), i.e. everything of the
+         N > 1 path except RCCL itself; rank 0 writes its trace to a file.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_callbacks(dist, world):
+    import torch
+
+    def allgather(user, ptr, block):
+        arr = np.ctypeslib.as_array(ptr, (block * world,))
+        t = torch.from_numpy(arr)
+        mine = t[dist.get_rank() * block:(dist.get_rank() + 1) * block].clone()
+        dist.all_gather(list(t.view(world, block).unbind(0)), mine)
+
+    def allreduce(user, ptr, n):
+        arr = np.ctypeslib.as_array(ptr, (n,))
+        dist.all_reduce(torch.from_numpy(arr))
+    return allgather, allreduce
+
+
+def main():
+    mode, name, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuda_gcn_amd import datagen, model
+    ds = datagen.make_dataset(name)
+    gp, gi, N = ds["g_indptr"], ds["g_indices"], ds["num_nodes"]
+    if mode == "cpu":
+        import ctypes as C
+        import scipy.sparse as sp
+        from oracle.pyoracle import Oracle
+        start, rows_max = model.partition(gp, world)
+        ip, ix, cd, n_cols = model.local_graph(gp, gi, world, rank)
+        r0, r1 = int(start[rank]), int(start[rank + 1])
+        dim = 12
+        x = np.random.default_rng(0).standard_normal((N, dim)).astype(np.float32)     # same on every rank
+        # in-place all-gather of this rank's block through the host callbacks
+        full = np.zeros((world * rows_max, dim), np.float32)
+        full[rank * rows_max:rank * rows_max + (r1 - r0)] = x[r0:r1]
+        ag, ar = make_callbacks(dist, world)
+        ag(None, full.ctypes.data_as(C.POINTER(C.c_float)), rows_max * dim)
+        for q in range(world):                                                        # every block landed where padded() says
+            a, b = int(start[q]), int(start[q + 1])
+            assert np.array_equal(full[q * rows_max:q * rows_max + (b - a)], x[a:b])
+        deg = np.diff(ip).astype(np.int64)
+        src = np.repeat(np.arange(r1 - r0), deg)
+        coef = (1.0 / np.sqrt((deg[src] * cd[ix].astype(np.int64)).astype(np.float32)).astype(np.float64)).astype(np.float32)
+        A = sp.csr_matrix((coef, ix, ip), shape=(r1 - r0, n_cols))
+        local = A @ full
+        want = Oracle().graphsum(gp, gi, x, dim)[r0:r1]
+        assert np.allclose(local, want, rtol=1e-5, atol=1e-5), np.abs(local - want).max()
+        v = np.array([rank + 1.0, 10.0 * (rank + 1)], np.float64)
+        ar(None, v.ctypes.data_as(C.POINTER(C.c_double)), 2)
+        tot = world * (world + 1) / 2
+        assert np.array_equal(v, [tot, 10 * tot])
+        if rank == 0:
+            np.save(out, np.array([1.0]))
+    else:
+        ag, ar = make_callbacks(dist, world)
+        epochs = int(sys.argv[4])
+        flags = int(sys.argv[5])
+        dropout = float(sys.argv[6])
+        m = model.HipGCNModel(ds, seed=4, device=0, flags=flags, rank=rank, world=world, host_allgather=ag, host_allreduce=ar,
+                              hidden_dim=16, dropout=dropout, epochs=epochs)
+        info = m.info()
+        assert info["world"] == world and info["rank"] == rank
+        tr = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
+        test = m.eval(3)
+        w1 = m.var(2)
+        h1 = m.var(3)                                   # this rank's rows of H1
+        m.close()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (info["row_start"], h1))
+        if rank == 0:
+            H1 = np.concatenate([g[1] for g in sorted(gathered, key=lambda t: t[0])], axis=0)
+            np.savez(out, trace=tr, test=np.array(test, np.float32), w1=w1, h1=H1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
