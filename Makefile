@@ -7,7 +7,7 @@ LIBDIR   = $(PKG)/lib
 BINDIR   = $(PKG)/bin
 OBJDIR   = build/obj
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Iinclude
-CXXFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -Iinclude -I$(PKG)/host -I/opt/rocm/include -D__HIP_PLATFORM_AMD__
+CXXFLAGS = -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-sign-compare -Iinclude -I$(PKG)/host -I/opt/rocm/include -D__HIP_PLATFORM_AMD__
 
 KSRC = $(wildcard $(PKG)/csrc/*.hip)
 KOBJ = $(patsubst $(PKG)/csrc/%.hip,$(OBJDIR)/%.o,$(KSRC))
@@ -36,9 +36,11 @@ $(LIBDIR)/libgcnhost.so: $(HOBJ) $(LIBDIR)/libgcnhip.so
 	$(CXX) -shared -fPIC $(HOBJ) -L$(LIBDIR) -lgcnhip -L/opt/rocm/lib -lrccl -lamdhip64 \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -o $@
 
-$(BINDIR)/gcn-hip: $(PKG)/host/main.cpp $(LIBDIR)/libgcnhost.so
+# the program links the host objects directly (libgcnhost.so exports only its C entry points)
+$(BINDIR)/gcn-hip: $(PKG)/host/main.cpp $(HOBJ) $(LIBDIR)/libgcnhip.so
 	@mkdir -p $(BINDIR)
-	$(CXX) $(CXXFLAGS) $< -L$(LIBDIR) -lgcnhost -lgcnhip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -o $@
+	$(CXX) $(CXXFLAGS) $< $(HOBJ) -L$(LIBDIR) -lgcnhip -L/opt/rocm/lib -lrccl -lamdhip64 -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -o $@
 
 oracle:
 	$(MAKE) -s -C oracle

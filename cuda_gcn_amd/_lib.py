@@ -28,7 +28,7 @@ def _load(name: str) -> C.CDLL:
             f"{path} not found: the HIP extension is not built. Run `make kernels host` "
             f"(or __graft_entry__.build()); there is no CPU fallback.")
     try:
-        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(path)          # RTLD_LOCAL: the C++ host classes must not interpose on anyone else's
     except OSError as e:  # pragma: no cover
         raise NativeLibraryMissing(f"cannot load {path}: {e}") from e
     _cache[name] = lib

@@ -18,6 +18,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 typedef struct gcnhost_model gcnhost_model;
 
@@ -99,6 +100,7 @@ int gcnhost_local_graph(const int *g_indptr, const int *g_indices, int n_rows, i
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws);
 int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t skip_draws);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif
