@@ -57,6 +57,7 @@ struct gcnhip_feat {
     int *csc_ptr;       // [n_cols+1]
     int *csc_row;       // [nnz] source row of each entry
     int *csc_pos;       // [nnz] position jj in CSR order (selects value + dropout decision)
+    uint32_t *keep_bits; // [ceil(nnz/32)+1] input-dropout decisions of the current call (dense path)
 };
 
 // ---- Philox4x32-10 (Salmon et al., SC'11): counter-based, so the dropout
@@ -77,38 +78,47 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// threshold of the reference: int(p * MY_RAND_MAX) with float arithmetic
-// (src/seq/module.cpp:211); keep <=> (int)r31 >= threshold.
-__host__ __device__ inline int dropout_threshold(float p) { return (int)(p * (float)0x7fffffff); }
-
-// keep decisions of the 4 elements j0..j0+3 (j0 % 4 == 0) -> bit i set = keep
-__device__ inline uint32_t keep4(uint64_t quad, uint32_t epoch, uint64_t seed, int thr) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), epoch, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) bits |= ((int)(r[i] & 0x7fffffffu) >= thr ? 1u : 0u) << i;
-    return bits;
-}
-__device__ inline bool keep1(uint64_t j, uint32_t epoch, uint64_t seed, int thr) {
-    uint32_t r[4];
-    const uint64_t quad = j >> 2;
-    philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), epoch, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return (int)(r[j & 3] & 0x7fffffffu) >= thr;
+// ---- dropout decisions: bit-sliced Bernoulli on top of Philox ----------------
+// The reference keeps an element iff (int)RAND() >= int(p * 0x7fffffff) with a
+// 31-bit uniform (src/seq/module.cpp:211-215).  Here the uniform has 16 bits:
+//     keep(j)  <=>  U16(j) >= thr16,   thr16 = round(p * 65536)
+// and U16 is never materialised: its bit planes are 32-lane words, so one
+// Philox block decides 32 elements per plane, and only the planes down to the
+// lowest set bit of thr16 are needed (p = 0.5 -> thr16 = 0x8000 -> ONE plane:
+// 128 decisions per Philox call instead of 4).
+//   element j: block c = j >> 7, group g = (j >> 5) & 3, bit b = j & 31
+//   plane i (1 = MSB .. 16): P_i = Philox4x32-10(ctr = {lo32 c, hi32 c, epoch, i}, key = seed)[g]
+//   ge = ~0; for i = n_planes .. 1: ge = bit(thr16, 16 - i) ? (P_i & ge) : (P_i | ge)
+//   keep(j) = bit b of ge;   n_planes = 16 - ctz(thr16);  thr16 == 0 keeps everything.
+__host__ __device__ inline int dropout_threshold(float p) {
+    int t = (int)(p * 65536.0f + 0.5f);
+    return t < 0 ? 0 : (t > 65535 ? 65535 : t);
 }
 
-// keep decisions of V (1, 2 or 4) consecutive elements starting at j, j % V == 0:
-// they share one Philox block.  Bit s set = keep element j + s.
+// the 32 keep decisions of group g of block c
+__device__ inline uint32_t keep_word(uint64_t c, int g, uint32_t epoch, uint64_t seed, int thr16) {
+    if (thr16 == 0) return 0xFFFFFFFFu;
+    const int n_planes = 16 - (__ffs(thr16) - 1);
+    uint32_t ge = 0xFFFFFFFFu;
+    for (int i = n_planes; i >= 1; i--) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), epoch, (uint32_t)i, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        const uint32_t P = g == 0 ? r[0] : (g == 1 ? r[1] : (g == 2 ? r[2] : r[3]));
+        ge = (thr16 >> (16 - i) & 1) ? (P & ge) : (P | ge);
+    }
+    return ge;
+}
+__device__ inline bool keep1(uint64_t j, uint32_t epoch, uint64_t seed, int thr16) {
+    return (keep_word(j >> 7, (int)(j >> 5) & 3, epoch, seed, thr16) >> (j & 31)) & 1u;
+}
+// V (1, 2 or 4) consecutive elements starting at j, j % V == 0: bit s set = keep element j + s
 template <int V>
-__device__ inline uint32_t keepv(uint64_t j, uint32_t epoch, uint64_t seed, int thr) {
-    uint32_t r[4];
-    const uint64_t quad = j >> 2;
-    philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), epoch, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    const int w0 = (int)(j & 3);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int s = 0; s < V; s++) bits |= ((int)(r[(w0 + s) & 3] & 0x7fffffffu) >= thr ? 1u : 0u) << s;
-    return bits;
+__device__ inline uint32_t keepv(uint64_t j, uint32_t epoch, uint64_t seed, int thr16) {
+    return (keep_word(j >> 7, (int)(j >> 5) & 3, epoch, seed, thr16) >> (j & 31)) & ((1u << V) - 1u);
+}
+// the 4 elements of quad q (elements 4q .. 4q+3)
+__device__ inline uint32_t keep4(uint64_t quad, uint32_t epoch, uint64_t seed, int thr16) {
+    return keepv<4>(quad << 2, epoch, seed, thr16);
 }
 
 __device__ inline float wave_sum(float v) {

@@ -239,6 +239,7 @@ int gcnhip_feat_create(gcnhip_ctx *c, gcnhip_feat **out, const int *h_indptr, co
     GCNHIP_TRY(hipMemcpy(f->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
     GCNHIP_TRY(hipMalloc((void **)&f->values, (size_t)std::max<int64_t>(nnz, 4) * sizeof(float)));
     if (nnz) GCNHIP_TRY(hipMemcpy(f->values, h_values, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (size_t)(nnz / 32 + 2) * sizeof(uint32_t)));
     if (!dense) {
         for (int64_t e = 0; e < nnz; e++)
             if (h_indices[e] < 0 || h_indices[e] >= n_cols) { return -1; }
@@ -278,6 +279,7 @@ int gcnhip_feat_destroy(gcnhip_ctx *c, gcnhip_feat *f) {
     if (f->csc_ptr) hipFree(f->csc_ptr);
     if (f->csc_row) hipFree(f->csc_row);
     if (f->csc_pos) hipFree(f->csc_pos);
+    if (f->keep_bits) hipFree(f->keep_bits);
     delete f;
     return 0;
 }

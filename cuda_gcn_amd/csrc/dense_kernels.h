@@ -34,7 +34,10 @@ struct RowStreamArgs {
     const float *H; int ldh; float scale;
 };
 
-template <int NT, bool VEC, bool FUSE>
+// KCH > 0: the K extent is KCH chunks of 16 (K <= 128) and a wave issues all of its KCH
+// 16-byte loads of a row tile before the first MFMA (KCH KiB in flight per wave instead of
+// one dependent load per chunk).  KCH == 0: generic loop for longer K.
+template <int NT, bool VEC, bool FUSE, int KCH>
 __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float Bs[];
     constexpr int NCLD = NT * 16 + 4;        // +4: the four k-groups of a wave hit disjoint banks
@@ -51,6 +54,20 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int n_tiles = (a.m + 15) / 16;
+    auto load4 = [&](const float *ap, int kk, bool valid, float av[4]) {
+        av[0] = av[1] = av[2] = av[3] = 0.f;
+        if (valid && kk < a.K) {
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4 *>(ap + kk);
+                av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; s++) if (kk + s < a.K) av[s] = ap[kk + s];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) if (kk + s >= a.K) av[s] = 0.f;   // pad columns may hold anything
+        }
+    };
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int row = tile * 16 + li;
         const bool valid = row < a.m;
@@ -58,26 +75,34 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < Kp; k0 += 16) {
-            const int kk = k0 + 4 * kq;
-            float av[4] = {0.f, 0.f, 0.f, 0.f};
-            if (valid && kk < a.K) {
-                if (VEC) {
-                    const float4 v = *reinterpret_cast<const float4 *>(ap + kk);
-                    av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
-                } else {
+        if (KCH > 0) {
+            float av[KCH > 0 ? KCH : 1][4];
 #pragma unroll
-                    for (int s = 0; s < 4; s++) if (kk + s < a.K) av[s] = ap[kk + s];
+            for (int c = 0; c < KCH; c++) load4(ap, c * 16 + 4 * kq, valid, av[c]);
+#pragma unroll
+            for (int c = 0; c < KCH; c++) {
+                const int kk = c * 16 + 4 * kq;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const float b = Bs[(kk + s) * NCLD + t * 16 + li];
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][s], b, acc[t], 0, 0, 0);
+                    }
                 }
-#pragma unroll
-                for (int s = 0; s < 4; s++) if (kk + s >= a.K) av[s] = 0.f;   // pad columns may hold anything
             }
+        } else {
+            for (int k0 = 0; k0 < Kp; k0 += 16) {
+                const int kk = k0 + 4 * kq;
+                float av[4];
+                load4(ap, kk, valid, av);
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < 4; s++) {
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const float b = Bs[(kk + s) * NCLD + t * 16 + li];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) {
+                        const float b = Bs[(kk + s) * NCLD + t * 16 + li];
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b, acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -186,16 +211,29 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
             }
 }
 
-// out[nidx][pidx] = sum over workers, in worker order
+// out[nidx][pidx] = sum over workers.  Each output is summed by 4 threads over 4
+// contiguous worker ranges; the 4 partials are added in range order (fixed tree:
+// bitwise reproducible).
 static __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *slab, int n_workers, int n, int p, int p_ld,
-                                                          float *out, int ld_out) {
+                                                                 float *out, int ld_out) {
+    __shared__ float part[4][64];
     const int64_t total = (int64_t)n * p;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / p), c = (int)(i % p);
-        const float *s = slab + (size_t)r * p_ld + c;
+    const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+    const int per = (n_workers + 3) / 4;
+    const int w0 = chunk * per, w1 = min(n_workers, w0 + per);
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
         float acc = 0.f;
-        for (int w = 0; w < n_workers; w++) acc += s[(size_t)w * n * p_ld];
-        out[(size_t)r * ld_out + c] = acc;
+        int r = 0, c = 0;
+        if (i < total) {
+            r = (int)(i / p); c = (int)(i % p);
+            const float *s = slab + (size_t)r * p_ld + c;
+            for (int w = w0; w < w1; w++) acc += s[(size_t)w * n * p_ld];
+        }
+        part[chunk][lane] = acc;
+        __syncthreads();
+        if (chunk == 0 && i < total) out[(size_t)r * ld_out + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        __syncthreads();
     }
 }
 
@@ -244,8 +282,8 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     else ATB(1, 1);
 #undef ATB
     GCNHIP_LAUNCH_CHECK();
-    int rb = ceil_div((int64_t)n * p, 256);
-    if (rb > 2048) rb = 2048;
+    int rb = ceil_div((int64_t)n * p, 64);
+    if (rb > 4096) rb = 4096;
     slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(a.slab, a.n_workers, n, p, a.p_ld, out, ld_out);
     GCNHIP_LAUNCH_CHECK();
     return 0;
@@ -268,12 +306,22 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
     const int cap = c->n_cu * (lds > 76 * 1024 ? 1 : (lds > 32 * 1024 ? 2 : 4));
     if (gx > cap) gx = cap;
     dim3 grid(gx, gy);
-#define RS1(NT_, V_, F_)                                                                                  \
+#define RS2(NT_, V_, F_, K_)                                                                              \
     do {                                                                                                  \
-        auto kern = gemm_rowstream_kernel<NT_, V_, F_>;                                                   \
+        auto kern = gemm_rowstream_kernel<NT_, V_, F_, K_>;                                               \
         if (lds > 64 * 1024)                                                                              \
             GCNHIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<grid, 256, lds, c->stream>>>(a);                                                           \
+    } while (0)
+#define RS1(NT_, V_, F_)                                                                                  \
+    do {                                                                                                  \
+        switch (Kp <= 128 ? Kp / 16 : 0) {                                                                \
+            case 1: RS2(NT_, V_, F_, 1); break;                                                           \
+            case 2: RS2(NT_, V_, F_, 2); break;                                                           \
+            case 3: RS2(NT_, V_, F_, 3); break;                                                           \
+            case 4: RS2(NT_, V_, F_, 4); break;                                                           \
+            default: RS2(NT_, V_, F_, 0); break;                                                          \
+        }                                                                                                 \
     } while (0)
 #define RS(NT_)                                                                                           \
     do {                                                                                                  \
@@ -292,6 +340,7 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
     }
 #undef RS
 #undef RS1
+#undef RS2
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

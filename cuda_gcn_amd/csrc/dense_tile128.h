@@ -1,0 +1,288 @@
+// dense_tile128.h — the two compute-bound GEMMs of a dense-X first layer
+// (Reddit: X is 232 965 x 602, stored as CSR with every column present):
+//     forward   H0[m x p]  = X~[m x K] . W[K x p]           (35.9 GFLOP at p = 128)
+//     backward  dW[K x p]  = X~^T[K x m] . dH0[m x p]        (same FLOPs, m is the reduction)
+// Exact-f32 matrix cores: v_mfma_f32_32x32x2_f32 (A[i=lane&31][k=lane>>5], B[k][j=lane&31],
+// D[row=(reg&3)+8*(reg>>2)+4*(lane>>5)][col=lane&31]; cdna guide §3) — one LDS read per operand
+// per 4096 FLOP, half of the 16x16x4 form.  Workgroup tile 128 x 128, 4 waves as 2 x 2, each
+// wave 64 x 64 = 2 x 2 MFMA tiles; K chunks of 32 staged through LDS with the next chunk
+// prefetched into registers while the current one is multiplied.
+// The input dropout is applied while staging X, from a bit mask built once per call by
+// dropbits_kernel (one Philox block per 32 decisions and bit plane; one plane at p = 0.5).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- keep bits: bit (e & 31) of word (e >> 5) = keep decision of stored element e ----------
+__global__ __launch_bounds__(256) void dropbits_kernel(uint32_t *__restrict__ bits, int64_t n_elems, int thr,
+                                                       uint64_t seed, const uint32_t *d_epoch, uint64_t off,
+                                                       const uint8_t *__restrict__ keep_mask) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e0 = w * 32;
+    if (e0 >= n_elems) return;
+    uint32_t word = 0;
+    if (keep_mask) {
+        for (int b = 0; b < 32 && e0 + b < n_elems; b++) word |= (keep_mask[e0 + b] ? 1u : 0u) << b;
+    } else {
+        const uint32_t epoch = d_epoch ? *d_epoch : 0u;
+        const uint64_t j0 = off + (uint64_t)e0;
+        const uint32_t sh = (uint32_t)(j0 & 31);
+        word = keep_word(j0 >> 7, (int)(j0 >> 5) & 3, epoch, seed, thr) >> sh;
+        if (sh) {                                           // the rank's offset is not a multiple of 32
+            const uint64_t j1 = j0 + 32;
+            word |= keep_word(j1 >> 7, (int)(j1 >> 5) & 3, epoch, seed, thr) << (32 - sh);
+        }
+    }
+    bits[w] = word;
+}
+
+struct Tile128Args {
+    const float *x; int ldx;          // X: m x K, row stride ldx
+    const float *w; int ldw;          // fwd: W [K x p];  bwd: dH0 [m x p]
+    float *out; int ldo;              // fwd: H0 [m x p]; bwd: slab [S][K][p_ld]
+    int m, K, p;
+    const uint32_t *bits;             // NULL: no dropout
+    float scale;
+    int rows_per_split;               // bwd only
+};
+
+template <int V>
+__device__ inline void load_vec_t(const float *p, int valid, float out[V]) {
+    if (valid >= V) {
+        if (V == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+        else if (V == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); out[0] = v.x; out[1] = v.y; }
+        else out[0] = *p;
+    } else {
+#pragma unroll
+        for (int s = 0; s < V; s++) out[s] = s < valid ? p[s] : 0.f;
+    }
+}
+
+// keep bits of V consecutive stored elements starting at e
+template <int V>
+__device__ inline uint32_t bits_at(const uint32_t *bits, uint64_t e) {
+    const uint32_t sh = (uint32_t)(e & 31);
+    uint32_t v = bits[e >> 5] >> sh;
+    if (V > 1 && sh + V > 32) v |= bits[(e >> 5) + 1] << (32 - sh);
+    return v;
+}
+
+#define MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+
+// --------------------------------------------------------------------- forward
+constexpr int T_BM = 128, T_BN = 128, T_BK = 32;
+constexpr int T_ALD = T_BK + 1;       // A tile [row][k]: lanes of a half-wave walk rows -> odd stride, conflict-free
+
+template <int VX>
+__global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
+    __shared__ float As[T_BM * T_ALD];
+    __shared__ __attribute__((aligned(16))) float Bs[T_BK * T_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kq = lane >> 5;
+    const int row_base = blockIdx.x * T_BM, col_base = blockIdx.y * T_BN;
+    constexpr int LPR = T_BK / VX;                        // lanes per A row
+    constexpr int A_PIECES = T_BM * T_BK / (256 * VX);
+    float areg[A_PIECES][VX];
+    uint32_t kreg[A_PIECES];                              // keep bits, applied in stash(): the multiply must not
+    float4 breg[4];                                       // wait for the loads before the MFMA loop starts
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 256 + tid;
+            const int r = idx / LPR, c = (idx % LPR) * VX;
+            const int row = row_base + r, col = k0 + c;
+#pragma unroll
+            for (int s = 0; s < VX; s++) areg[pc][s] = 0.f;
+            if (row < a.m && col < a.K) {
+                load_vec_t<VX>(a.x + (size_t)row * a.ldx + col, a.K - col, areg[pc]);
+                if (a.bits) kreg[pc] = a.bits[((uint64_t)row * a.K + col) >> 5];      // raw word: no ALU on it here
+            }
+        }
+#pragma unroll
+        for (int pc = 0; pc < 4; pc++) {
+            const int idx = (pc * 256 + tid) * 4;
+            const int k = idx / T_BN, c = idx % T_BN;
+            const int gk = k0 + k, gc = col_base + c;
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gk < a.K) {
+                if ((a.ldw & 3) == 0 && gc + 4 <= a.p) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.w + (size_t)gk * a.ldw + gc);
+                    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) if (gc + s < a.p) t[s] = a.w[(size_t)gk * a.ldw + gc + s];
+                }
+            }
+            breg[pc] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    auto stash = [&](int cur_k0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 256 + tid;
+            const int r = idx / LPR, c = (idx % LPR) * VX;
+            // element index of (row, col) is a multiple of VX, so its VX bits sit in one word
+            const uint32_t kb = a.bits ? kreg[pc] >> (uint32_t)(((uint64_t)(row_base + r) * a.K + cur_k0 + c) & 31) : 0xFu;
+#pragma unroll
+            for (int s = 0; s < VX; s++)
+                As[r * T_ALD + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
+        }
+#pragma unroll
+        for (int pc = 0; pc < 4; pc++) {
+            const int idx = (pc * 256 + tid) * 4;
+            *reinterpret_cast<float4 *>(&Bs[idx]) = breg[pc];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    fetch(0);
+    for (int k0 = 0; k0 < a.K; k0 += T_BK) {
+        __syncthreads();
+        stash(k0);
+        __syncthreads();
+        if (k0 + T_BK < a.K) fetch(k0 + T_BK);
+        const float *Ap = &As[(wm * 64 + li) * T_ALD + kq];
+        const float *Bp = &Bs[kq * T_BN + wn * 64 + li];
+#pragma unroll
+        for (int kk = 0; kk < T_BK; kk += 2) {
+            const float a0 = Ap[kk], a1 = Ap[32 * T_ALD + kk];
+            const float b0 = Bp[kk * T_BN], b1 = Bp[kk * T_BN + 32];
+            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = col_base + wn * 64 + j * 32 + li;
+            if (col >= a.p) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = row_base + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                if (row < a.m) a.out[(size_t)row * a.ldo + col] = acc[i][j][r];
+            }
+        }
+}
+
+// -------------------------------------------------------------------- backward
+// grid (S splits of the row range, K tiles of 128 X-columns, p tiles of 128).
+// LDS tiles are k-major exactly as loaded: As[k][xcol], Bs[k][pcol]; both MFMA
+// operands read 32 consecutive floats per half-wave (conflict-free).
+template <int VX>
+__global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
+    __shared__ __attribute__((aligned(16))) float As[T_BK * 128];
+    __shared__ __attribute__((aligned(16))) float Bs[T_BK * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kq = lane >> 5;
+    const int xc_base = blockIdx.y * 128, pc_base = blockIdx.z * 128;
+    const int r_begin = blockIdx.x * a.rows_per_split;
+    const int r_end = min(a.m, r_begin + a.rows_per_split);
+    constexpr int LPR = 128 / VX;
+    constexpr int A_PIECES = T_BK * 128 / (256 * VX);
+    float areg[A_PIECES][VX];
+    uint32_t kreg[A_PIECES];
+    float4 breg[4];
+
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 256 + tid;
+            const int k = idx / LPR, c = (idx % LPR) * VX;
+            const int row = r0 + k, col = xc_base + c;
+#pragma unroll
+            for (int s = 0; s < VX; s++) areg[pc][s] = 0.f;
+            if (row < r_end && col < a.K) {
+                load_vec_t<VX>(a.x + (size_t)row * a.ldx + col, a.K - col, areg[pc]);
+                if (a.bits) kreg[pc] = a.bits[((uint64_t)row * a.K + col) >> 5];      // raw word: no ALU on it here
+            }
+        }
+#pragma unroll
+        for (int pc = 0; pc < 4; pc++) {
+            const int idx = (pc * 256 + tid) * 4;
+            const int k = idx / 128, c = idx % 128;
+            const int row = r0 + k, gc = pc_base + c;
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < r_end) {
+                if ((a.ldw & 3) == 0 && gc + 4 <= a.p) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.w + (size_t)row * a.ldw + gc);
+                    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) if (gc + s < a.p) t[s] = a.w[(size_t)row * a.ldw + gc + s];
+                }
+            }
+            breg[pc] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    auto stash = [&](int cur_r0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 256 + tid;
+            const int k = idx / LPR, c = (idx % LPR) * VX;
+            const uint32_t kb = a.bits ? kreg[pc] >> (uint32_t)(((uint64_t)(cur_r0 + k) * a.K + xc_base + c) & 31) : 0xFu;
+#pragma unroll
+            for (int s = 0; s < VX; s++)
+                As[k * 128 + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
+        }
+#pragma unroll
+        for (int pc = 0; pc < 4; pc++) {
+            const int idx = (pc * 256 + tid) * 4;
+            *reinterpret_cast<float4 *>(&Bs[idx]) = breg[pc];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += T_BK) {
+        __syncthreads();
+        stash(r0);
+        __syncthreads();
+        if (r0 + T_BK < r_end) fetch(r0 + T_BK);
+        const float *Ap = &As[kq * 128 + wm * 64 + li];
+        const float *Bp = &Bs[kq * 128 + wn * 64 + li];
+#pragma unroll
+        for (int kk = 0; kk < T_BK; kk += 2) {
+            const float a0 = Ap[kk * 128], a1 = Ap[kk * 128 + 32];
+            const float b0 = Bp[kk * 128], b1 = Bp[kk * 128 + 32];
+            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+        }
+    }
+    // partial [K x p] of this split
+    float *slab = a.out + (size_t)blockIdx.x * a.K * a.ldo;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int pc = pc_base + wn * 64 + j * 32 + li;
+            if (pc >= a.p) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int xc = xc_base + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                if (xc < a.K) slab[(size_t)xc * a.ldo + pc] = acc[i][j][r];
+            }
+        }
+}

@@ -12,6 +12,7 @@
 //    (dense_kernels.h).  Treating it as a gather would move nnz*h*4 bytes
 //    (72 GB) through L2 instead of 0.56 GB from HBM.
 #include "dense_kernels.h"
+#include "dense_tile128.h"
 
 struct DropSpec {
     int on, thr;
@@ -298,6 +299,18 @@ static DropSpec make_drop(float p_drop, uint64_t seed, const uint32_t *d_epoch, 
     return d;
 }
 
+// keep bits for the nnz stored elements of f (Philox or injected decisions)
+static int make_keep_bits(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d) {
+    const int64_t words = (f->nnz + 31) / 32;
+    dropbits_kernel<<<ceil_div(words, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off, d.keep_mask);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+static int x_vec_width(const gcnhip_feat *f, const float *vals) {
+    return (f->n_cols % 4 == 0 && aligned16(vals)) ? 4 : ((f->n_cols % 2 == 0 && ((uintptr_t)vals & 7) == 0) ? 2 : 1);
+}
+
 template <int NT>
 static void launch_dense_fwd(const DenseFwdArgs &a, int vx, dim3 grid, hipStream_t s) {
     if (vx == 4) spmm_dense_fwd_kernel<NT, 4><<<grid, 256, 0, s>>>(a);
@@ -314,6 +327,19 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
     if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
     if (f->n_rows == 0) return 0;
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
+    if (f->dense && p > 64) {                 // 128 x 128 MFMA tiles
+        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
+        Tile128Args t;
+        t.x = vals; t.ldx = f->n_cols; t.w = w; t.ldw = ld_w; t.out = out; t.ldo = ld_out;
+        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = 0;
+        dim3 grid(ceil_div(f->n_rows, T_BM), ceil_div(p, T_BN));
+        const int vx = x_vec_width(f, vals);
+        if (vx == 4) dense_fwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
+        else if (vx == 2) dense_fwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
+        else dense_fwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (f->dense) {
         DenseFwdArgs a;
         a.x = vals; a.ldx = f->n_cols; a.w = w; a.ldw = ld_w; a.out = out; a.ldo = ld_out;
@@ -355,6 +381,32 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
     if (!c || !f || !vals || !dout || !dw || p <= 0 || ld_dout < p || ld_dw < p) return -1;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
+    if (f->dense && p > 64 && f->n_cols >= 64) {      // split-K 128 x 128 MFMA tiles + ordered slab sum
+        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
+        const int kt = ceil_div(f->n_cols, 128), pt = ceil_div(p, 128);
+        int S = (2 * c->n_cu) / (kt * pt);
+        if (S < 1) S = 1;
+        int rps = (ceil_div(f->n_rows, S) + T_BK - 1) / T_BK * T_BK;
+        if (rps < T_BK) rps = T_BK;
+        S = ceil_div(f->n_rows, rps);
+        const int p_ld = (p + 3) / 4 * 4;
+        const int rc = ensure_slab(c, (size_t)S * f->n_cols * p_ld * sizeof(float));
+        if (rc) return rc;
+        Tile128Args t;
+        t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
+        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps;
+        dim3 grid(S, kt, pt);
+        const int vx = x_vec_width(f, vals);
+        if (vx == 4) dense_bwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
+        else if (vx == 2) dense_bwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
+        else dense_bwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
+        GCNHIP_LAUNCH_CHECK();
+        int rb = ceil_div((int64_t)f->n_cols * p, 64);
+        if (rb > 4096) rb = 4096;
+        slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(c->slab, S, f->n_cols, p, p_ld, dw, ld_dw);
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (f->dense)
         return launch_atb(c, vals, f->n_cols, dout, ld_dout, dw, ld_dw, f->n_rows, f->n_cols, p,
                           d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask);

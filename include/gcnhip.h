@@ -150,15 +150,17 @@ int gcnhip_relu_bwd(gcnhip_ctx *ctx, float *grad, const uint8_t *mask, int64_t n
 /* ---- Dropout (CUDADropout: cuda_module.cu:201-227; cuda_kernel.cu:223-240;
  *      CPU: src/seq/module.cpp:207-233) -----------------------------------------
  * x[i] *= keep(i) ? 1/(1-p) : 0;  mask[i] = keep(i) when mask != NULL.
- * keep(i) <=> (r31 >= (int)(p * 0x7fffffff)) with r31 the low 31 bits of word
- * (j & 3) of Philox4x32-10(counter = {lo32(j>>2), hi32(j>>2), epoch, 0},
- * key = {lo32(seed), hi32(seed)}), j = elem_offset + i, epoch = d_epoch ?
- * *d_epoch : 0 (a device word, so a captured graph replays with fresh masks).
- * This counter-based stream replaces the reference's sequential xorshift128+
- * (rand.cpp:17-28) and its 1024 shared curand states (cuda_kernel.cu:229); it
- * is invariant to how rows are partitioned across GPUs.  For bit-parity runs
- * against the CPU path pass the reference's own decisions in keep_in (one
- * byte per element); then the RNG is not used. */
+ * keep(i) <=> U16(j) >= thr16 with j = elem_offset + i, thr16 = round(p * 65536) — the reference's
+ * test (int)RAND() >= int(p * 0x7fffffff) (module.cpp:211-215) at 16-bit resolution.  U16 is generated
+ * bit-sliced from a counter-based generator: with c = j >> 7, g = (j >> 5) & 3, b = j & 31 and
+ *     P_i = Philox4x32-10(counter = {lo32 c, hi32 c, epoch, i}, key = {lo32 seed, hi32 seed})[g]
+ * for planes i = 1 (MSB) .. n = 16 - ctz(thr16):  ge = ~0; for i = n..1: ge = bit(thr16, 16-i) ?
+ * (P_i & ge) : (P_i | ge);  keep = bit b of ge  (p = 0.5 needs one plane: 128 decisions per Philox
+ * block; thr16 == 0 keeps everything).  epoch = d_epoch ? *d_epoch : 0 is a DEVICE word, so a captured
+ * graph replays with fresh masks.  This replaces the reference's sequential xorshift128+
+ * (rand.cpp:17-28) and its 1024 shared curand states (cuda_kernel.cu:229), and is invariant to how
+ * rows are partitioned across GPUs.  For bit-parity runs against the CPU path pass the reference's
+ * own decisions in keep_in (one byte per element); then the generator is not used. */
 int gcnhip_dropout_fwd(gcnhip_ctx *ctx, float *x, int32_t *mask, int64_t n, float p,
                        uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
                        const uint8_t *keep_in);

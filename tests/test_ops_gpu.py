@@ -55,32 +55,42 @@ def close(a, b, rtol=RTOL, atol=ATOL):
 
 
 # --------------------------------------------------------------- Philox (test side)
-def philox_keep(seed, epoch, idx, thr):
-    """keep decisions for element indices idx (uint64 array) — numpy restatement
-    of the documented stream in include/gcnhip.h (gcnhip_dropout_fwd)."""
-    idx = np.asarray(idx, np.uint64)
-    quad = idx >> np.uint64(2)
-    c = [(quad & np.uint64(0xffffffff)).astype(np.uint64), (quad >> np.uint64(32)).astype(np.uint64),
-         np.full(idx.shape, epoch, np.uint64), np.zeros(idx.shape, np.uint64)]
-    k0, k1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
-    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
-    mask32 = np.uint64(0xffffffff)
+def philox4x32(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on uint64 numpy arrays holding 32-bit values"""
+    M0, M1, m32 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xffffffff)
+    c = [np.asarray(x, np.uint64) for x in (c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
     for _ in range(10):
         p0, p1 = M0 * c[0], M1 * c[2]
-        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask32
-        n1 = p1 & mask32
-        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask32
-        n3 = p0 & mask32
-        c = [n0, n1, n2, n3]
-        k0 = (k0 + np.uint64(0x9E3779B9)) & mask32
-        k1 = (k1 + np.uint64(0xBB67AE85)) & mask32
-    words = np.stack(c, axis=-1)
-    r = np.take_along_axis(words, (idx & np.uint64(3)).astype(np.int64)[..., None], axis=-1)[..., 0]
-    return (r & np.uint64(0x7fffffff)).astype(np.int64) >= thr
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c
+
+
+def philox_keep(seed, epoch, idx, thr16):
+    """keep decisions for element indices idx — numpy restatement of the bit-sliced stream
+    documented in include/gcnhip.h (gcnhip_dropout_fwd)."""
+    idx = np.asarray(idx, np.uint64)
+    if thr16 == 0:
+        return np.ones(idx.shape, bool)
+    n_planes = 16 - ((thr16 & -thr16).bit_length() - 1)
+    blk = idx >> np.uint64(7)
+    g = ((idx >> np.uint64(5)) & np.uint64(3)).astype(np.int64)
+    b = idx & np.uint64(31)
+    ublk, inv = np.unique(blk, return_inverse=True)
+    ge = np.full((ublk.size, 4), 0xFFFFFFFF, np.uint64)
+    for i in range(n_planes, 0, -1):
+        r = philox4x32(ublk & np.uint64(0xffffffff), ublk >> np.uint64(32), np.full(ublk.shape, epoch, np.uint64),
+                       np.full(ublk.shape, i, np.uint64), seed & 0xffffffff, (seed >> 32) & 0xffffffff)
+        P = np.stack(r, axis=-1)
+        ge = (P & ge) if (thr16 >> (16 - i)) & 1 else (P | ge)
+    word = ge[inv, g]
+    return ((word >> b) & np.uint64(1)).astype(bool)
 
 
 def thr_of(p):
-    return int(np.float32(p) * np.float32(0x7fffffff))
+    return min(65535, max(0, int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))))
 
 
 def hub_graph(n=3000, hub_deg=2500, seed=3):

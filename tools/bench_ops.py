@@ -54,6 +54,8 @@ def main():
         print(f"graphsum d={dim} ld={ld}: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
     gs(h, h)
     gs(Cc, (Cc + 3) // 4 * 4)
+    gs(Cc, 48)
+    gs(Cc, 64)
     gs(Cc, Cc)
 
     w1 = dev.buf(rng.standard_normal((F, h)).astype(np.float32))
