@@ -14,10 +14,14 @@
 //  * rows longer than SPLIT_EDGES are cut into segments processed by separate
 //    waves (heavy segments dispatched first) and summed in segment order by a
 //    small second kernel, so a hub row does not serialise the tail;
+//  * XCD-aware launch for wide rows: the columns are cut into 128-byte slices and
+//    each slice is bound to the workgroups of one XCD group (blockIdx % 8), so every
+//    XCD's private 4 MiB L2 caches 1/4 of the table instead of all of it;
 //  * the ReLU + dropout of the first layer is an optional store epilogue.
 // The reference launches one block per row with `dim` threads and does a
 // global read-modify-write per edge (cuda_kernel.cu:126-143).
 #include "common.h"
+#include <stdlib.h>
 
 struct GsArgs {
     const int *indptr, *indices;
@@ -28,6 +32,7 @@ struct GsArgs {
     float *out;
     float *partials;
     int ld_in, ld_out, part_ld, dim;
+    int n_slices;     // > 1: the columns are cut into n_slices slices of L*4 floats, one slice per XCD group
     // epilogue
     int fuse, training, thr;
     float scale;
@@ -79,7 +84,19 @@ template <int L>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int t, cslice;
+    if (a.n_slices > 1) {
+        // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names
+        // the group that shares an L2; speed only, never correctness).  XCD group x works on column
+        // slice x % n_slices only, so its 4 MiB L2 sees 1/n_slices of the gathered table.
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int groups = 8 / a.n_slices;
+        cslice = xcd % a.n_slices;
+        t = (q * groups + xcd / a.n_slices) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    } else {
+        cslice = blockIdx.y;
+        t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    }
     const int nt = a.n_tasks ? a.n_tasks : a.n_rows;
     if (t >= nt) return;                                   // wave-uniform
     int row, e0, e1, slot;
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
     }
     const int g = lane / L, l = lane % L;
-    const int col0 = (blockIdx.y * L + l) * 4;             // first column of this lane's float4
+    const int col0 = (cslice * L + l) * 4;                  // first column of this lane's float4
     const bool active = col0 < a.dim;
     const float *in = a.in + col0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -220,10 +237,18 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
 }
 
 template <int L>
-static void launch_vec(const GsArgs &a, int nt, hipStream_t s) {
+static void launch_vec(GsArgs a, int nt, hipStream_t s) {
     const int ychunks = ceil_div(a.dim, L * 4);
-    dim3 grid(ceil_div(nt, 4), ychunks);
-    graphsum_vec_kernel<L><<<grid, 256, 0, s>>>(a);
+    if (ychunks > 1 && 8 % ychunks == 0) {                 // XCD-sliced columns (1-D grid)
+        a.n_slices = ychunks;
+        const int groups = 8 / ychunks;
+        dim3 grid(ceil_div(ceil_div(nt, 4), groups) * 8);
+        graphsum_vec_kernel<L><<<grid, 256, 0, s>>>(a);
+    } else {
+        a.n_slices = 1;
+        dim3 grid(ceil_div(nt, 4), ychunks);
+        graphsum_vec_kernel<L><<<grid, 256, 0, s>>>(a);
+    }
 }
 template <int L>
 static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
@@ -254,7 +279,19 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     const int nt = g->n_tasks ? g->n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
-    if (vec) {
+    a.n_slices = 1;
+    static const int force_l = getenv("GCNHIP_GS_LANES") ? atoi(getenv("GCNHIP_GS_LANES")) : 0;   // experiments
+    if (vec && force_l && d4 > force_l) {
+        if (force_l == 4) launch_vec<4>(a, nt, c->stream);
+        else if (force_l == 8) launch_vec<8>(a, nt, c->stream);
+        else if (force_l == 16) launch_vec<16>(a, nt, c->stream);
+        else launch_vec<32>(a, nt, c->stream);
+    } else if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
+        // rows of whole 128-byte lines: one 32-float column slice per XCD group (measured at
+        // Reddit scale, d = 128: 1.42 ms unsliced -> 1.26 ms; L2 hit rate of the gather rises
+        // because each XCD's L2 holds a quarter of the table)
+        launch_vec<8>(a, nt, c->stream);
+    } else if (vec) {
         if (d4 <= 1) launch_vec<1>(a, nt, c->stream);
         else if (d4 <= 2) launch_vec<2>(a, nt, c->stream);
         else if (d4 <= 4) launch_vec<4>(a, nt, c->stream);
