@@ -144,7 +144,7 @@ def main():
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab},
-            "roofline": {"bound": "hbm", "kernel": f"graphsum_vec_kernel<32> (GraphSum d={args.hidden})",
+            "roofline": {"bound": "hbm", "kernel": f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s,
                          "launches": n_wide,

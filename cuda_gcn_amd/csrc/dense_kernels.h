@@ -32,6 +32,7 @@ struct RowStreamArgs {
     int m, K, Nc;
     // epilogue: C = H > 0 ? scale*C : 0
     const float *H; int ldh; float scale;
+    int vec_out;                                // C (and H) rows are 16-byte aligned: LDS-staged row stores
 };
 
 // KCH > 0: the K extent is KCH chunks of 16 (K <= 128) and a wave issues all of its KCH
@@ -106,17 +107,56 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                 }
             }
         }
+        if (a.vec_out) {
+            // Stage the 16 x (NT*16) result through LDS so rows leave as whole 16-byte lane
+            // stores (and the mask operand H arrives as 16-byte loads): a lane owns 4
+            // consecutive columns of one row instead of 1 column of 4 rows.
+            float *Cs = Bs + Kp * NCLD + wave * 16 * (NT * 16 + 4);
+            constexpr int CLD = NT * 16 + 4;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int col = c_base + t * 16 + li;
-            if (col >= a.Nc) continue;
+            for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int r = tile * 16 + 4 * kq + i;
-                if (r >= a.m) continue;
-                float v = acc[t][i];
-                if (FUSE) v = a.H[(size_t)r * a.ldh + col] > 0.f ? v * a.scale : 0.f;
-                a.C[(size_t)r * a.ldc + col] = v;
+                for (int i = 0; i < 4; i++) Cs[(4 * kq + i) * CLD + t * 16 + li] = acc[t][i];
+            __builtin_amdgcn_wave_barrier();
+            constexpr int LPRW = NT * 4;                      // lanes per row (float4 each)
+            constexpr int RPP = 64 / LPRW > 0 ? 64 / LPRW : 1; // rows per pass
+            for (int r0 = 0; r0 < 16; r0 += RPP) {
+                const int rr = r0 + lane / LPRW, cc = (lane % LPRW) * 4;
+                const int r = tile * 16 + rr, col = c_base + cc;
+                if (lane < RPP * LPRW && rr < 16 && r < a.m && col < a.Nc) {
+                    float4 v = *reinterpret_cast<const float4 *>(&Cs[rr * CLD + cc]);
+                    float *cp = a.C + (size_t)r * a.ldc + col;
+                    if (col + 4 <= a.Nc) {
+                        if (FUSE) {
+                            const float4 h = *reinterpret_cast<const float4 *>(a.H + (size_t)r * a.ldh + col);
+                            v.x = h.x > 0.f ? v.x * a.scale : 0.f; v.y = h.y > 0.f ? v.y * a.scale : 0.f;
+                            v.z = h.z > 0.f ? v.z * a.scale : 0.f; v.w = h.w > 0.f ? v.w * a.scale : 0.f;
+                        }
+                        *reinterpret_cast<float4 *>(cp) = v;
+                    } else {
+                        const float x[4] = {v.x, v.y, v.z, v.w};
+                        for (int q = 0; col + q < a.Nc; q++) {
+                            float y = x[q];
+                            if (FUSE) y = a.H[(size_t)r * a.ldh + col + q] > 0.f ? y * a.scale : 0.f;
+                            cp[q] = y;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int col = c_base + t * 16 + li;
+                if (col >= a.Nc) continue;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int r = tile * 16 + 4 * kq + i;
+                    if (r >= a.m) continue;
+                    float v = acc[t][i];
+                    if (FUSE) v = a.H[(size_t)r * a.ldh + col] > 0.f ? v * a.scale : 0.f;
+                    a.C[(size_t)r * a.ldc + col] = v;
+                }
             }
         }
     }
@@ -164,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
 #pragma unroll
         for (int u = 0; u < VB; u++) acc[s][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int validA = a.n - colA, validB = a.p - colB;
-#pragma unroll 2
+#pragma unroll 4
     for (int k0 = r0; k0 < r1; k0 += 4) {
         const int row = k0 + kq;
         float av[VA], bv[VB];
@@ -260,7 +300,7 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     const int VB = (ldb % 4 == 0 && aligned16(Bm)) ? 4 : ((ldb % 2 == 0 && ((uintptr_t)Bm & 7) == 0) ? 2 : 1);
     const int gy = ceil_div(n, 16 * VA), gz = ceil_div(p, 16 * VB);
     // enough split-K workers to fill the chip (~8 waves per CU), at least 64 rows each
-    int workers = ceil_div((int64_t)c->n_cu * 8, (int64_t)gy * gz);
+    int workers = ceil_div((int64_t)c->n_cu * 4, (int64_t)gy * gz);
     if (workers > ceil_div(m, 64)) workers = ceil_div(m, 64);
     if (workers < 1) workers = 1;
     workers = (workers + 3) / 4 * 4;
@@ -295,12 +335,13 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
     RowStreamArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.transB = transB; a.C = C; a.ldc = ldc;
     a.m = m; a.K = K; a.Nc = Nc; a.H = H; a.ldh = ldh; a.scale = scale;
+    a.vec_out = (Nc >= 64 && ldc % 4 == 0 && aligned16(C) && (!H || (ldh % 4 == 0 && aligned16(H)))) ? 1 : 0;
     const bool vec = lda % 4 == 0 && aligned16(A);
     const int nt_total = ceil_div(Nc, 16);
     const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 3 ? 4 : nt_total));
     const int gy = ceil_div(nt_total, NT);
     const int Kp = (K + 15) / 16 * 16;
-    const size_t lds = (size_t)Kp * (NT * 16 + 4) * sizeof(float);
+    const size_t lds = ((size_t)Kp * (NT * 16 + 4) + (a.vec_out ? 4 * 16 * (NT * 16 + 4) : 0)) * sizeof(float);   // Bs (+ 4 waves' C staging)
     if (lds > 156 * 1024) return -1;          // K too long for an LDS-resident operand (gfx950: 160 KiB per CU)
     int gx = ceil_div(ceil_div(m, 16), 4);
     const int cap = c->n_cu * (lds > 76 * 1024 ? 1 : (lds > 32 * 1024 ? 2 : 4));
