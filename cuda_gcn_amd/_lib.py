@@ -82,6 +82,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graph_destroy": (I, [P, P]),
     "gcnhip_graph_arrays": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
     "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),
+    "gcnhip_graphsum_rowmask": (I, [P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
     "gcnhip_feat_destroy": (I, [P, P]),

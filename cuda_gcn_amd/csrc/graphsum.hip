@@ -39,6 +39,7 @@ struct GsArgs {
     uint64_t seed, elem_offset;
     const uint32_t *d_epoch;
     const uint8_t *keep_mask;
+    const uint32_t *row_bits;   // optional: bit j == 0 -> row j of `in` is all zero and is not read
 };
 
 __device__ inline float4 f4_fma(float c, float4 v, float4 a) {
@@ -115,14 +116,18 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         const int cnt = min(WAVE, e1 - base);
         int my_idx = 0;
         float my_c = 0.f;
-        if (lane < cnt) { my_idx = a.indices[base + lane]; my_c = a.coef[base + lane]; }
+        if (lane < cnt) {
+            my_idx = a.indices[base + lane];
+            my_c = a.coef[base + lane];                    // > 0 for every real edge
+            if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
+        }
         const int iters = (cnt + G - 1) / G;
 #pragma unroll 8
         for (int k = 0; k < iters; k++) {
             const int src = k * G + g;
             const int j = __shfl(my_idx, src, WAVE);
             const float c = __shfl(my_c, src, WAVE);
-            if (active && src < cnt) {                     // a padded lane must not touch memory: 0 * Inf = NaN
+            if (active && src < cnt && c != 0.f) {         // padded lanes and known-zero rows are never read
                 const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld_in);
                 acc = f4_fma(c, v, acc);
             }
@@ -169,7 +174,11 @@ __global__ __launch_bounds__(256) void graphsum_scalar_kernel(GsArgs a) {
             const int cnt = min(WAVE, e1 - base);
             int my_idx = 0;
             float my_c = 0.f;
-            if (lane < cnt) { my_idx = a.indices[base + lane]; my_c = a.coef[base + lane]; }
+            if (lane < cnt) {
+                my_idx = a.indices[base + lane];
+                my_c = a.coef[base + lane];
+                if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
+            }
             const int iters = (cnt + G - 1) / G;
 #pragma unroll 4
             for (int k = 0; k < iters; k++) {
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void graphsum_scalar_kernel(GsArgs a) {
                 const int j = __shfl(my_idx, src, WAVE);
                 const float c = __shfl(my_c, src, WAVE);
                 const float *p = a.in + (size_t)j * a.ld_in + cbase + l;
-                if (src < cnt) {
+                if (src < cnt && c != 0.f) {
 #pragma unroll
                     for (int q = 0; q < MAXC; q++)
                         if (cbase + l + q * L < a.dim) acc[q] += c * p[q * L];
@@ -257,7 +266,7 @@ static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
 
 static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in, float *out, int ld_out,
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
-                         uint64_t elem_offset, const uint8_t *keep_mask) {
+                         uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr) {
     if (!c || !g || !in || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (g->n_rows == 0) return 0;
     gcnhip_graph *gm = const_cast<gcnhip_graph *>(g);
@@ -276,6 +285,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.fuse = fuse; a.training = training; a.thr = dropout_threshold(p);
     a.scale = 1 / (1 - p);                                  // module.cpp:212
     a.seed = seed; a.elem_offset = elem_offset; a.d_epoch = d_epoch; a.keep_mask = keep_mask;
+    a.row_bits = row_bits;
     const int nt = g->n_tasks ? g->n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
@@ -321,6 +331,11 @@ extern "C" {
 int gcnhip_graphsum(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
                     float *out, int ld_out, int dim) {
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr);
+}
+
+int gcnhip_graphsum_rowmask(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
+                            float *out, int ld_out, int dim, const uint32_t *in_row_bits) {
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr, in_row_bits);
 }
 
 int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,

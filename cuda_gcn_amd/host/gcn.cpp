@@ -79,6 +79,16 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         for (int s = 1; s <= 3; s++) split_count[s] = (int)cnt[s];
     }
 
+    // training-split bit per padded node position: dZ is zero elsewhere, GraphSum's backward skips those rows
+    {
+        const size_t n_pos = world > 1 ? (size_t)world * part.rows_max : (size_t)N;
+        std::vector<uint32_t> bits(n_pos / 32 + 2, 0u);
+        for (int j = 0; j < N; j++)
+            if (data->split[j] == 1) { const size_t pj = world > 1 ? (size_t)part.padded(j) : (size_t)j; bits[pj >> 5] |= 1u << (pj & 31); }
+        d_train_bits = dev_upload(env.ctx, bits.data(), bits.size());
+        bwd_bits = d_train_bits;
+    }
+
     // ---- variables (numbering of gcn.cpp:21-54)
     variables.resize(7);
     for (auto &v : variables) v.reset(new HipVariable());
@@ -162,14 +172,14 @@ void HipGCN::build_modules() {
         modules.push_back(new HipReLU(&env, H1));
         modules.push_back(new HipDropout(&env, H1, p, KEY_HIDDEN_DROPOUT, hid_off, (flags & HIPGCN_HOST_MASKS) ? &env.keep_hidden : &no_mask));
         modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C));
-        modules.push_back(new HipGraphSum(&env, Z0, Z, graph, C));
+        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, true));
     } else {
         const float scale = 1 / (1 - p);
         modules.push_back(new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, p, nnz_off));
         modules.push_back(new HipGraphSum(&env, H0, H1, graph, H, p, hid_off));
         modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C, scale));
-        modules.push_back(new HipGraphSum(&env, Z0, Z, graph, C));
+        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
     }
 }
@@ -190,6 +200,7 @@ HipGCN::~HipGCN() {
     gcnhip_free(env.ctx, env.d_epoch);
     gcnhip_free(env.ctx, d_keep0);
     gcnhip_free(env.ctx, d_keep1);
+    gcnhip_free(env.ctx, d_train_bits);
     timers.reset();
     owned_comm.reset();
     gcnhip_ctx_destroy(env.ctx);

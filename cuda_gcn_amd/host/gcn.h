@@ -103,6 +103,8 @@ private:
     int32_t *d_result_i = nullptr;
     int32_t *d_truth[4] = {};                                  // per split code 1..3
     int32_t *cur_truth = nullptr;
+    uint32_t *d_train_bits = nullptr;                          // bit per (padded) node: in the training split
+    const uint32_t *bwd_bits = nullptr;
     int split_count[4] = {};
     int cur_count = 0;
     float *d_ring = nullptr;

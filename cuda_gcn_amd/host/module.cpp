@@ -80,7 +80,10 @@ void HipGraphSum::backward() {
     const float *src = out->full_grad ? out->full_grad : out->grad;
     env->timers->start(TMR_GRAPHSUM_BW);
     if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-    GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, out->ld, in->grad, in->ld, dim));
+    if (bwd_row_bits && *bwd_row_bits)
+        GCNHIP_CHECK(gcnhip_graphsum_rowmask(env->ctx, graph, src, out->ld, in->grad, in->ld, dim, *bwd_row_bits));
+    else
+        GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, out->ld, in->grad, in->ld, dim));
     if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
     env->timers->stop(TMR_GRAPHSUM_BW);
 }

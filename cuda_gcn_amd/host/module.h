@@ -70,8 +70,9 @@ class HipGraphSum : public Module {
     int dim;
     float fused_relu_dropout;       // >= 0: ReLU (+ dropout with this p when training) in the store epilogue
     uint64_t elem_offset;           // global element index of this rank's first output element
-    timer_instance fw_extra;
 public:
+    // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
+    const uint32_t *const *bwd_row_bits = nullptr;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
     void forward(bool) override;

@@ -105,14 +105,20 @@ class Device:
         return Feat(self, indptr, indices, values, n_cols)
 
     # ---- ops (numpy in, numpy out)
-    def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None):
+    def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None, row_nonzero=None):
         x = np.asarray(x, np.float32)
         dim = x.shape[1]
         ld_in = ld_in or dim
         ld_out = ld_out or dim
         xin = self.padded(x, ld_in)
         out = self.buf(np.full((g.n_rows, ld_out), np.nan, np.float32))
-        _ck(self.lib, self.lib.gcnhip_graphsum(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim), "gcnhip_graphsum")
+        if row_nonzero is None:
+            _ck(self.lib, self.lib.gcnhip_graphsum(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim), "gcnhip_graphsum")
+        else:
+            bits = np.packbits(np.asarray(row_nonzero, bool), bitorder="little")
+            bits = np.concatenate([bits, np.zeros((-bits.size) % 4 + 4, np.uint8)]).view(np.uint32)
+            bb = self.buf(bits)
+            _ck(self.lib, self.lib.gcnhip_graphsum_rowmask(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr), "gcnhip_graphsum_rowmask")
         return out.download()[:, :dim]
 
     def graphsum_relu_dropout(self, g, x, training, p, seed=0, epoch=0, elem_offset=0, keep_mask=None, ld=None):

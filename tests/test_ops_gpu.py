@@ -143,6 +143,23 @@ def test_graphsum_golden(dev, mods, g, dim):
     gr.free()
 
 
+@pytest.mark.parametrize("dim,ld", [(41, 48), (41, 41), (128, 128), (7, 8)])
+def test_graphsum_rowmask(dev, oracle, dim, ld):
+    """rows promised to be zero are not read: same result as the oracle on the zeroed input, even
+    when those rows hold NaN on the device"""
+    gp, gi = hub_graph()
+    n = gp.size - 1
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    nz = rng.random(n) < 0.6
+    xz = np.where(nz[:, None], x, 0).astype(np.float32)
+    xn = np.where(nz[:, None], x, np.nan).astype(np.float32)
+    g = dev.graph(gp, gi)
+    got = dev.graphsum(g, xn, ld_in=ld, ld_out=ld, row_nonzero=nz)
+    close_mag(got, oracle.graphsum(gp, gi, xz, dim), oracle.graphsum(gp, gi, np.abs(xz), dim))
+    g.free()
+
+
 def test_graphsum_nan_isolation(dev, oracle):
     """padding lanes must not read row 0: an Inf in row 0 may only reach its neighbours"""
     gp, gi = hub_graph(400, 50, 1)
