@@ -130,6 +130,15 @@ def main():
             breakdown[name] = round(1e3 * s / args.steps, 4)      # ms per epoch
     out = None
     if rank == 0:
+        # fabric traffic per launch of the same kernel from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be collected live here)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_graphsum_pmc.json")
+        if world == 1 and args.dataset == "reddit-syn" and args.hidden == 128 and os.path.exists(pmc):
+            k = json.load(open(pmc)).get("graphsum_vec_kernel<8>", {})
+            if "traffic_bytes_per_launch" in k:
+                traffic = k["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r01_graphsum_pmc.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, rocprofv3 --pmc in separate passes"
         bytes_per_launch = b_gs(info["local_rows"], info["local_edges"], args.hidden)
         avg_s = s_wide / max(n_wide, 1)
         achieved = bytes_per_launch / avg_s / 1e9
@@ -146,7 +155,7 @@ def main():
                        "train_nodes": n_lab},
             "roofline": {"bound": "hbm", "kernel": f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s,
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s,
                          "launches": n_wide,
                          "note": "algorithmic gather-model bytes B_gs(d); the 119 MB feature table is Infinity-Cache "
                                  "resident, so achieved may exceed HBM traffic (see DESIGN.md, profiles/)"},

@@ -34,6 +34,26 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "reddit-syn"
     h = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     t0 = time.time()
+    if name.startswith("rmat-") and len(sys.argv) > 3 and sys.argv[3] == "graphsum":
+        # graph only (the feature matrix of an R-MAT stress graph is synthetic anyway)
+        scale = int(name.split("-")[1])
+        lo, hi = datagen._rmat_edges(np.random.default_rng(datagen.DEFAULT_SEED), scale, 16)
+        gp, gi = datagen.csr_with_self_loops(lo, hi, 1 << scale)
+        del lo, hi
+        N = 1 << scale
+        dev = Device(0); lib = dev.lib
+        g = dev.graph(gp, gi)
+        deg = np.diff(gp)
+        print(f"rmat scale {scale}: N={N} nnzA={gi.size} max_deg={deg.max()} built in {time.time() - t0:.1f}s", flush=True)
+        rng = np.random.default_rng(0)
+        for dim in (128, 256, 48):
+            x = dev.buf(rng.standard_normal((N, dim), dtype=np.float32)); o = dev.buf((N, dim))
+            d_eff = 41 if dim == 48 else dim
+            ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, dim, o.ptr, dim, d_eff), "gs"), iters=10)
+            bgs = 4 * (N + 1) + 4 * gi.size + 4 * gi.size * d_eff + 4 * N * d_eff
+            print(f"graphsum d={d_eff} ld={dim} table={N * dim * 4 / 2**20:.0f} MiB: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
+            x.free(); o.free()
+        return
     ds = datagen.make_dataset(name)
     print("dataset", name, "built in %.1fs" % (time.time() - t0), flush=True)
     N, F, Cc = ds["num_nodes"], ds["input_dim"], ds["output_dim"]
