@@ -94,6 +94,29 @@ int gcnhip_d2d_async(gcnhip_ctx *c, void *dst, const void *src, size_t bytes) {
     return 0;
 }
 
+int gcnhip_capture_begin(gcnhip_ctx *c) {
+    GCNHIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+int gcnhip_capture_end(gcnhip_ctx *c, void **graph_exec) {
+    hipGraph_t graph = nullptr;
+    GCNHIP_TRY(hipStreamEndCapture(c->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec = (void *)exec;
+    return 0;
+}
+int gcnhip_graph_launch(gcnhip_ctx *c, void *graph_exec) {
+    GCNHIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, c->stream));
+    return 0;
+}
+int gcnhip_graph_exec_destroy(void *graph_exec) {
+    if (graph_exec) GCNHIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
 int gcnhip_event_create(void **ev) { GCNHIP_TRY(hipEventCreate((hipEvent_t *)ev)); return 0; }
 int gcnhip_event_destroy(void *ev) { GCNHIP_TRY(hipEventDestroy((hipEvent_t)ev)); return 0; }
 int gcnhip_event_record(gcnhip_ctx *c, void *ev) { GCNHIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream)); return 0; }

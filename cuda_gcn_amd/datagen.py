@@ -37,11 +37,23 @@ def _unique_undirected(u, v, n):
     return (key // n).astype(np.int64), (key % n).astype(np.int64)
 
 
-def _sample_edges(rng, n, m, weights=None):
-    """m distinct undirected edges; endpoints uniform or ∝ weights (Chung-Lu)"""
+def _sample_edges(rng, n, m, weights=None, label=None, homophily=0.0):
+    """m distinct undirected edges; endpoints uniform or ∝ weights (Chung-Lu).  With `label`
+    and homophily h, a fraction h of the edges picks its second endpoint inside the first
+    endpoint's class (still ∝ weights), which gives the graph the community structure a GCN
+    can learn from."""
     if weights is not None:
         cdf = np.cumsum(weights, dtype=np.float64)
         cdf /= cdf[-1]
+    if label is not None and homophily > 0:
+        order = np.argsort(label, kind="stable")
+        wl = weights[order] if weights is not None else np.ones(n)
+        ccdf = np.cumsum(wl, dtype=np.float64)
+        n_cls = int(label.max()) + 1
+        first = np.searchsorted(label[order], np.arange(n_cls), side="left")
+        last = np.searchsorted(label[order], np.arange(n_cls), side="right")
+        c_lo = np.where(first > 0, ccdf[np.maximum(first, 1) - 1], 0.0)
+        c_hi = ccdf[last - 1]
     lo = np.empty(0, np.int64)
     hi = np.empty(0, np.int64)
     while lo.size < m:
@@ -52,6 +64,11 @@ def _sample_edges(rng, n, m, weights=None):
         else:
             u = np.searchsorted(cdf, rng.random(need), side="right").clip(0, n - 1)
             v = np.searchsorted(cdf, rng.random(need), side="right").clip(0, n - 1)
+            if label is not None and homophily > 0:
+                intra = rng.random(need) < homophily
+                cu = label[u[intra]]
+                r = c_lo[cu] + rng.random(cu.size) * (c_hi[cu] - c_lo[cu])
+                v[intra] = order[np.searchsorted(ccdf, r, side="right").clip(0, n - 1)]
         a, b = _unique_undirected(np.concatenate([lo, np.minimum(u, v)]),
                                   np.concatenate([hi, np.maximum(u, v)]), n)
         lo, hi = a, b
@@ -108,18 +125,23 @@ def make_dataset(name: str, seed: int = DEFAULT_SEED, rows: slice | None = None)
     else:
         N, F, C, M, nnz_row, n_train, n_val, n_test = SHAPES[name]
         if name.startswith("reddit"):
-            # Chung-Lu, power-law expected degrees (exponent ~2.3), capped
+            # Chung-Lu, power-law expected degrees (exponent ~2.3), capped; 60 % of the edges stay
+            # inside a class (Reddit communities are posts of one subreddit = one label)
             w = (np.arange(1, N + 1, dtype=np.float64)) ** (-1.0 / 1.3)
             rng.shuffle(w)
             cap = 2.0e4 * w.sum() / (2.0 * M)
             w = np.minimum(w, cap)
-            lo, hi = _sample_edges(rng, N, M, w)
+            pre_label = np.random.default_rng(seed + 1).integers(0, C, N).astype(np.int32)
+            pre_label[:C] = np.arange(C, dtype=np.int32)
+            lo, hi = _sample_edges(rng, N, M, w, pre_label, 0.6)
         else:
             lo, hi = _sample_edges(rng, N, M)
     g_indptr, g_indices = csr_with_self_loops(lo, hi, N)
 
     label = rng.integers(0, C, N).astype(np.int32)
     label[:C] = np.arange(C, dtype=np.int32)       # every class occurs (loader: output_dim = max label + 1)
+    if name.startswith("reddit"):
+        label = pre_label
 
     if nnz_row == 0:
         # dense standardised features with a class-dependent shift (learnable signal)

@@ -191,6 +191,7 @@ HipGCN::~HipGCN() {
     if (variables.size() == 7) { variables[2]->grad = nullptr; variables[5]->grad = nullptr; }
     variables.clear();
     optimizer.reset();
+    if (epoch_graph) gcnhip_graph_exec_destroy(epoch_graph);
     if (graph) gcnhip_graph_destroy(env.ctx, graph);
     if (feat) gcnhip_feat_destroy(env.ctx, feat);
     for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_truth[s]);
@@ -290,10 +291,32 @@ std::pair<float, float> HipGCN::eval(int s) {
 
 void HipGCN::run_epochs(int n, float *trace) {
     int done = 0;
+    // One epoch (train + validation) is a fixed launch sequence whose epoch-dependent inputs all live in
+    // device memory, so it is captured once into a hipGraph and replayed (single GPU, device RNG, no
+    // per-op timers).  The first epoch runs eagerly so every scratch buffer has its final size.
+    const bool graph_ok = env.comm->size() == 1 && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_TIMERS | HIPGCN_NO_GRAPH));
     while (done < n) {
         const int chunk = std::min(n - done, RING);
         const long first = epochs_done;
-        for (int i = 0; i < chunk; i++) { train_epoch_async(); eval_async(2); }
+        for (int i = 0; i < chunk; i++) {
+            if (graph_ok && epochs_done >= 1 && optimizer->can_replay(1)) {
+                if (!epoch_graph) {
+                    GCNHIP_CHECK(gcnhip_capture_begin(env.ctx));
+                    train_epoch_async();
+                    eval_async(2);
+                    GCNHIP_CHECK(gcnhip_capture_end(env.ctx, &epoch_graph));
+                    // the capture only recorded: undo its host-side bookkeeping, then run it for real
+                    epochs_done--;
+                    optimizer->note_replayed(-1);
+                }
+                GCNHIP_CHECK(gcnhip_graph_launch(env.ctx, epoch_graph));
+                epochs_done++;
+                optimizer->note_replayed(1);
+            } else {
+                train_epoch_async();
+                eval_async(2);
+            }
+        }
         sync();
         if (trace) {
             std::vector<float> ring((size_t)RING * 32);

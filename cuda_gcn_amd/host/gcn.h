@@ -34,6 +34,7 @@ enum HipGCNFlags {
     HIPGCN_MODULAR = 1,       // one module per reference module instead of the fused epilogues
     HIPGCN_HOST_MASKS = 2,    // parity mode: dropout decisions from the reference's host RNG stream
     HIPGCN_TIMERS = 4,        // record device-event timers per op
+    HIPGCN_NO_GRAPH = 8,      // never replay epochs from a captured hipGraph
 };
 
 struct HipGCNOptions {
@@ -112,6 +113,7 @@ private:
     uint8_t *d_keep0 = nullptr, *d_keep1 = nullptr;
     std::vector<uint8_t> h_keep0, h_keep1;
     long epochs_done = 0;                                      // host mirror of *d_epoch + 1
+    void *epoch_graph = nullptr;                               // captured train_epoch + eval(2)
 
     void build_modules();
     void set_truth(int current_split);

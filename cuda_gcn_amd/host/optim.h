@@ -26,4 +26,7 @@ public:
     void init(HipEnv *env, std::vector<std::pair<HipVariable *, bool>> vars, AdamParams params, int max_steps);
     static float step_size(const AdamParams &p, int step_count);    // optim.cpp:26
     void step();                            // uses the device epoch word as step index when a table exists
+    // graph replay: n steps happened on the device; true if all of them were inside the table
+    bool can_replay(int n) const { return step_count + n <= table_len; }
+    void note_replayed(int n) { step_count += n; }
 };

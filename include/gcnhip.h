@@ -228,6 +228,16 @@ int gcnhip_metrics_record(gcnhip_ctx *ctx, float *d_ring, int capacity, int slot
                           const uint32_t *d_epoch, const float *d_result, const int32_t *d_result_i,
                           const float *d_sumsq);
 
+/* ---- hipGraph capture of a launch sequence (small graphs are launch-bound: ~25 kernels of a few
+ *      microseconds per epoch).  Everything the ops read that changes from epoch to epoch lives in
+ *      device memory (epoch word, step-size table, metrics ring), so one captured epoch replays
+ *      correctly any number of times.  Ops must have run once eagerly before (scratch is sized on
+ *      first use). */
+int gcnhip_capture_begin(gcnhip_ctx *ctx);
+int gcnhip_capture_end(gcnhip_ctx *ctx, void **graph_exec);
+int gcnhip_graph_launch(gcnhip_ctx *ctx, void *graph_exec);
+int gcnhip_graph_exec_destroy(void *graph_exec);
+
 /* ---- timing (replaces the host chrono timers that the CUDA path leaves
  *      unsynchronised) ---------------------------------------------- */
 int gcnhip_event_create(void **ev);

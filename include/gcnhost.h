@@ -32,7 +32,8 @@ typedef struct {
 enum {
     GCNHOST_MODULAR = 1,      /* one module per reference module (no fused epilogues) */
     GCNHOST_HOST_MASKS = 2,   /* dropout decisions replayed from the reference's host RNG (parity runs) */
-    GCNHOST_TIMERS = 4        /* per-op device-event timers */
+    GCNHOST_TIMERS = 4,       /* per-op device-event timers */
+    GCNHOST_NO_GRAPH = 8      /* run_epochs never replays a captured hipGraph */
 };
 
 #define GCNHOST_NCCL_ID_BYTES 128

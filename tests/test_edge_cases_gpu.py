@@ -1,0 +1,79 @@
+"""Edge cases of the training path on the GPU against the CPU oracle: odd widths
+(scalar-load kernels), many classes, wide hidden layers, isolated nodes, a single
+labelled node per split, heavy dropout."""
+import numpy as np
+import pytest
+
+from cuda_gcn_amd import datagen
+from tests.test_model_gpu import check_trace, oracle_trace
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(N, F, C, M, nnz_row, seed, dense=False, isolated=0):
+    rng = np.random.default_rng(seed)
+    lo, hi = datagen._sample_edges(rng, N - isolated, M)
+    gp, gi = datagen.csr_with_self_loops(lo, hi, N)          # the last `isolated` nodes keep only the self loop
+    label = rng.integers(0, C, N).astype(np.int32)
+    label[:C] = np.arange(C)
+    if dense:
+        x = rng.standard_normal((N, F)).astype(np.float32)
+        fp = (np.arange(N + 1) * F).astype(np.int32)
+        fi = np.tile(np.arange(F, dtype=np.int32), N)
+        fv = x.reshape(-1)
+    else:
+        cols = np.sort(np.stack([rng.choice(F, nnz_row, replace=False) for _ in range(N)]), axis=1)
+        cols[0, -1] = F - 1
+        fp = (np.arange(N + 1) * nnz_row).astype(np.int32)
+        fi = cols.reshape(-1).astype(np.int32)
+        fv = rng.standard_normal(N * nnz_row).astype(np.float32)
+    split = rng.integers(1, 4, N).astype(np.int32)
+    return dict(num_nodes=N, input_dim=F, output_dim=C, g_indptr=gp, g_indices=gi, f_indptr=fp, f_indices=fi,
+                f_val=fv, split=split, label=label)
+
+
+@pytest.mark.parametrize("N,F,C,hidden,dense,isolated", [
+    (300, 40, 3, 10, False, 0),       # hidden % 4 != 0: every matrix takes the padded-ld path
+    (257, 33, 5, 6, True, 7),         # dense X at odd sizes (16x16x4 MFMA path), isolated nodes
+    (500, 64, 100, 64, False, 0),     # 100 classes: two register chunks in the loss kernel
+    (400, 50, 41, 256, False, 3),     # wide hidden layer: 8 XCD slices, LDS-resident 256-row operand
+    (130, 70, 7, 128, True, 0),       # dense X with hidden 128 (128x128 MFMA tiles) on a tiny graph
+])
+def test_odd_shapes_vs_oracle(oracle, N, F, C, hidden, dense, isolated):
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+    ds = synth(N, F, C, 4 * N, 5, seed=N + hidden, dense=dense, isolated=isolated)
+    for dropout, flags in ((0.0, 0), (0.5, HOST_MASKS)):
+        want, _, om = oracle_trace(oracle, ds, 2, 12, hidden_dim=hidden, dropout=dropout)
+        m = HipGCNModel(ds, seed=2, flags=flags, hidden_dim=hidden, dropout=dropout, epochs=12)
+        got = np.array([m.train_epoch() + m.eval(2) for _ in range(12)], np.float32)
+        check_trace(got, want, ds)
+        m.close(); om.close()
+
+
+def test_single_labelled_node_and_heavy_dropout(oracle):
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+    ds = synth(120, 30, 4, 300, 4, seed=9)
+    ds["split"][:] = 0
+    ds["split"][5] = 1
+    ds["split"][6] = 2
+    ds["split"][7] = 3
+    want, wtest, om = oracle_trace(oracle, ds, 3, 10, hidden_dim=16, dropout=0.9)
+    m = HipGCNModel(ds, seed=3, flags=HOST_MASKS, hidden_dim=16, dropout=0.9, epochs=10)
+    got = np.array([m.train_epoch() + m.eval(2) for _ in range(10)], np.float32)
+    assert np.abs(got[:, [0, 2]] - want[:, [0, 2]]).max() <= 2e-3
+    assert np.array_equal(got[:, [1, 3]], want[:, [1, 3]])          # 0 or 1 with a single row
+    m.close(); om.close()
+
+
+def test_empty_split_gives_nan_like_reference(oracle):
+    """count == 0 -> 0/0 = NaN loss, as the reference (module.cpp:154)"""
+    from cuda_gcn_amd.model import HipGCNModel
+    ds = synth(60, 20, 3, 100, 3, seed=1)
+    ds["split"][ds["split"] == 2] = 0
+    m = HipGCNModel(ds, seed=1, hidden_dim=8, dropout=0.0, epochs=2)
+    om = oracle.model(ds, seed_time=1, hidden_dim=8, dropout=0.0)
+    a, b = m.train_epoch(), om.train_epoch()
+    assert abs(a[0] - b[0]) <= 2e-4
+    va, vb = m.eval(2), om.eval(2)
+    assert np.isnan(va[0]) and np.isnan(vb[0])
+    m.close(); om.close()
