@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--dataset", default="reddit-syn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
+                    help="validation forward on a second stream (auto: only with more than one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +92,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)    # control plane; data plane is RCCL in libgcnhost
 
     from cuda_gcn_amd import datagen
-    from cuda_gcn_amd.model import HipGCNModel, TIMERS, nccl_unique_id
+    from cuda_gcn_amd.model import HipGCNModel, TIMERS, EVAL_LANE, NO_EVAL_LANE, nccl_unique_id
 
     def barrier():
         if world > 1:
@@ -104,7 +106,8 @@ def main():
         box = [nccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         nccl_id = box[0]
-    model = HipGCNModel(ds, seed=1, device=local_rank, flags=TIMERS, rank=rank, world=world, nccl_id=nccl_id,
+    lane_flag = {"auto": 0, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
+    model = HipGCNModel(ds, seed=1, device=local_rank, flags=TIMERS | lane_flag, rank=rank, world=world, nccl_id=nccl_id,
                         hidden_dim=args.hidden, dropout=0.5, epochs=args.steps + args.warmup)
     info = model.info()
 

@@ -113,6 +113,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_event_create": (I, [C.POINTER(P)]),
     "gcnhip_event_destroy": (I, [P]),
     "gcnhip_event_record": (I, [P, P]),
+    "gcnhip_stream_wait_event": (I, [P, P]),
     "gcnhip_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),
 }
 

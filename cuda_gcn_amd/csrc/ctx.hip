@@ -120,6 +120,10 @@ int gcnhip_graph_exec_destroy(void *graph_exec) {
 int gcnhip_event_create(void **ev) { GCNHIP_TRY(hipEventCreate((hipEvent_t *)ev)); return 0; }
 int gcnhip_event_destroy(void *ev) { GCNHIP_TRY(hipEventDestroy((hipEvent_t)ev)); return 0; }
 int gcnhip_event_record(gcnhip_ctx *c, void *ev) { GCNHIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream)); return 0; }
+int gcnhip_stream_wait_event(gcnhip_ctx *c, void *ev) {
+    GCNHIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));
+    return 0;
+}
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms) {
     GCNHIP_TRY(hipEventSynchronize((hipEvent_t)stop));
     GCNHIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

@@ -112,9 +112,9 @@ int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *ro
 int gcnhost_model_set_weights(gcnhost_model *m, const float *w1, const float *w2) { API_TRY({ m->gcn->set_weights(w1, w2); }) }
 int gcnhost_model_timer(gcnhost_model *m, int id, double *seconds, long *count) {
     if (id < 0 || id >= __NUM_TMR) { g_err = "bad timer id"; return -1; }
-    API_TRY({ *seconds = m->gcn->device_timers().total((timer_instance)id, count); })
+    API_TRY({ *seconds = m->gcn->timer_total((timer_instance)id, count); })
 }
-int gcnhost_model_timers_reset(gcnhost_model *m) { API_TRY({ m->gcn->device_timers().reset(); }) }
+int gcnhost_model_timers_reset(gcnhost_model *m) { API_TRY({ m->gcn->timers_reset(); }) }
 
 int gcnhost_dataset_load(gcnhost_dataset **out, const char *root, const char *name, gcnhost_params *p) {
     API_TRY({

@@ -35,10 +35,18 @@ struct RcclComm : Comm {
         ncclUniqueId u;
         memcpy(&u, id, sizeof u);
         NCCL_CHECK(ncclCommInitRank(&comm, world, u, rank));
+        alloc_scratch();
+    }
+    RcclComm(gcnhip_ctx *c, int rank, int world, ncclComm_t parent) : ctx(c), r(rank), w(world) {
+        NCCL_CHECK(ncclCommSplit(parent, 0, rank, &comm, nullptr));
+        alloc_scratch();
+    }
+    void alloc_scratch() {
         void *p;
         GCNHIP_CHECK(gcnhip_malloc(ctx, &p, 64 * sizeof(float)));
         scratch = (float *)p;
     }
+    Comm *clone_for(gcnhip_ctx *other) override { return new RcclComm(other, r, w, comm); }
     ~RcclComm() override {
         gcnhip_ctx_sync(ctx);
         ncclCommDestroy(comm);
@@ -92,6 +100,7 @@ struct HostComm : Comm {
         GCNHIP_CHECK(gcnhip_h2d(ctx, buf, stage.data(), n * sizeof(float)));
     }
     void allreduce_sum_host(double *vals, int n) override { ar(user, vals, (size_t)n); }
+    Comm *clone_for(gcnhip_ctx *other) override { return new HostComm(other, r, w, ag, ar, user); }
 };
 
 }  // namespace

@@ -16,6 +16,9 @@ struct Comm {
     virtual void allgather_rows(float *base, size_t block_elems) = 0;
     virtual void allreduce_sum(float *buf, size_t n) = 0;
     virtual void allreduce_sum_host(double *vals, int n) = 0;   // init-time scalars (synchronises)
+    // a second communicator over the same ranks whose collectives run on another context's stream
+    // (the validation lane); every rank must call it at the same point
+    virtual Comm *clone_for(gcnhip_ctx *ctx) = 0;
 };
 
 // world == 1: nothing to exchange
@@ -25,6 +28,7 @@ struct SelfComm : Comm {
     void allgather_rows(float *, size_t) override {}
     void allreduce_sum(float *, size_t) override {}
     void allreduce_sum_host(double *, int) override {}
+    Comm *clone_for(gcnhip_ctx *) override { return new SelfComm(); }
 };
 
 // RCCL (librccl; "nccl" API) on the context's stream

@@ -18,6 +18,7 @@ T *dev_upload(gcnhip_ctx *ctx, const T *h, size_t n) {
 }  // namespace
 
 HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : params(p), data(input_data), flags(opt.flags) {
+    device_ = opt.device;
     GCNHIP_CHECK(gcnhip_ctx_create(&env.ctx, opt.device, nullptr));
     timers.reset(new DeviceTimers(env.ctx));
     timers->enabled = (flags & HIPGCN_TIMERS) != 0;
@@ -147,6 +148,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         env.keep_hidden = d_keep1;
     }
     build_modules();
+    if (!(flags & HIPGCN_NO_EVAL_LANE) && ((flags & HIPGCN_EVAL_LANE) || world > 1)) build_eval_lane();
     AdamParams ap = AdamParams::get_default();
     ap.lr = params.learning_rate;
     ap.weight_decay = params.weight_decay;
@@ -184,8 +186,65 @@ void HipGCN::build_modules() {
     }
 }
 
+void HipGCN::build_eval_lane() {
+    const int world = env.comm->size(), rank = env.comm->rank();
+    const int N = n_local, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
+    lane.reset(new EvalLane());
+    EvalLane &L = *lane;
+    GCNHIP_CHECK(gcnhip_ctx_create(&L.env.ctx, /*device of the main context*/ device_, nullptr));
+    L.timers.reset(new DeviceTimers(L.env.ctx));
+    L.timers->enabled = timers->enabled;
+    L.env.timers = L.timers.get();
+    L.comm.reset(env.comm->clone_for(L.env.ctx));
+    L.env.comm = L.comm.get();
+    L.env.seed = env.seed;
+    void *q;
+    GCNHIP_CHECK(gcnhip_malloc(L.env.ctx, &q, sizeof(uint32_t)));
+    L.env.d_epoch = (uint32_t *)q;
+    GCNHIP_CHECK(gcnhip_memset_async(L.env.ctx, q, 0xFF, sizeof(uint32_t)));
+    GCNHIP_CHECK(gcnhip_malloc(L.env.ctx, &q, 4 * sizeof(float))); L.d_result = (float *)q;
+    GCNHIP_CHECK(gcnhip_malloc(L.env.ctx, &q, 2 * sizeof(int32_t))); L.d_result_i = (int32_t *)q;
+    // same adjacency, own scratch for split rows
+    const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
+    if (world > 1) {
+        const LocalGraph lg = build_local_graph(gp.data(), gi.data(), params.num_nodes, part, rank);
+        GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
+    } else {
+        GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, gp.data(), gi.data(), params.num_nodes, params.num_nodes, nullptr));
+    }
+    const int rm = part.rows_max;
+    L.H0.reset(new HipVariable()); L.H1.reset(new HipVariable()); L.Z0.reset(new HipVariable()); L.Z.reset(new HipVariable());
+    L.H0->alloc(L.env.ctx, N, H, false, true, false, world, rank, rm);
+    L.H1->alloc(L.env.ctx, N, H, false);
+    L.Z0->alloc(L.env.ctx, N, C, false, true, false, world, rank, rm);
+    L.Z->alloc(L.env.ctx, N, C, false);
+    const uint64_t nnz_off = (uint64_t)data->feature_index.indptr[part.start[rank]];
+    eval_vals = gcnhip_feat_values(feat);
+    L.modules.push_back(new HipSparseMatmul(&L.env, &eval_vals, variables[2].get(), L.H0.get(), feat, N, F, H, 0.f, nnz_off));
+    L.modules.push_back(new HipGraphSum(&L.env, L.H0.get(), L.H1.get(), L.graph, H, 0.f, 0));      // ReLU epilogue, no dropout in eval
+    L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
+    L.modules.push_back(new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C));
+    L.modules.push_back(new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false));
+    GCNHIP_CHECK(gcnhip_event_create(&L.ev_weights));
+    GCNHIP_CHECK(gcnhip_event_create(&L.ev_done));
+    GCNHIP_CHECK(gcnhip_ctx_sync(L.env.ctx));
+}
+
 HipGCN::~HipGCN() {
     if (env.ctx) gcnhip_ctx_sync(env.ctx);
+    if (lane) {
+        EvalLane &L = *lane;
+        gcnhip_ctx_sync(L.env.ctx);
+        for (auto m : L.modules) delete m;
+        L.H0.reset(); L.H1.reset(); L.Z0.reset(); L.Z.reset();
+        if (L.graph) gcnhip_graph_destroy(L.env.ctx, L.graph);
+        gcnhip_free(L.env.ctx, L.d_result); gcnhip_free(L.env.ctx, L.d_result_i); gcnhip_free(L.env.ctx, L.env.d_epoch);
+        gcnhip_event_destroy(L.ev_weights); gcnhip_event_destroy(L.ev_done);
+        L.timers.reset();
+        L.comm.reset();
+        gcnhip_ctx_destroy(L.env.ctx);
+        lane.reset();
+    }
     for (auto m : modules) delete m;
     // W1/W2 grads live in gradbuf
     if (variables.size() == 7) { variables[2]->grad = nullptr; variables[5]->grad = nullptr; }
@@ -208,7 +267,22 @@ HipGCN::~HipGCN() {
     env.ctx = nullptr;
 }
 
-void HipGCN::sync() { GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx)); }
+void HipGCN::sync() {
+    GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
+    if (lane) GCNHIP_CHECK(gcnhip_ctx_sync(lane->env.ctx));
+}
+
+double HipGCN::timer_total(timer_instance t, long *count) {
+    long c0 = 0, c1 = 0;
+    double s = timers->total(t, &c0);
+    if (lane) s += lane->timers->total(t, &c1);
+    if (count) *count = c0 + c1;
+    return s;
+}
+void HipGCN::timers_reset() {
+    timers->reset();
+    if (lane) lane->timers->reset();
+}
 
 void HipGCN::set_truth(int s) {                 // gcn.cpp:78-81: here a pointer switch
     cur_truth = d_truth[s];
@@ -253,7 +327,30 @@ void HipGCN::train_epoch_async() {              // gcn.cpp:107-118
     }
     // loss/accuracy of this forward + the L2 term of the weights it used, then the update
     GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, 0, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
+    if (lane && lane->pending) {                    // the previous validation pass still reads W1, W2 and the L2 term
+        GCNHIP_CHECK(gcnhip_stream_wait_event(env.ctx, lane->ev_done));
+        lane->pending = false;
+    }
     optimizer->step();
+    if (lane) GCNHIP_CHECK(gcnhip_event_record(env.ctx, lane->ev_weights));
+}
+
+// validation forward of the epoch that just finished, on the second stream
+void HipGCN::eval_on_lane(int s) {
+    EvalLane &L = *lane;
+    GCNHIP_CHECK(gcnhip_stream_wait_event(L.env.ctx, L.ev_weights));
+    GCNHIP_CHECK(gcnhip_counter_add(L.env.ctx, L.env.d_epoch, 1u));
+    L.truth = d_truth[s];
+    L.count = split_count[s];
+    for (auto m : L.modules) m->forward(false);
+    if (L.env.comm->size() > 1) {
+        L.timers->start(TMR_COMM);
+        L.env.comm->allreduce_sum(L.d_result, 4);
+        L.timers->stop(TMR_COMM);
+    }
+    GCNHIP_CHECK(gcnhip_metrics_record(L.env.ctx, d_ring, RING, s == 2 ? 1 : 2, L.env.d_epoch, L.d_result, nullptr, optimizer->d_sumsq));
+    GCNHIP_CHECK(gcnhip_event_record(L.env.ctx, L.ev_done));
+    L.pending = true;
 }
 
 void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
@@ -271,6 +368,7 @@ void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
 
 std::pair<float, float> HipGCN::read_metrics(long epoch_index, int slot) {
     float row[8];
+    if (lane) GCNHIP_CHECK(gcnhip_ctx_sync(lane->env.ctx));
     const uint32_t e = (uint32_t)epoch_index;   // epoch_index == -1 (eval before any training) wraps like the device word
     GCNHIP_CHECK(gcnhip_d2h(env.ctx, row, d_ring + ((size_t)(e % RING) * 4 + slot) * 8, sizeof row));
     const float loss = row[0] / (int)row[1];                                    // module.cpp:154
@@ -294,7 +392,7 @@ void HipGCN::run_epochs(int n, float *trace) {
     // One epoch (train + validation) is a fixed launch sequence whose epoch-dependent inputs all live in
     // device memory, so it is captured once into a hipGraph and replayed (single GPU, device RNG, no
     // per-op timers).  The first epoch runs eagerly so every scratch buffer has its final size.
-    const bool graph_ok = env.comm->size() == 1 && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_TIMERS | HIPGCN_NO_GRAPH));
+    const bool graph_ok = env.comm->size() == 1 && !lane && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_TIMERS | HIPGCN_NO_GRAPH));
     while (done < n) {
         const int chunk = std::min(n - done, RING);
         const long first = epochs_done;
@@ -314,7 +412,7 @@ void HipGCN::run_epochs(int n, float *trace) {
                 optimizer->note_replayed(1);
             } else {
                 train_epoch_async();
-                eval_async(2);
+                if (lane) eval_on_lane(2); else eval_async(2);
             }
         }
         sync();
@@ -343,7 +441,7 @@ void HipGCN::run() {                            // gcn.cpp:130-158
         float train_loss, train_acc, val_loss, val_acc;
         auto t0 = std::chrono::high_resolution_clock::now();
         train_epoch_async();
-        eval_async(2);
+        if (lane) eval_on_lane(2); else eval_async(2);
         std::tie(train_loss, train_acc) = read_metrics(epochs_done - 1, 0);     // one synchronisation per epoch
         std::tie(val_loss, val_acc) = read_metrics(epochs_done - 1, 1);
         const float dt = std::chrono::duration_cast<std::chrono::duration<float>>(std::chrono::high_resolution_clock::now() - t0).count();

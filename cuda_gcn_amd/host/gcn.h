@@ -35,6 +35,8 @@ enum HipGCNFlags {
     HIPGCN_HOST_MASKS = 2,    // parity mode: dropout decisions from the reference's host RNG stream
     HIPGCN_TIMERS = 4,        // record device-event timers per op
     HIPGCN_NO_GRAPH = 8,      // never replay epochs from a captured hipGraph
+    HIPGCN_EVAL_LANE = 16,    // validation forward on a second stream, overlapped with the next training epoch
+    HIPGCN_NO_EVAL_LANE = 32, // never (default: on when world > 1, where it hides the all-gathers)
 };
 
 struct HipGCNOptions {
@@ -77,6 +79,8 @@ public:
     void get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols);
     void set_weights(const float *w1, const float *w2);       // [F x h], [h x C] row-major
     DeviceTimers &device_timers() { return *timers; }
+    double timer_total(timer_instance t, long *count);        // both lanes
+    void timers_reset();
     long n_edges_local() const { return nnzA_local; }
 
 private:
@@ -88,6 +92,8 @@ private:
     int n_local = 0;
     long nnzA_local = 0;
     int flags = 0;
+    int device_ = 0;
+    const float *eval_vals = nullptr;
     HostRng rng;
 
     gcnhip_graph *graph = nullptr;
@@ -114,6 +120,28 @@ private:
     std::vector<uint8_t> h_keep0, h_keep1;
     long epochs_done = 0;                                      // host mirror of *d_epoch + 1
     void *epoch_graph = nullptr;                               // captured train_epoch + eval(2)
+
+    // Validation lane.  eval(e) reads only the weights Adam(e) wrote, and train(e+1) needs the same
+    // weights and nothing from eval(e): the two are independent until Adam(e+1).  With more than one GPU
+    // each of them alternates compute with an all-gather, so running eval(e) on its own stream /
+    // communicator / activation buffers lets one lane compute while the other communicates.
+    struct EvalLane {
+        HipEnv env;
+        std::unique_ptr<Comm> comm;
+        std::unique_ptr<DeviceTimers> timers;
+        gcnhip_graph *graph = nullptr;                         // own split-row scratch
+        std::unique_ptr<HipVariable> H0, H1, Z0, Z;
+        std::vector<Module *> modules;
+        float *d_result = nullptr;
+        int32_t *d_result_i = nullptr;
+        int32_t *truth = nullptr;
+        int count = 0;
+        void *ev_weights = nullptr, *ev_done = nullptr;        // Adam(e) -> eval(e);  eval(e) -> Adam(e+1)
+        bool pending = false;
+    };
+    std::unique_ptr<EvalLane> lane;
+    void build_eval_lane();
+    void eval_on_lane(int current_split);
 
     void build_modules();
     void set_truth(int current_split);

@@ -244,6 +244,8 @@ int gcnhip_event_create(void **ev);
 int gcnhip_event_destroy(void *ev);
 int gcnhip_event_record(gcnhip_ctx *ctx, void *ev);
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+/* make the context's stream wait (on the device) for work recorded before `ev` on another context's stream */
+int gcnhip_stream_wait_event(gcnhip_ctx *ctx, void *ev);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,9 @@ enum {
     GCNHOST_MODULAR = 1,      /* one module per reference module (no fused epilogues) */
     GCNHOST_HOST_MASKS = 2,   /* dropout decisions replayed from the reference's host RNG (parity runs) */
     GCNHOST_TIMERS = 4,       /* per-op device-event timers */
-    GCNHOST_NO_GRAPH = 8      /* run_epochs never replays a captured hipGraph */
+    GCNHOST_NO_GRAPH = 8,     /* run_epochs never replays a captured hipGraph */
+    GCNHOST_EVAL_LANE = 16,   /* validation forward on a second stream, overlapped with the next training epoch */
+    GCNHOST_NO_EVAL_LANE = 32 /* never (default: on when world > 1) */
 };
 
 #define GCNHOST_NCCL_ID_BYTES 128

@@ -79,7 +79,10 @@ def main():
                               hidden_dim=16, dropout=dropout, epochs=epochs)
         info = m.info()
         assert info["world"] == world and info["rank"] == rank
-        tr = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
+        if os.environ.get("MR_ASYNC") == "1":
+            tr = m.run_epochs(epochs)                 # training lane + overlapped validation lane
+        else:
+            tr = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
         test = m.eval(3)
         w1 = m.var(2)
         h1 = m.var(3)                                   # this rank's rows of H1

@@ -221,3 +221,17 @@ def test_rccl_selftest():
     lib = _lib.gcnhost()
     rc = lib.gcnhost_rccl_selftest(0)
     assert rc == 0, lib.gcnhost_last_error()
+
+
+def test_eval_lane_is_bit_identical():
+    """validation on a second stream, overlapped with the next training epoch: same numbers as the
+    sequential schedule (the lane only reorders independent work), eager and via run()"""
+    from cuda_gcn_amd.model import HipGCNModel, EVAL_LANE, NO_GRAPH
+    ds = datagen.make_dataset("pubmed-syn")
+    a = HipGCNModel(ds, seed=6, flags=NO_GRAPH, hidden_dim=16, dropout=0.5, epochs=30)
+    b = HipGCNModel(ds, seed=6, flags=EVAL_LANE, hidden_dim=16, dropout=0.5, epochs=30)
+    ta, tb = a.run_epochs(30), b.run_epochs(30)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert a.eval(3) == b.eval(3)
+    assert np.array_equal(a.var(2), b.var(2))
+    a.close(); b.close()

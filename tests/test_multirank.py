@@ -27,12 +27,12 @@ def free_port():
     return p
 
 
-def launch(world, args, timeout=600):
+def launch(world, args, timeout=600, extra_env=None):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, WORKER] + [str(a) for a in args], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -57,14 +57,15 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world,dropout", [("cora-syn", 2, 0.0), ("cora-syn", 2, 0.5), ("tiny-syn", 3, 0.5), ("pubmed-syn", 2, 0.5)])
-def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout):
+@pytest.mark.parametrize("name,world,dropout,run_async", [("cora-syn", 2, 0.0, 0), ("cora-syn", 2, 0.5, 0), ("tiny-syn", 3, 0.5, 1),
+                                                          ("pubmed-syn", 2, 0.5, 1)])
+def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async):
     from cuda_gcn_amd import datagen
     from cuda_gcn_amd.model import HipGCNModel
     epochs = 12
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "mr.npz")
-        launch(world, ["gpu", name, out, epochs, 0, dropout])
+        launch(world, ["gpu", name, out, epochs, 0, dropout], extra_env={"MR_ASYNC": str(run_async)})
         got = np.load(out)
     ds = datagen.make_dataset(name)
     m = HipGCNModel(ds, seed=4, hidden_dim=16, dropout=dropout, epochs=epochs)
