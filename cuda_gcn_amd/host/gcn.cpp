@@ -61,6 +61,16 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &feat, lp.data(), fi.empty() ? nullptr : fi.data() + f0,
                                         data->feature_value.data() + f0, n_local, F));
     }
+    replicate_l1 = world > 1 && !(flags & (HIPGCN_NO_REPLICATE_L1 | HIPGCN_MODULAR));
+    if (replicate_l1) {
+        GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &feat_full, fp.data(), fi.empty() ? nullptr : fi.data(),
+                                        data->feature_value.data(), N, F));
+        full_vals = gcnhip_feat_values(feat_full);
+        std::vector<int> lp(n_local + 1), deg(N);
+        for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
+        for (int j = 0; j < N; j++) deg[j] = gp[j + 1] - gp[j];
+        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data()));
+    }
     // truth per split, once (the reference rebuilds and re-uploads it per call: cuda_gcn.cu:85-97)
     {
         int32_t *d_split = dev_upload(env.ctx, data->split.data() + r0, (size_t)n_local);
@@ -102,7 +112,8 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     } else {
         input_vals = gcnhip_feat_values(feat);
     }
-    variables[1]->alloc(env.ctx, n_local, H, true, true, false, world, rank, rm);    // H0: data gathered
+    if (replicate_l1) variables[1]->alloc_replicated(env.ctx, N, n_local, r0, H, true);   // H0: every row computed here
+    else variables[1]->alloc(env.ctx, n_local, H, true, true, false, world, rank, rm);    // H0: data gathered
     variables[3]->alloc(env.ctx, n_local, H, true, false, true, world, rank, rm);    // H1: grad gathered
     variables[4]->alloc(env.ctx, n_local, C, true, true, false, world, rank, rm);    // Z0: data gathered
     variables[6]->alloc(env.ctx, n_local, C, true, false, true, world, rank, rm);    // Z : grad gathered
@@ -139,12 +150,14 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         W2->upload(h2.data.data());
     }
     if (flags & HIPGCN_HOST_MASKS) {
-        h_keep0.resize((size_t)(f1 - f0));
+        keep0_first = replicate_l1 ? 0 : f0;
+        h_keep0.resize(replicate_l1 ? (size_t)fp[N] : (size_t)(f1 - f0));
         h_keep1.resize((size_t)n_local * H);
         void *q;
         GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, h_keep0.size() + 16)); d_keep0 = (uint8_t *)q;
         GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, h_keep1.size() + 16)); d_keep1 = (uint8_t *)q;
         env.keep_input = d_keep0;
+        env.keep_input_bwd = d_keep0 + (f0 - keep0_first);
         env.keep_hidden = d_keep1;
     }
     build_modules();
@@ -178,8 +191,13 @@ void HipGCN::build_modules() {
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, true));
     } else {
         const float scale = 1 / (1 - p);
-        modules.push_back(new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, p, nnz_off));
-        modules.push_back(new HipGraphSum(&env, H0, H1, graph, H, p, hid_off));
+        {
+            auto *sm = new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, p, nnz_off);
+            auto *gs = new HipGraphSum(&env, H0, H1, graph, H, p, hid_off);
+            if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = graph_l1; }
+            modules.push_back(sm);
+            modules.push_back(gs);
+        }
         modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C, scale));
         { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
@@ -214,14 +232,28 @@ void HipGCN::build_eval_lane() {
     }
     const int rm = part.rows_max;
     L.H0.reset(new HipVariable()); L.H1.reset(new HipVariable()); L.Z0.reset(new HipVariable()); L.Z.reset(new HipVariable());
-    L.H0->alloc(L.env.ctx, N, H, false, true, false, world, rank, rm);
+    if (replicate_l1) {
+        std::vector<int> lp(N + 1), deg(params.num_nodes);
+        const int r0 = part.start[rank];
+        for (int r = 0; r <= N; r++) lp[r] = gp[r0 + r] - gp[r0];
+        for (int j = 0; j < params.num_nodes; j++) deg[j] = gp[j + 1] - gp[j];
+        GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph_l1, lp.data(), gi.data() + gp[r0], N, params.num_nodes, deg.data()));
+        L.H0->alloc_replicated(L.env.ctx, params.num_nodes, N, r0, H, false);
+    } else {
+        L.H0->alloc(L.env.ctx, N, H, false, true, false, world, rank, rm);
+    }
     L.H1->alloc(L.env.ctx, N, H, false);
     L.Z0->alloc(L.env.ctx, N, C, false, true, false, world, rank, rm);
     L.Z->alloc(L.env.ctx, N, C, false);
     const uint64_t nnz_off = (uint64_t)data->feature_index.indptr[part.start[rank]];
     eval_vals = gcnhip_feat_values(feat);
-    L.modules.push_back(new HipSparseMatmul(&L.env, &eval_vals, variables[2].get(), L.H0.get(), feat, N, F, H, 0.f, nnz_off));
-    L.modules.push_back(new HipGraphSum(&L.env, L.H0.get(), L.H1.get(), L.graph, H, 0.f, 0));      // ReLU epilogue, no dropout in eval
+    {
+        auto *sm = new HipSparseMatmul(&L.env, &eval_vals, variables[2].get(), L.H0.get(), feat, N, F, H, 0.f, nnz_off);
+        auto *gs = new HipGraphSum(&L.env, L.H0.get(), L.H1.get(), L.graph, H, 0.f, 0);   // ReLU epilogue, no dropout in eval
+        if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = L.graph_l1; }
+        L.modules.push_back(sm);
+        L.modules.push_back(gs);
+    }
     L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
     L.modules.push_back(new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C));
     L.modules.push_back(new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false));
@@ -238,6 +270,7 @@ HipGCN::~HipGCN() {
         for (auto m : L.modules) delete m;
         L.H0.reset(); L.H1.reset(); L.Z0.reset(); L.Z.reset();
         if (L.graph) gcnhip_graph_destroy(L.env.ctx, L.graph);
+        if (L.graph_l1) gcnhip_graph_destroy(L.env.ctx, L.graph_l1);
         gcnhip_free(L.env.ctx, L.d_result); gcnhip_free(L.env.ctx, L.d_result_i); gcnhip_free(L.env.ctx, L.env.d_epoch);
         gcnhip_event_destroy(L.ev_weights); gcnhip_event_destroy(L.ev_done);
         L.timers.reset();
@@ -253,6 +286,8 @@ HipGCN::~HipGCN() {
     if (epoch_graph) gcnhip_graph_exec_destroy(epoch_graph);
     if (graph) gcnhip_graph_destroy(env.ctx, graph);
     if (feat) gcnhip_feat_destroy(env.ctx, feat);
+    if (feat_full) gcnhip_feat_destroy(env.ctx, feat_full);
+    if (graph_l1) gcnhip_graph_destroy(env.ctx, graph_l1);
     for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_truth[s]);
     gcnhip_free(env.ctx, gradbuf);
     gcnhip_free(env.ctx, d_result_i);
@@ -297,7 +332,7 @@ void HipGCN::host_masks_for_epoch() {
     const int thr = (int)(params.dropout * MY_RAND_MAX);
     const int rank = env.comm->rank();
     const long nnz_total = data->feature_index.indptr[params.num_nodes];
-    const long f0 = data->feature_index.indptr[part.start[rank]];
+    const long f0 = keep0_first;
     for (long i = 0; i < nnz_total; i++) {
         const bool keep = (int)rng.next() >= thr;
         if (i >= f0 && i < f0 + (long)h_keep0.size()) h_keep0[i - f0] = keep;

@@ -37,6 +37,7 @@ enum HipGCNFlags {
     HIPGCN_NO_GRAPH = 8,      // never replay epochs from a captured hipGraph
     HIPGCN_EVAL_LANE = 16,    // validation forward on a second stream, overlapped with the next training epoch
     HIPGCN_NO_EVAL_LANE = 32, // never (default: on when world > 1, where it hides the all-gathers)
+    HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
 };
 
 struct HipGCNOptions {
@@ -98,6 +99,12 @@ private:
 
     gcnhip_graph *graph = nullptr;
     gcnhip_feat *feat = nullptr;
+    // multi-GPU: the first-layer product is replicated (every rank multiplies ALL rows of X by W1): one GEMM
+    // of N x F x h per forward instead of an all-gather of N x h floats over xGMI
+    gcnhip_feat *feat_full = nullptr;
+    gcnhip_graph *graph_l1 = nullptr;                          // this rank's rows, GLOBAL column ids
+    const float *full_vals = nullptr;
+    bool replicate_l1 = false;
     std::vector<std::unique_ptr<HipVariable>> variables;       // index = reference variable number
     HipVariable *input = nullptr, *output = nullptr;
     const float *input_vals = nullptr;                         // what SparseMatmul reads
@@ -118,6 +125,7 @@ private:
     static constexpr int RING = 1024;
     uint8_t *d_keep0 = nullptr, *d_keep1 = nullptr;
     std::vector<uint8_t> h_keep0, h_keep1;
+    long keep0_first = 0;                                      // global nnz index of h_keep0[0]
     long epochs_done = 0;                                      // host mirror of *d_epoch + 1
     void *epoch_graph = nullptr;                               // captured train_epoch + eval(2)
 
@@ -130,6 +138,7 @@ private:
         std::unique_ptr<Comm> comm;
         std::unique_ptr<DeviceTimers> timers;
         gcnhip_graph *graph = nullptr;                         // own split-row scratch
+        gcnhip_graph *graph_l1 = nullptr;
         std::unique_ptr<HipVariable> H0, H1, Z0, Z;
         std::vector<Module *> modules;
         float *d_result = nullptr;

@@ -31,9 +31,14 @@ void HipSparseMatmul::forward(bool training) {
     last_training = training;
     env->timers->start(TMR_SPMATMUL_FW);
     const float pd = training ? fused_dropout : 0.f;
-    GCNHIP_CHECK(gcnhip_spmm_fwd(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p, pd,
-                                 env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
-                                 pd > 0.f ? env->keep_input : nullptr));
+    if (sp_full)        // every row of the product, with global element indices for the dropout stream
+        GCNHIP_CHECK(gcnhip_spmm_fwd(env->ctx, sp_full, *vals_full, b->data, b->ld, c->full, c->ld, p, pd,
+                                     env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, 0,
+                                     pd > 0.f ? env->keep_input : nullptr));
+    else
+        GCNHIP_CHECK(gcnhip_spmm_fwd(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p, pd,
+                                     env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
+                                     pd > 0.f ? env->keep_input : nullptr));
     env->timers->stop(TMR_SPMATMUL_FW);
 }
 
@@ -42,7 +47,7 @@ void HipSparseMatmul::backward() {
     const float pd = last_training ? fused_dropout : 0.f;     // the same X~ the forward saw (module.cpp:72)
     GCNHIP_CHECK(gcnhip_spmm_bwd(env->ctx, sp, *vals, c->grad, c->ld, b->grad, b->ld, p, pd,
                                  env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
-                                 pd > 0.f ? env->keep_input : nullptr));
+                                 pd > 0.f ? env->keep_input_bwd : nullptr));
     env->timers->stop(TMR_SPMATMUL_BW);
 }
 
@@ -51,8 +56,12 @@ HipGraphSum::HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_
     : env(env), in(in), out(out), graph(graph), dim(dim), fused_relu_dropout(frd), elem_offset(off) {}
 
 void HipGraphSum::forward(bool training) {
-    // rows of `in` named by this rank's columns live on other ranks: gather them first
-    if (env->comm->size() > 1) {
+    // rows of `in` named by this rank's columns live on other ranks: gather them first — unless every
+    // rank computed all of `in` itself (replicated first-layer product)
+    gcnhip_graph *graph = this->graph;
+    if (in->replicated && fwd_graph_replicated) {
+        graph = fwd_graph_replicated;
+    } else if (env->comm->size() > 1) {
         env->timers->start(TMR_COMM);
         env->comm->allgather_rows(in->full, in->full_elems / env->comm->size());
         env->timers->stop(TMR_COMM);

@@ -25,7 +25,8 @@ struct HipEnv {
     uint64_t seed = 0;
     uint32_t *d_epoch = nullptr;
     // parity mode: decisions generated on the host with the reference's RNG
-    const uint8_t *keep_input = nullptr;     // [local nnz of X]
+    const uint8_t *keep_input = nullptr;     // [nnz of the X the forward multiplies: local rows, or all rows when replicated]
+    const uint8_t *keep_input_bwd = nullptr; // [local nnz of X] (same decisions, this rank's slice)
     const uint8_t *keep_hidden = nullptr;    // [local rows * hidden]
 };
 
@@ -57,6 +58,9 @@ class HipSparseMatmul : public Module {
     uint64_t nnz_offset;            // global index of this rank's first stored value
     bool last_training = false;
 public:
+    // replicated forward (multi-GPU): X of ALL rows, so c->full is computed here and never gathered
+    gcnhip_feat *sp_full = nullptr;
+    const float *const *vals_full = nullptr;
     HipSparseMatmul(HipEnv *env, const float *const *vals, HipVariable *b, HipVariable *c, gcnhip_feat *sp,
                     int m, int n, int p, float fused_dropout, uint64_t nnz_offset);
     void forward(bool) override;
@@ -71,6 +75,7 @@ class HipGraphSum : public Module {
     float fused_relu_dropout;       // >= 0: ReLU (+ dropout with this p when training) in the store epilogue
     uint64_t elem_offset;           // global element index of this rank's first output element
 public:
+    gcnhip_graph *fwd_graph_replicated = nullptr;   // global column ids: forward reads a replicated `in` without a gather
     // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
     const uint32_t *const *bwd_row_bits = nullptr;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,

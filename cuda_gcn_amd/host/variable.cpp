@@ -54,6 +54,23 @@ void HipVariable::alloc(gcnhip_ctx *c, int r, int cl, bool rg, bool gather_data,
     }
 }
 
+void HipVariable::alloc_replicated(gcnhip_ctx *c, int total_rows, int local_rows, int row_start, int cl, bool rg) {
+    ctx = c; rows = local_rows; cols = cl; requires_grad = rg; replicated = true;
+    ld = cl <= 32 ? (cl + 3) / 4 * 4 : (cl + 15) / 16 * 16;
+    full_elems = (size_t)total_rows * ld;
+    void *p = nullptr;
+    GCNHIP_CHECK(gcnhip_malloc(ctx, &p, (full_elems ? full_elems : 4) * sizeof(float)));
+    GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, full_elems * sizeof(float)));
+    full = (float *)p;
+    data = full + (size_t)row_start * ld;
+    if (rg) {
+        const size_t local = (size_t)(rows > 0 ? rows : 1) * ld;
+        GCNHIP_CHECK(gcnhip_malloc(ctx, &p, local * sizeof(float)));
+        GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, local * sizeof(float)));
+        grad = (float *)p;
+    }
+}
+
 void HipVariable::zero() { GCNHIP_CHECK(gcnhip_memset_async(ctx, data, 0, elems() * sizeof(float))); }
 void HipVariable::zero_grad() { if (grad) GCNHIP_CHECK(gcnhip_memset_async(ctx, grad, 0, elems() * sizeof(float))); }
 

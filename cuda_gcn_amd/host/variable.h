@@ -32,6 +32,10 @@ struct HipVariable {
     // gather_rows_max > 0: allocate world * gather_rows_max rows and place this rank's block at rank * gather_rows_max
     void alloc(gcnhip_ctx *ctx, int rows, int cols, bool requires_grad, bool gather_data = false,
                bool gather_grad = false, int world = 1, int rank = 0, int gather_rows_max = 0);
+    // replicated input of a GraphSum: every rank computes all `total_rows` rows itself (no all-gather);
+    // data points at this rank's rows inside the full matrix
+    void alloc_replicated(gcnhip_ctx *ctx, int total_rows, int local_rows, int row_start, int cols, bool requires_grad);
+    bool replicated = false;
     size_t elems() const { return (size_t)rows * ld; }
     void zero();
     void zero_grad();

@@ -57,18 +57,22 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world,dropout,run_async", [("cora-syn", 2, 0.0, 0), ("cora-syn", 2, 0.5, 0), ("tiny-syn", 3, 0.5, 1),
-                                                          ("pubmed-syn", 2, 0.5, 1)])
-def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async):
+@pytest.mark.parametrize("name,world,dropout,run_async,flags", [
+    ("cora-syn", 2, 0.0, 0, 0), ("cora-syn", 2, 0.5, 0, 0), ("tiny-syn", 3, 0.5, 1, 0), ("pubmed-syn", 2, 0.5, 1, 0),
+    ("cora-syn", 2, 0.5, 1, 64),        # NO_REPLICATE_L1: H0 all-gathered instead of recomputed on every rank
+    ("tiny-syn", 3, 0.5, 0, 64 | 32),   # ... and no validation lane
+    ("cora-syn", 2, 0.5, 0, 2),         # HOST_MASKS: the reference's RNG stream sliced per rank
+])
+def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, flags):
     from cuda_gcn_amd import datagen
     from cuda_gcn_amd.model import HipGCNModel
     epochs = 12
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "mr.npz")
-        launch(world, ["gpu", name, out, epochs, 0, dropout], extra_env={"MR_ASYNC": str(run_async)})
+        launch(world, ["gpu", name, out, epochs, flags, dropout], extra_env={"MR_ASYNC": str(run_async)})
         got = np.load(out)
     ds = datagen.make_dataset(name)
-    m = HipGCNModel(ds, seed=4, hidden_dim=16, dropout=dropout, epochs=epochs)
+    m = HipGCNModel(ds, seed=4, flags=flags & 2, hidden_dim=16, dropout=dropout, epochs=epochs)
     want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
     wtest = m.eval(3)
     # same kernels on the same rows; only the order of the cross-rank gradient sum differs
