@@ -76,7 +76,7 @@ def main():
         flags = int(sys.argv[5])
         dropout = float(sys.argv[6])
         m = model.HipGCNModel(ds, seed=4, device=0, flags=flags, rank=rank, world=world, host_allgather=ag, host_allreduce=ar,
-                              hidden_dim=16, dropout=dropout, epochs=epochs)
+                              hidden_dim=int(os.environ.get("MR_HIDDEN", "16")), dropout=dropout, epochs=epochs)
         info = m.info()
         assert info["world"] == world and info["rank"] == rank
         if os.environ.get("MR_ASYNC") == "1":

@@ -62,6 +62,7 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
     ("cora-syn", 2, 0.5, 1, 64),        # NO_REPLICATE_L1: H0 all-gathered instead of recomputed on every rank
     ("tiny-syn", 3, 0.5, 0, 64 | 32),   # ... and no validation lane
     ("cora-syn", 2, 0.5, 0, 2),         # HOST_MASKS: the reference's RNG stream sliced per rank
+    ("reddit-mini", 2, 0.5, 1, 0),      # dense 602-column X, hidden 128, hub rows: the bench's shapes at 1/10 scale
 ])
 def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, flags):
     from cuda_gcn_amd import datagen
@@ -69,17 +70,20 @@ def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, fla
     epochs = 12
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "mr.npz")
-        launch(world, ["gpu", name, out, epochs, flags, dropout], extra_env={"MR_ASYNC": str(run_async)})
+        hidden = 128 if name.startswith("reddit") else 16
+        launch(world, ["gpu", name, out, epochs, flags, dropout], extra_env={"MR_ASYNC": str(run_async), "MR_HIDDEN": str(hidden)})
         got = np.load(out)
     ds = datagen.make_dataset(name)
-    m = HipGCNModel(ds, seed=4, flags=flags & 2, hidden_dim=16, dropout=dropout, epochs=epochs)
+    m = HipGCNModel(ds, seed=4, flags=flags & 2, hidden_dim=hidden, dropout=dropout, epochs=epochs)
     want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
     wtest = m.eval(3)
     # same kernels on the same rows; only the order of the cross-rank gradient sum differs
-    assert np.abs(got["trace"] - want).max() <= 2e-5, np.abs(got["trace"] - want).max()
+    assert np.abs(got["trace"] - want).max() <= (2e-4 if hidden > 16 else 2e-5), np.abs(got["trace"] - want).max()
     assert np.abs(got["test"] - np.array(wtest, np.float32)).max() <= 2e-5
-    assert np.allclose(got["w1"], m.var(2), rtol=1e-4, atol=1e-6)
-    assert np.allclose(got["h1"], m.var(3), rtol=1e-4, atol=1e-6)
+    # Adam divides by sqrt(v): last-bit differences of tiny gradients move a weight by up to ~lr * 1e-3
+    wtol = 1e-6 if hidden == 16 else 5e-4
+    assert np.abs(got["w1"] - m.var(2)).max() <= wtol + 1e-4 * np.abs(m.var(2)).max(), np.abs(got["w1"] - m.var(2)).max()
+    assert np.allclose(got["h1"], m.var(3), rtol=1e-3 if hidden > 16 else 1e-4, atol=wtol * 10), np.abs(got["h1"] - m.var(3)).max()
     # dropout decisions identical => the same zero pattern in H1 of the last eval... eval has no dropout;
     # the trace equality above at dropout 0.5 is the partition-invariance check of the RNG
     m.close()
