@@ -169,6 +169,16 @@ int gcnhost_rccl_selftest(int device) {
             double v[2] = {3.0, 4.0};
             comm->allreduce_sum_host(v, 2);
             if (v[0] != 3.0 || v[1] != 4.0) throw GcnHipFailure(-1, "RCCL self-test: host reduction");
+            // the validation lane's communicator (ncclCommSplit) on a second stream
+            gcnhip_ctx *ctx2 = nullptr;
+            GCNHIP_CHECK(gcnhip_ctx_create(&ctx2, device, nullptr));
+            {
+                std::unique_ptr<Comm> comm2(comm->clone_for(ctx2));
+                double w2[1] = {5.0};
+                comm2->allreduce_sum_host(w2, 1);
+                if (w2[0] != 5.0) throw GcnHipFailure(-1, "RCCL self-test: split communicator");
+            }
+            gcnhip_ctx_destroy(ctx2);
         }
         gcnhip_ctx_destroy(ctx);
     })

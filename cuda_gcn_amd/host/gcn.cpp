@@ -161,7 +161,15 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         env.keep_hidden = d_keep1;
     }
     build_modules();
-    if (!(flags & HIPGCN_NO_EVAL_LANE) && ((flags & HIPGCN_EVAL_LANE) || world > 1)) build_eval_lane();
+    if (!(flags & HIPGCN_NO_EVAL_LANE) && ((flags & HIPGCN_EVAL_LANE) || world > 1)) {
+        try {
+            build_eval_lane();
+        } catch (const GcnHipFailure &e) {
+            // e.g. an RCCL without ncclCommSplit: every rank fails the same way and falls back to one lane
+            fprintf(stderr, "gcn-hip: validation lane disabled (%s)\n", e.what());
+            lane.reset();
+        }
+    }
     AdamParams ap = AdamParams::get_default();
     ap.lr = params.learning_rate;
     ap.weight_decay = params.weight_decay;
