@@ -241,12 +241,23 @@ int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int *
 }
 
 // ---------------------------------------------------------------- features
+static int feat_create_impl(gcnhip_ctx *c, gcnhip_feat *f, const int *h_indptr, const int *h_indices,
+                            const float *h_values, int n_rows, int n_cols);
+
 int gcnhip_feat_create(gcnhip_ctx *c, gcnhip_feat **out, const int *h_indptr, const int *h_indices,
                        const float *h_values, int n_rows, int n_cols) {
     if (!c || !out || !h_indptr || !h_values || n_rows < 0 || n_cols <= 0) return -1;
-    GCNHIP_TRY(hipSetDevice(c->device));
     gcnhip_feat *f = new gcnhip_feat();
     memset(f, 0, sizeof *f);
+    const int rc = feat_create_impl(c, f, h_indptr, h_indices, h_values, n_rows, n_cols);
+    if (rc != 0) { gcnhip_feat_destroy(c, f); return rc; }     // frees whatever was allocated
+    *out = f;
+    return 0;
+}
+
+static int feat_create_impl(gcnhip_ctx *c, gcnhip_feat *f, const int *h_indptr, const int *h_indices,
+                            const float *h_values, int n_rows, int n_cols) {
+    GCNHIP_TRY(hipSetDevice(c->device));
     f->n_rows = n_rows; f->n_cols = n_cols;
     const int64_t nnz = h_indptr[n_rows];
     f->nnz = nnz;
@@ -260,7 +271,7 @@ int gcnhip_feat_create(gcnhip_ctx *c, gcnhip_feat **out, const int *h_indptr, co
                 if (row[k] != k) { dense = false; break; }
         }
     }
-    if (!h_indices && !dense) { delete f; return -1; }
+    if (!h_indices && !dense) return -1;
     f->dense = dense;
     GCNHIP_TRY(hipMalloc((void **)&f->indptr, (size_t)(n_rows + 1) * sizeof(int)));
     GCNHIP_TRY(hipMemcpy(f->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
@@ -294,14 +305,14 @@ int gcnhip_feat_create(gcnhip_ctx *c, gcnhip_feat **out, const int *h_indptr, co
             GCNHIP_TRY(hipMemcpy(f->csc_pos, pos.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
         }
     }
-    *out = f;
     return 0;
 }
 
 int gcnhip_feat_destroy(gcnhip_ctx *c, gcnhip_feat *f) {
     if (!f) return 0;
     hipSetDevice(c->device);
-    hipFree(f->indptr); hipFree(f->values);
+    if (f->indptr) hipFree(f->indptr);
+    if (f->values) hipFree(f->values);
     if (f->indices) hipFree(f->indices);
     if (f->csc_ptr) hipFree(f->csc_ptr);
     if (f->csc_row) hipFree(f->csc_row);

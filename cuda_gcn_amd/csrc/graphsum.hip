@@ -21,7 +21,6 @@
 // The reference launches one block per row with `dim` threads and does a
 // global read-modify-write per edge (cuda_kernel.cu:126-143).
 #include "common.h"
-#include <stdlib.h>
 
 struct GsArgs {
     const int *indptr, *indices;
@@ -290,13 +289,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
     a.n_slices = 1;
-    static const int force_l = getenv("GCNHIP_GS_LANES") ? atoi(getenv("GCNHIP_GS_LANES")) : 0;   // experiments
-    if (vec && force_l && d4 > force_l) {
-        if (force_l == 4) launch_vec<4>(a, nt, c->stream);
-        else if (force_l == 8) launch_vec<8>(a, nt, c->stream);
-        else if (force_l == 16) launch_vec<16>(a, nt, c->stream);
-        else launch_vec<32>(a, nt, c->stream);
-    } else if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
+    if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
         // rows of whole 128-byte lines: one 32-float column slice per XCD group (measured at
         // Reddit scale, d = 128: 1.42 ms unsliced -> 1.26 ms; L2 hit rate of the gather rises
         // because each XCD's L2 holds a quarter of the table)

@@ -149,6 +149,7 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
     int blocks = ceil_div(a.n_rows, 4 * 8);             // ~8 rows per wave
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
+    if (a.n_rows == 0) blocks = 1;                      // a rank that owns no rows still reports zeros
     a.part_f = c->red_f + 2048;
     a.part_i = c->red_i;
     if (!a.acc_only && a.training && a.count <= 0) {    // count first, like module.cpp:127-133
@@ -175,7 +176,7 @@ int gcnhip_xent_fwd(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_gr
                     int count, int shift_in_place, float *d_result, int32_t *d_result_i) {
     if (!c || !logits || !truth || !d_result || num_classes <= 0 || ld < num_classes) return -1;
     if (training && (!grad || ld_grad < num_classes)) return -1;
-    if (n_rows <= 0) return -1;
+    if (n_rows < 0) return -1;
     XentArgs a;
     a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_rows; a.C = num_classes;
@@ -186,7 +187,7 @@ int gcnhip_xent_fwd(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_gr
 
 int gcnhip_accuracy(gcnhip_ctx *c, const float *logits, int ld, const int32_t *truth,
                     int n_rows, int num_classes, int32_t *d_result_i) {
-    if (!c || !logits || !truth || !d_result_i || num_classes <= 0 || ld < num_classes || n_rows <= 0) return -1;
+    if (!c || !logits || !truth || !d_result_i || num_classes <= 0 || ld < num_classes || n_rows < 0) return -1;
     XentArgs a;
     a.logits = const_cast<float *>(logits); a.grad = nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = 0; a.n_rows = n_rows; a.C = num_classes;

@@ -69,7 +69,7 @@ class HipGCNModel:
                                       int(rank), int(world), nccl_id, self._ag, self._ar, None)
         _ck(lib, rc, "gcnhost_model_create")
         self.h = h
-        self._keep = None if world == 1 and False else self._keep   # the C++ side copied everything
+        self._keep = None           # the C++ side copied everything it needs
 
     def train_epoch(self):
         a, b = C.c_float(), C.c_float()

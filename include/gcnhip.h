@@ -17,9 +17,11 @@
  *    (The reference prints and exits: CUDA_CHECK, src/cuda/cuda_kernel.cuh:11-18 —
  *    that policy belongs to the caller; see GCNHIP_CHECK in host/hip_check.h.)
  *  - all launches are asynchronous on the context's stream; only functions
- *    documented as "synchronises" wait.  No allocation happens inside an op:
- *    scratch lives in the context / graph / feature objects created up front, so
- *    every op is hipGraph-capturable.
+ *    documented as "synchronises" wait.  Scratch lives in the context / graph /
+ *    feature objects; the few buffers whose size depends on an op's arguments
+ *    (split-K slabs, split-row partials) are sized on the first call that needs
+ *    them (that call synchronises once).  After one warm-up call no op allocates,
+ *    so every op is hipGraph-capturable.
  *  - all matrices are row-major f32 with an explicit leading dimension `ld`
  *    (floats).  The reference's layout is ld == number of columns.  Rows that
  *    are 16-byte aligned (ld % 4 == 0 and a 16-byte aligned base) take the
