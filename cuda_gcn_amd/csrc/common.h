@@ -44,6 +44,8 @@ struct gcnhip_graph {
     float *partials;    // [n_slots * part_ld]
     int part_ld;
     int n_slots;
+    // task ranges of equal edge count for 1, 2, 4 or 8 XCD groups: bounds[log2 G][g] .. bounds[log2 G][g+1]
+    int bounds[4][9];
 };
 
 struct gcnhip_feat {

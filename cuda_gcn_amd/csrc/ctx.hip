@@ -168,7 +168,26 @@ int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, 
     GCNHIP_TRY(hipMalloc((void **)&g->indices, (size_t)std::max(nnz, 1) * sizeof(int)));
     GCNHIP_TRY(hipMalloc((void **)&g->coef, (size_t)std::max(nnz, 1) * sizeof(float)));
     GCNHIP_TRY(hipMemcpy(g->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
-    if (nnz) GCNHIP_TRY(hipMemcpy(g->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    // Gather order inside a row: neighbours by descending degree.  Every wave then asks for the
+    // popular rows (which are the ones that stay in L2) at the same point of its walk; measured on
+    // reddit-syn this and the degree-ordered task list below are worth 6 % (d = 128) and 13 % (d = 41).
+    // Only the order of the floating-point sum changes.
+    std::vector<int> sorted_idx;
+    if (nnz) {
+        sorted_idx.assign(h_indices, h_indices + nnz);
+        auto deg_of = [&](int j) { return h_col_deg ? h_col_deg[j] : h_indptr[j + 1] - h_indptr[j]; };
+        std::vector<std::pair<int, int>> tmp;
+        for (int r = 0; r < n_rows; r++) {
+            const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
+            if (e1 - e0 < 2) continue;
+            tmp.resize(e1 - e0);
+            for (int e = e0; e < e1; e++) tmp[e - e0] = {-deg_of(sorted_idx[e]), sorted_idx[e]};
+            std::sort(tmp.begin(), tmp.end());
+            for (int e = e0; e < e1; e++) sorted_idx[e] = tmp[e - e0].second;
+        }
+        h_indices = sorted_idx.data();
+        GCNHIP_TRY(hipMemcpy(g->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    }
     int *d_col_deg = nullptr;
     if (h_col_deg) {
         GCNHIP_TRY(hipMalloc((void **)&d_col_deg, (size_t)std::max(n_cols, 1) * sizeof(int)));
@@ -181,38 +200,55 @@ int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, 
     GCNHIP_TRY(hipStreamSynchronize(c->stream));
     if (d_col_deg) GCNHIP_TRY(hipFree(d_col_deg));
 
-    // long-row splitting: segments of SPLIT_EDGES edges, heavy tasks first
-    int n_long = 0, n_slots = 0;
-    for (int r = 0; r < n_rows; r++) {
-        const int d = h_indptr[r + 1] - h_indptr[r];
-        if (d > SPLIT_EDGES) { n_long++; n_slots += (d + SPLIT_EDGES - 1) / SPLIT_EDGES; }
+    // Task list: rows in descending degree order (heavy work first, similar rows together); a row
+    // above SPLIT_EDGES becomes consecutive segments whose partial sums a second kernel adds in order.
+    std::vector<int> order(n_rows);
+    for (int r = 0; r < n_rows; r++) order[r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return h_indptr[a + 1] - h_indptr[a] > h_indptr[b + 1] - h_indptr[b];
+    });
+    int n_slots = 0;
+    std::vector<int4> tasks, srows;
+    tasks.reserve((size_t)n_rows + 64);
+    for (int r : order) {
+        const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
+        if (e1 - e0 <= SPLIT_EDGES) { tasks.push_back(make_int4(r, e0, e1, -1)); continue; }
+        const int ns = (e1 - e0 + SPLIT_EDGES - 1) / SPLIT_EDGES;
+        srows.push_back(make_int4(r, n_slots, ns, 0));
+        for (int q = 0; q < ns; q++)
+            tasks.push_back(make_int4(r, e0 + q * SPLIT_EDGES, std::min(e1, e0 + (q + 1) * SPLIT_EDGES), n_slots + q));
+        n_slots += ns;
     }
-    if (n_long) {
-        std::vector<int4> tasks, srows;
-        tasks.reserve((size_t)n_rows + n_slots);
-        int slot = 0;
-        for (int r = 0; r < n_rows; r++) {
-            const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
-            if (e1 - e0 <= SPLIT_EDGES) continue;
-            const int ns = (e1 - e0 + SPLIT_EDGES - 1) / SPLIT_EDGES;
-            srows.push_back(make_int4(r, slot, ns, 0));
-            for (int s = 0; s < ns; s++)
-                tasks.push_back(make_int4(r, e0 + s * SPLIT_EDGES, std::min(e1, e0 + (s + 1) * SPLIT_EDGES), slot + s));
-            slot += ns;
-        }
-        for (int r = 0; r < n_rows; r++) {
-            const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
-            if (e1 - e0 <= SPLIT_EDGES) tasks.push_back(make_int4(r, e0, e1, -1));
-        }
-        g->n_tasks = (int)tasks.size();
-        g->n_split_rows = (int)srows.size();
-        g->n_slots = n_slots;
+    g->n_tasks = (int)tasks.size();
+    g->n_split_rows = (int)srows.size();
+    g->n_slots = n_slots;
+    const int n_units = g->n_tasks;
+    std::vector<int64_t> prefix((size_t)n_units + 1);   // work before task t: edges + a per-task constant
+    prefix[0] = 0;
+    for (int t = 0; t < n_units; t++) prefix[t + 1] = prefix[t] + (tasks[t].z - tasks[t].y) + 8;
+    if (n_units) {
         GCNHIP_TRY(hipMalloc((void **)&g->tasks, tasks.size() * sizeof(int4)));
         GCNHIP_TRY(hipMemcpy(g->tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    if (!srows.empty()) {
         GCNHIP_TRY(hipMalloc((void **)&g->split_rows, srows.size() * sizeof(int4)));
         GCNHIP_TRY(hipMemcpy(g->split_rows, srows.data(), srows.size() * sizeof(int4), hipMemcpyHostToDevice));
-        g->part_ld = 0;       // partial buffer sized lazily for the widest dim seen
-        g->partials = nullptr;
+    }
+    g->part_ld = 0;           // partial buffer sized lazily for the widest dim seen
+    g->partials = nullptr;
+    // equal-work task ranges for 1/2/4/8 XCD groups, each starting on a multiple of 4 tasks (one workgroup)
+    for (int lg = 0; lg < 4; lg++) {
+        const int G = 1 << lg;
+        g->bounds[lg][0] = 0;
+        for (int k = 1; k < G; k++) {
+            const int64_t target = prefix[n_units] * k / G;
+            int t = (int)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+            t = (t + 3) / 4 * 4;
+            if (t > n_units) t = n_units;
+            if (t < g->bounds[lg][k - 1]) t = g->bounds[lg][k - 1];
+            g->bounds[lg][k] = t;
+        }
+        for (int k = G; k <= 8; k++) g->bounds[lg][k] = n_units;
     }
     *out = g;
     return 0;

@@ -21,6 +21,7 @@
 // The reference launches one block per row with `dim` threads and does a
 // global read-modify-write per edge (cuda_kernel.cu:126-143).
 #include "common.h"
+#include <algorithm>
 
 struct GsArgs {
     const int *indptr, *indices;
@@ -31,7 +32,8 @@ struct GsArgs {
     float *out;
     float *partials;
     int ld_in, ld_out, part_ld, dim;
-    int n_slices;     // > 1: the columns are cut into n_slices slices of L*4 floats, one slice per XCD group
+    int n_slices;     // >= 1: the columns are cut into n_slices slices of L*4 floats, one slice per XCD group
+    int bounds[9];          // task range [bounds[g], bounds[g+1]) of XCD group g (equal edge counts)
     // epilogue
     int fuse, training, thr;
     float scale;
@@ -84,21 +86,21 @@ template <int L>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
+    // XCD-aware mapping (speed only, never correctness): workgroups are dealt round-robin over the
+    // 8 XCDs, so blockIdx % 8 names the group of blocks that share an L2.  Each group gets
+    //  (a) one column slice (wide rows): its 4 MiB L2 then sees 1/n_slices of the gathered table;
+    //  (b) a CONTIGUOUS range of the task list, so rows that are neighbours in the node order —
+    //      the same community after reordering — are gathered through the same L2.
     int t, cslice;
-    if (a.n_slices > 1) {
-        // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names
-        // the group that shares an L2; speed only, never correctness).  XCD group x works on column
-        // slice x % n_slices only, so its 4 MiB L2 sees 1/n_slices of the gathered table.
+    {
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int groups = 8 / a.n_slices;
-        cslice = xcd % a.n_slices;
-        t = (q * groups + xcd / a.n_slices) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    } else {
-        cslice = blockIdx.y;
-        t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int groups = 8 / a.n_slices;                 // XCD groups per slice
+        cslice = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
+        const int g_id = xcd / a.n_slices;                 // which share of the tasks
+        t = a.bounds[g_id] + q * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (t >= a.bounds[g_id + 1]) return;               // wave-uniform
+        (void)groups;
     }
-    const int nt = a.n_tasks ? a.n_tasks : a.n_rows;
-    if (t >= nt) return;                                   // wave-uniform
     int row, e0, e1, slot;
     if (a.n_tasks) {
         const int4 tk = a.tasks[t];
@@ -245,18 +247,16 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
 }
 
 template <int L>
-static void launch_vec(GsArgs a, int nt, hipStream_t s) {
+static void launch_vec(GsArgs a, const gcnhip_graph *g, hipStream_t s) {
     const int ychunks = ceil_div(a.dim, L * 4);
-    if (ychunks > 1 && 8 % ychunks == 0) {                 // XCD-sliced columns (1-D grid)
-        a.n_slices = ychunks;
-        const int groups = 8 / ychunks;
-        dim3 grid(ceil_div(ceil_div(nt, 4), groups) * 8);
-        graphsum_vec_kernel<L><<<grid, 256, 0, s>>>(a);
-    } else {
-        a.n_slices = 1;
-        dim3 grid(ceil_div(nt, 4), ychunks);
-        graphsum_vec_kernel<L><<<grid, 256, 0, s>>>(a);
-    }
+    const bool sliced = ychunks > 1 && 8 % ychunks == 0;   // XCD-sliced columns (1-D grid)
+    a.n_slices = sliced ? ychunks : 1;
+    const int G = 8 / a.n_slices;                          // XCD groups that share the task list
+    const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
+    int max_blocks = 1;
+    for (int k = 0; k <= 8; k++) a.bounds[k] = g->bounds[lg][k];
+    for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
+    graphsum_vec_kernel<L><<<dim3(max_blocks * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
 }
 template <int L>
 static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
@@ -269,7 +269,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     if (!c || !g || !in || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (g->n_rows == 0) return 0;
     gcnhip_graph *gm = const_cast<gcnhip_graph *>(g);
-    if (g->n_tasks && g->part_ld < dim) {      // first call at this width: size the segment scratch
+    if (g->n_slots && g->part_ld < dim) {      // first call at this width: size the segment scratch
         GCNHIP_TRY(hipStreamSynchronize(c->stream));
         if (gm->partials) GCNHIP_TRY(hipFree(gm->partials));
         gm->part_ld = (dim + 3) / 4 * 4;
@@ -293,15 +293,15 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         // rows of whole 128-byte lines: one 32-float column slice per XCD group (measured at
         // Reddit scale, d = 128: 1.42 ms unsliced -> 1.26 ms; L2 hit rate of the gather rises
         // because each XCD's L2 holds a quarter of the table)
-        launch_vec<8>(a, nt, c->stream);
+        launch_vec<8>(a, g, c->stream);
     } else if (vec) {
-        if (d4 <= 1) launch_vec<1>(a, nt, c->stream);
-        else if (d4 <= 2) launch_vec<2>(a, nt, c->stream);
-        else if (d4 <= 4) launch_vec<4>(a, nt, c->stream);
-        else if (d4 <= 8) launch_vec<8>(a, nt, c->stream);
-        else if (d4 <= 16) launch_vec<16>(a, nt, c->stream);
-        else if (d4 <= 32) launch_vec<32>(a, nt, c->stream);
-        else launch_vec<64>(a, nt, c->stream);
+        if (d4 <= 1) launch_vec<1>(a, g, c->stream);
+        else if (d4 <= 2) launch_vec<2>(a, g, c->stream);
+        else if (d4 <= 4) launch_vec<4>(a, g, c->stream);
+        else if (d4 <= 8) launch_vec<8>(a, g, c->stream);
+        else if (d4 <= 16) launch_vec<16>(a, g, c->stream);
+        else if (d4 <= 32) launch_vec<32>(a, g, c->stream);
+        else launch_vec<64>(a, g, c->stream);
     } else {
         if (dim <= 1) launch_scalar<1>(a, nt, c->stream);
         else if (dim <= 2) launch_scalar<2>(a, nt, c->stream);
