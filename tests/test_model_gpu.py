@@ -235,3 +235,38 @@ def test_eval_lane_is_bit_identical():
     assert a.eval(3) == b.eval(3)
     assert np.array_equal(a.var(2), b.var(2))
     a.close(); b.close()
+
+
+def _run_cli(binary, td, args, env):
+    r = subprocess.run([binary] + args, cwd=td, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    ep = [dict((k, float(v)) for k, v in (t.split("=") for t in l.split())) for l in lines if l.startswith("epoch=")]
+    return lines, ep
+
+
+def test_cli_early_stopping_and_host_masks():
+    """early stopping (gcn.cpp:141-150) and GCN_HOST_MASKS=1 (the CPU path's own dropout decisions) through
+    the command line, beside gcn-seq"""
+    ds = datagen.make_dataset("tiny-syn")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "gcn-seq"], check=True)
+    hip = os.path.join(ROOT, "cuda_gcn_amd", "bin", "gcn-hip")
+    seq = os.path.join(ROOT, "oracle", "gcn-seq")
+    with tempfile.TemporaryDirectory() as td:
+        datagen.write_text(ds, os.path.join(td, "data"), "tiny-syn")
+        # dropout 0.5 with replayed masks: the two traces stay together
+        env = dict(os.environ, GCN_SEED="11", GCN_HOST_MASKS="1")
+        args = ["tiny-syn", "-", "-", "16", "-", "0.5", "-", "-", "40"]
+        _, ea = _run_cli(hip, td, args, env)
+        _, eb = _run_cli(seq, td, args, env)
+        assert len(ea) == len(eb) == 40
+        for x, y in zip(ea, eb):
+            assert abs(x["train_loss"] - y["train_loss"]) <= 2e-3 and abs(x["val_loss"] - y["val_loss"]) <= 2e-3
+            assert abs(x["train_acc"] - y["train_acc"]) <= 2 / 30 + 1e-6
+        # early stopping window 5, dropout 0: both stop, within two epochs of each other
+        env = dict(os.environ, GCN_SEED="11")
+        args = ["tiny-syn", "-", "-", "16", "-", "0", "0.05", "-", "300", "5"]
+        la, ea = _run_cli(hip, td, args, env)
+        lb, eb = _run_cli(seq, td, args, env)
+        assert any("Early stopping..." in l for l in la) and any("Early stopping..." in l for l in lb)
+        assert abs(len(ea) - len(eb)) <= 2 and len(ea) < 300
