@@ -214,3 +214,17 @@ def write_text(ds, root: str, name: str | None = None):
     with open(os.path.join(root, name + ".split"), "w") as f:
         for s in ds["split"].tolist():
             f.write("%d\n" % s)
+
+
+def write_gcnbin(ds, path: str):
+    """Binary dataset cache read by the C++ Parser (host/parser.cpp: magic, 3 dims, then seven
+    length-prefixed arrays).  `gcn-hip <name>` prefers `<root>/<name>.gcnbin` over the text files."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"GCNBIN01")
+        f.write(struct.pack("<3i", int(ds["num_nodes"]), int(ds["input_dim"]), int(ds["output_dim"])))
+        for key, dt in (("g_indptr", np.int32), ("g_indices", np.int32), ("f_indptr", np.int32), ("f_indices", np.int32),
+                        ("f_val", np.float32), ("split", np.int32), ("label", np.int32)):
+            a = np.ascontiguousarray(ds[key], dt)
+            f.write(struct.pack("<Q", a.size))
+            a.tofile(f)

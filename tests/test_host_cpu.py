@@ -96,3 +96,46 @@ def test_partition_covers_and_balances(name, world):
     cost = np.diff(gp) + gp[-1] / n
     share = [cost[start[q]:start[q + 1]].sum() for q in range(world)]
     assert max(share) <= 1.25 * cost.sum() / world + cost.max()
+
+
+def test_gcnbin_written_from_python_loads_in_cpp():
+    from cuda_gcn_amd import model
+    ds = datagen.make_dataset("tiny-syn", seed=5)
+    with tempfile.TemporaryDirectory() as td:
+        datagen.write_gcnbin(ds, os.path.join(td, "t.gcnbin"))
+        back = model.load_dataset(td, "t")
+    for k in KEYS:
+        assert np.array_equal(back[k], ds[k]), k
+    assert (back["num_nodes"], back["input_dim"], back["output_dim"]) == (ds["num_nodes"], ds["input_dim"], ds["output_dim"])
+
+
+def test_graphsage_converter_on_a_small_fixture():
+    """tools/reddit_convert.py on a 6-node GraphSAGE-format dataset: dropped node, sorted renumbering,
+    split codes, train-only standardisation, self loop first"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import reddit_convert
+    nodes = [{"id": "n3", "val": False, "test": False}, {"id": "n1", "val": True, "test": False},
+             {"id": "n2", "val": False, "test": True}, {"id": "n0", "val": False, "test": False},
+             {"id": "broken"}, {"id": "n4", "val": False, "test": False}]
+    links = [{"source": 0, "target": 1}, {"source": 1, "target": 2}, {"source": 3, "target": 0}, {"source": 4, "target": 0},
+             {"source": 5, "target": 3}]
+    feats = np.arange(30, dtype=np.float64).reshape(6, 5) ** 1.5
+    id_map = {n["id"]: i for i, n in enumerate(nodes)}
+    class_map = {"n0": 2, "n1": 0, "n2": 1, "n3": 1, "n4": 0, "broken": 0}
+    with tempfile.TemporaryDirectory() as td:
+        json.dump({"nodes": nodes, "links": links}, open(os.path.join(td, "x-G.json"), "w"))
+        np.save(os.path.join(td, "x-feats.npy"), feats)
+        json.dump(id_map, open(os.path.join(td, "x-id_map.json"), "w"))
+        json.dump(class_map, open(os.path.join(td, "x-class_map.json"), "w"))
+        ds = reddit_convert.convert(td, "x")
+    assert ds["num_nodes"] == 5 and ds["output_dim"] == 3 and ds["input_dim"] == 5     # "broken" dropped
+    # sorted ids n0..n4 -> 0..4; edges n3-n1, n1-n2, n0-n3, n4-n0
+    want = {0: [0, 3, 4], 1: [1, 3, 2], 2: [2, 1], 3: [3, 1, 0], 4: [4, 0]}
+    for r, row in want.items():
+        assert ds["g_indices"][ds["g_indptr"][r]:ds["g_indptr"][r + 1]].tolist() == row
+    assert ds["split"].tolist() == [1, 2, 3, 1, 1] and ds["label"].tolist() == [2, 0, 1, 1, 0]
+    X = ds["f_val"].reshape(5, 5)
+    tr = X[[0, 3, 4]]
+    assert np.allclose(tr.mean(axis=0), 0, atol=1e-6) and np.allclose(tr.std(axis=0), 1, atol=1e-5)
