@@ -143,6 +143,7 @@ def main():
                 traffic = k["traffic_bytes_per_launch"]
                 traffic_src = "profiles/r01_graphsum_pmc.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, rocprofv3 --pmc in separate passes"
         bytes_per_launch = b_gs(info["local_rows"], info["local_edges"], args.hidden)
+        table_mb = ds["num_nodes"] * args.hidden * 4 / 1e6
         avg_s = s_wide / max(n_wide, 1)
         achieved = bytes_per_launch / avg_s / 1e9
         n_lab = int((ds["split"] == 1).sum())
@@ -160,8 +161,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s,
                          "launches": n_wide,
-                         "note": "algorithmic gather-model bytes B_gs(d); the 119 MB feature table is Infinity-Cache "
-                                 "resident, so achieved may exceed HBM traffic (see DESIGN.md, profiles/)"},
+                         "note": ("algorithmic gather-model bytes B_gs(d); the gathered table (%.0f MB) is Infinity-Cache resident, "
+                                  "so achieved may exceed both HBM traffic and the HBM peak (see DESIGN.md, profiles/)" % table_mb)
+                                 if table_mb <= 256 else
+                                 ("algorithmic gather-model bytes B_gs(d); the gathered table (%.0f MB) exceeds the 256 MiB Infinity "
+                                  "Cache: HBM regime" % table_mb)},
             "breakdown_ms_per_epoch": breakdown,
             "final": {"train_loss": float(trace[-1, 0]), "train_acc": float(trace[-1, 1]),
                       "val_loss": float(trace[-1, 2]), "val_acc": float(trace[-1, 3])},
