@@ -86,7 +86,7 @@ def main():
     import torch.distributed as dist   # that one HIP runtime / one RCCL is loaded in the process
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(int(os.environ.get("GCN_BENCH_DEVICE", local_rank)))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)    # control plane; data plane is RCCL in libgcnhost
@@ -101,13 +101,24 @@ def main():
     t0 = time.perf_counter()
     ds = datagen.make_dataset(args.dataset)          # same seed on every rank -> identical graph
     t_data = time.perf_counter() - t0
-    nccl_id = None
-    if world > 1:
+    nccl_id, host_ag, host_ar = None, None, None
+    if world > 1 and os.environ.get("GCN_BENCH_TRANSPORT") == "host":
+        # rehearsal without RCCL (e.g. several ranks sharing one GPU): collectives staged through the host
+        # over gloo.  Never a performance number.
+        def host_ag(user, ptr, block):
+            t = torch.from_numpy(np.ctypeslib.as_array(ptr, (block * world,)))
+            dist.all_gather(list(t.view(world, block).unbind(0)), t[rank * block:(rank + 1) * block].clone())
+
+        def host_ar(user, ptr, n):
+            dist.all_reduce(torch.from_numpy(np.ctypeslib.as_array(ptr, (n,))))
+    elif world > 1:
         box = [nccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         nccl_id = box[0]
     lane_flag = {"auto": 0, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
-    model = HipGCNModel(ds, seed=1, device=local_rank, flags=TIMERS | lane_flag, rank=rank, world=world, nccl_id=nccl_id,
+    device = int(os.environ.get("GCN_BENCH_DEVICE", local_rank))
+    model = HipGCNModel(ds, seed=1, device=device, flags=TIMERS | lane_flag, rank=rank, world=world, nccl_id=nccl_id,
+                        host_allgather=host_ag, host_allreduce=host_ar,
                         hidden_dim=args.hidden, dropout=0.5, epochs=args.steps + args.warmup)
     info = model.info()
 
