@@ -270,3 +270,32 @@ def test_cli_early_stopping_and_host_masks():
         lb, eb = _run_cli(seq, td, args, env)
         assert any("Early stopping..." in l for l in la) and any("Early stopping..." in l for l in lb)
         assert abs(len(ea) - len(eb)) <= 2 and len(ea) < 300
+
+
+def test_full_size_reddit_two_epochs_vs_oracle(oracle):
+    """BASELINE configs[2] at full size (232 965 nodes, 23.4 M stored edges, 602 -> 128 -> 41): two
+    training epochs + validation against the CPU oracle with the reference's dropout decisions replayed
+    (about a minute: the oracle needs ~13 s per epoch)"""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+    ds = datagen.make_dataset("reddit-syn")
+    om = oracle.model(ds, seed_time=3, hidden_dim=128, dropout=0.5)
+    m = HipGCNModel(ds, seed=3, flags=HOST_MASKS, hidden_dim=128, dropout=0.5, epochs=2)
+    # a validation forward with the (identical) initial weights: every element of H1 and Z
+    a, b = m.eval(2), om.eval(2)
+    assert abs(a[0] - b[0]) <= 2e-5 and abs(a[1] - b[1]) <= 1e-4
+    h = m.var(3)
+    assert np.allclose(h, om.var(3).reshape(h.shape), rtol=1e-4, atol=2e-6)
+    z, zo = m.var(6), om.var(6).reshape(-1, ds["output_dim"])
+    lab = ds["split"] == 2                                   # the oracle max-shifts the rows it scored, in place
+    z = z - np.where(lab[:, None], z.max(axis=1, keepdims=True), 0)
+    assert np.allclose(z, zo, rtol=1e-4, atol=5e-6)
+    for e in range(2):
+        got = m.train_epoch() + m.eval(2)
+        want = om.train_epoch() + om.eval(2)
+        assert abs(got[0] - want[0]) <= 2e-4 and abs(got[2] - want[2]) <= 2e-4, (e, got, want)
+        assert abs(got[1] - want[1]) <= 2e-5 and abs(got[3] - want[3]) <= 1e-4, (e, got, want)
+    # after Adam steps single weights whose gradient is ~0 may have moved by +-lr in opposite directions
+    # (the first Adam step is lr * sign(g)); activations are therefore compared in bulk only
+    d = np.abs(m.var(3) - om.var(3).reshape(h.shape))
+    assert np.median(d) <= 1e-6 and d.max() <= 5e-3, (np.median(d), d.max())
+    m.close(); om.close()
