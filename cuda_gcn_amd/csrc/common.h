@@ -55,6 +55,8 @@ struct gcnhip_feat {
     int *indptr;        // [n_rows+1] (kept for dense too: row r starts at r*n_cols)
     int *indices;       // [nnz]; NULL when dense
     float *values;      // [nnz] pristine X
+    float *values_pad;  // dense X whose rows are not 16-byte aligned: a copy with row stride ld_pad (multiple of 4)
+    int ld_pad;
     // CSC view for the weight gradient (sparse X only)
     int *csc_ptr;       // [n_cols+1]
     int *csc_row;       // [nnz] source row of each entry

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
     constexpr int LPR = T_BK / VX;                        // lanes per A row
     constexpr int A_PIECES = T_BM * T_BK / (256 * VX);
     float areg[A_PIECES][VX];
-    uint32_t kreg[A_PIECES];                              // keep bits, applied in stash(): the multiply must not
+    uint64_t kreg[A_PIECES];                              // keep bits, applied in stash(): the multiply must not
     float4 breg[4];                                       // wait for the loads before the MFMA loop starts
 
     auto fetch = [&](int k0) {
@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
             for (int s = 0; s < VX; s++) areg[pc][s] = 0.f;
             if (row < a.m && col < a.K) {
                 load_vec_t<VX>(a.x + (size_t)row * a.ldx + col, a.K - col, areg[pc]);
-                if (a.bits) kreg[pc] = a.bits[((uint64_t)row * a.K + col) >> 5];      // raw word: no ALU on it here
+                if (a.bits) {                                   // raw words: no ALU on them here
+                    const uint64_t w = ((uint64_t)row * a.K + col) >> 5;
+                    kreg[pc] = a.bits[w];
+                    // rows padded to 16 bytes but K % VX != 0: the VX bits may straddle two words
+                    if (a.K % VX != 0) kreg[pc] |= (uint64_t)a.bits[w + 1] << 32;
+                }
             }
         }
 #pragma unroll
@@ -124,8 +129,7 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
             const int r = idx / LPR, c = (idx % LPR) * VX;
-            // element index of (row, col) is a multiple of VX, so its VX bits sit in one word
-            const uint32_t kb = a.bits ? kreg[pc] >> (uint32_t)(((uint64_t)(row_base + r) * a.K + cur_k0 + c) & 31) : 0xFu;
+            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)(row_base + r) * a.K + cur_k0 + c) & 31)) : 0xFu;
 #pragma unroll
             for (int s = 0; s < VX; s++)
                 As[r * T_ALD + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
     constexpr int LPR = 128 / VX;
     constexpr int A_PIECES = T_BK * 128 / (256 * VX);
     float areg[A_PIECES][VX];
-    uint32_t kreg[A_PIECES];
+    uint64_t kreg[A_PIECES];
     float4 breg[4];
 
     auto fetch = [&](int r0) {
@@ -207,7 +211,12 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
             for (int s = 0; s < VX; s++) areg[pc][s] = 0.f;
             if (row < r_end && col < a.K) {
                 load_vec_t<VX>(a.x + (size_t)row * a.ldx + col, a.K - col, areg[pc]);
-                if (a.bits) kreg[pc] = a.bits[((uint64_t)row * a.K + col) >> 5];      // raw word: no ALU on it here
+                if (a.bits) {                                   // raw words: no ALU on them here
+                    const uint64_t w = ((uint64_t)row * a.K + col) >> 5;
+                    kreg[pc] = a.bits[w];
+                    // rows padded to 16 bytes but K % VX != 0: the VX bits may straddle two words
+                    if (a.K % VX != 0) kreg[pc] |= (uint64_t)a.bits[w + 1] << 32;
+                }
             }
         }
 #pragma unroll
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
             const int k = idx / LPR, c = (idx % LPR) * VX;
-            const uint32_t kb = a.bits ? kreg[pc] >> (uint32_t)(((uint64_t)(cur_r0 + k) * a.K + xc_base + c) & 31) : 0xFu;
+            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)(cur_r0 + k) * a.K + xc_base + c) & 31)) : 0xFu;
 #pragma unroll
             for (int s = 0; s < VX; s++)
                 As[k * 128 + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];

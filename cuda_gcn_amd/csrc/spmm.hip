@@ -331,9 +331,10 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
         Tile128Args t;
         t.x = vals; t.ldx = f->n_cols; t.w = w; t.ldw = ld_w; t.out = out; t.ldo = ld_out;
+        int vx = x_vec_width(f, vals);
+        if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }   // aligned copy of the pristine X
         t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = 0;
         dim3 grid(ceil_div(f->n_rows, T_BM), ceil_div(p, T_BN));
-        const int vx = x_vec_width(f, vals);
         if (vx == 4) dense_fwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
         else if (vx == 2) dense_fwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
         else dense_fwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
@@ -394,9 +395,10 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         if (rc) return rc;
         Tile128Args t;
         t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
+        int vx = x_vec_width(f, vals);
+        if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }
         t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps;
         dim3 grid(S, kt, pt);
-        const int vx = x_vec_width(f, vals);
         if (vx == 4) dense_bwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
         else if (vx == 2) dense_bwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
         else dense_bwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);

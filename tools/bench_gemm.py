@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cuda_gcn_amd.ops import Device, _ck
 from tools.bench_ops import timeit
-N, F, h = 232965, 602, 128
+N, F, h = 232965, (int(sys.argv[1]) if len(sys.argv) > 1 else 602), 128
 dev = Device(0); lib = dev.lib
 rng = np.random.default_rng(0)
 x = rng.standard_normal(N * F, dtype=np.float32)
