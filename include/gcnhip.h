@@ -28,6 +28,9 @@
  *    vectorised kernels; any other ld takes a slower scalar-load kernel with the
  *    same results.
  *  - indices are int32 like the reference (src/seq/sparse.h:12-17).
+ *  - limits (argument error -1 beyond them): gcnhip_xent_fwd / gcnhip_accuracy up to 256 classes;
+ *    gcnhip_matmul_* keep the small operand in LDS (gfx950: 160 KiB per CU), i.e. inner dimension
+ *    n <= 736 for p <= 48 output columns (and any n for the backward); element counts below 2^31.
  */
 #ifndef GCNHIP_H
 #define GCNHIP_H
