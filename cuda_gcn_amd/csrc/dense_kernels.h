@@ -300,8 +300,13 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     const int VB = (ldb % 4 == 0 && aligned16(Bm)) ? 4 : ((ldb % 2 == 0 && ((uintptr_t)Bm & 7) == 0) ? 2 : 1);
     const int gy = ceil_div(n, 16 * VA), gz = ceil_div(p, 16 * VB);
     // enough split-K workers to fill the chip (~8 waves per CU), at least 64 rows each
-    int workers = ceil_div((int64_t)c->n_cu * 4, (int64_t)gy * gz);
-    if (workers > ceil_div(m, 64)) workers = ceil_div(m, 64);
+    // split-K workers: ~4 waves per CU when the partial slabs are large, up to 16 when they are small
+    // (narrow outputs are latency-bound: more waves in flight hide the dependent row loads)
+    const size_t slab_per_worker = (size_t)n * a.p_ld * sizeof(float);
+    int per_cu = slab_per_worker <= (256u << 10) ? 16 : 4;
+    int workers = ceil_div((int64_t)c->n_cu * per_cu, (int64_t)gy * gz);
+    while (workers > 4 && (size_t)workers * slab_per_worker > (12u << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials
+    if (workers > ceil_div(m, 256)) workers = ceil_div(m, 256);      // at least 64 K-steps per worker
     if (workers < 1) workers = 1;
     workers = (workers + 3) / 4 * 4;
     a.rows_per_worker = (ceil_div(m, workers) + 3) / 4 * 4;

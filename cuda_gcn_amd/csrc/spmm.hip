@@ -411,7 +411,7 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
     }
     if (f->dense)
         return launch_atb(c, vals, f->n_cols, dout, ld_dout, dw, ld_dw, f->n_rows, f->n_cols, p,
-                          d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask);
+                          d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask);   // narrow outputs (p <= 64)
     SpBwdArgs a;
     a.csc_ptr = f->csc_ptr; a.csc_row = f->csc_row; a.csc_pos = f->csc_pos;
     a.vals = vals; a.dout = dout; a.dw = dw;
