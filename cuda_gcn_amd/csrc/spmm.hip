@@ -167,7 +167,8 @@ struct DenseFwdArgs {
     const float *w; int ldw;
     float *out; int ldo;
     int m, K, p;
-    DropSpec d;
+    const uint32_t *bits;           // keep bits of the stored elements (dropbits_kernel), NULL: no dropout
+    float scale;
 };
 
 constexpr int DF_BM = 128, DF_BK = 32;
@@ -183,12 +184,12 @@ __global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
     const int li = lane & 15, kq = lane >> 4;
     const int row_base = blockIdx.x * DF_BM;
     const int col_base = blockIdx.y * BN;
-    const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
 
     // staging maps.  A: 128 x 32 floats = 4096; VX floats per lane per piece.
     constexpr int A_PIECES = DF_BM * DF_BK / (256 * VX);
     constexpr int LPR = DF_BK / VX;                       // lanes per A row
     float areg[A_PIECES][VX];
+    uint64_t kreg[A_PIECES];        // raw keep-bit words; applied in stash() so that no ALU sits behind the loads
     // B: 32 x BN floats, 4 per lane per piece (W rows are 16-byte aligned when ldw % 4 == 0; else scalar)
     constexpr int B_PIECES = (DF_BK * BN + 1023) / 1024;
     float breg[B_PIECES][4];
@@ -203,20 +204,10 @@ __global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
             for (int s = 0; s < VX; s++) areg[pc][s] = 0.f;
             if (row < a.m && col < a.K) {
                 load_vec<VX>(a.x + (size_t)row * a.ldx + col, a.K - col, areg[pc]);
-                if (a.d.on) {
-                    const uint64_t e = (uint64_t)row * a.K + col;
-                    uint32_t bits = 0;
-                    if (a.d.keep_mask) {
-#pragma unroll
-                        for (int s = 0; s < VX; s++) bits |= (col + s < a.K && a.d.keep_mask[e + s] != 0 ? 1u : 0u) << s;
-                    } else if (((a.d.off + e) & (VX - 1)) == 0) {
-                        bits = keepv<VX>(a.d.off + e, epoch, a.d.seed, a.d.thr);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < VX; s++) bits |= (keep1(a.d.off + e + s, epoch, a.d.seed, a.d.thr) ? 1u : 0u) << s;
-                    }
-#pragma unroll
-                    for (int s = 0; s < VX; s++) areg[pc][s] *= (bits >> s & 1u) ? a.d.scale : 0.f;
+                if (a.bits) {
+                    const uint64_t w = ((uint64_t)row * a.K + col) >> 5;
+                    kreg[pc] = a.bits[w];
+                    if (a.K % VX != 0) kreg[pc] |= (uint64_t)a.bits[w + 1] << 32;
                 }
             }
         }
@@ -231,13 +222,15 @@ __global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int cur_k0) {
 #pragma unroll
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
             const int r = idx / LPR, c = (idx % LPR) * VX;
+            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)(row_base + r) * a.K + cur_k0 + c) & 31)) : 0xFu;
 #pragma unroll
-            for (int s = 0; s < VX; s++) As[r * DF_ALD + c + s] = areg[pc][s];
+            for (int s = 0; s < VX; s++)
+                As[r * DF_ALD + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
         }
 #pragma unroll
         for (int pc = 0; pc < B_PIECES; pc++) {
@@ -259,7 +252,7 @@ __global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
     fetch(0);
     for (int k0 = 0; k0 < a.K; k0 += DF_BK) {
         __syncthreads();                 // previous chunk fully consumed
-        stash();
+        stash(k0);
         __syncthreads();
         if (k0 + DF_BK < a.K) fetch(k0 + DF_BK);
 #pragma unroll
@@ -342,10 +335,12 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         return 0;
     }
     if (f->dense) {
+        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
         DenseFwdArgs a;
         a.x = vals; a.ldx = f->n_cols; a.w = w; a.ldw = ld_w; a.out = out; a.ldo = ld_out;
-        a.m = f->n_rows; a.K = f->n_cols; a.p = p; a.d = d;
-        const int vx = (f->n_cols % 4 == 0 && aligned16(vals)) ? 4 : ((f->n_cols % 2 == 0 && ((uintptr_t)vals & 7) == 0) ? 2 : 1);
+        a.m = f->n_rows; a.K = f->n_cols; a.p = p; a.bits = d.on ? f->keep_bits : nullptr; a.scale = d.scale;
+        int vx = x_vec_width(f, vals);
+        if (vals == f->values && f->values_pad) { a.x = f->values_pad; a.ldx = f->ld_pad; vx = 4; }
         const int nt_total = ceil_div(p, 16);
         const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 2 ? 4 : nt_total));
         dim3 grid(ceil_div(f->n_rows, DF_BM), ceil_div(nt_total, NT));
