@@ -61,7 +61,10 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &feat, lp.data(), fi.empty() ? nullptr : fi.data() + f0,
                                         data->feature_value.data() + f0, n_local, F));
     }
-    replicate_l1 = world > 1 && !(flags & (HIPGCN_NO_REPLICATE_L1 | HIPGCN_MODULAR));
+    // Replicating X.W1 trades a 119 MB all-gather per forward for 0.4 ms of extra GEMM on every rank.  With 2-4
+    // GPUs each rank receives over 1-3 xGMI links (~60 GB/s each) and the GEMM is cheaper; with 8 GPUs seven
+    // links feed the gather (~0.3 ms) while the replicated GEMMs would be 45 % of the per-rank compute.
+    replicate_l1 = world > 1 && (world <= 4 || (flags & HIPGCN_REPLICATE_L1)) && !(flags & (HIPGCN_NO_REPLICATE_L1 | HIPGCN_MODULAR));
     if (replicate_l1) {
         GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &feat_full, fp.data(), fi.empty() ? nullptr : fi.data(),
                                         data->feature_value.data(), N, F));

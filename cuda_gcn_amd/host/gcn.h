@@ -38,6 +38,7 @@ enum HipGCNFlags {
     HIPGCN_EVAL_LANE = 16,    // validation forward on a second stream, overlapped with the next training epoch
     HIPGCN_NO_EVAL_LANE = 32, // never (default: on when world > 1, where it hides the all-gathers)
     HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
+    HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
 };
 
 struct HipGCNOptions {

@@ -36,7 +36,8 @@ enum {
     GCNHOST_NO_GRAPH = 8,     /* run_epochs never replays a captured hipGraph */
     GCNHOST_EVAL_LANE = 16,   /* validation forward on a second stream, overlapped with the next training epoch */
     GCNHOST_NO_EVAL_LANE = 32, /* never (default: on when world > 1) */
-    GCNHOST_NO_REPLICATE_L1 = 64 /* multi-GPU: all-gather H0 instead of replicating the first-layer product */
+    GCNHOST_NO_REPLICATE_L1 = 64, /* multi-GPU: all-gather H0 instead of replicating the first-layer product */
+    GCNHOST_REPLICATE_L1 = 128    /* force the replication (default: on for 2-4 GPUs, off for 8) */
 };
 
 #define GCNHOST_NCCL_ID_BYTES 128
