@@ -32,6 +32,7 @@ struct RowStreamArgs {
     int m, K, Nc;
     // epilogue: C = H > 0 ? scale*C : 0
     const float *H; int ldh; float scale;
+    const uint32_t *hbits; int wpr;             // alternative mask source: bit (c & 31) of hbits[r*wpr + (c >> 5)] = (H[r,c] > 0)
     int vec_out;                                // C (and H) rows are 16-byte aligned: LDS-staged row stores
 };
 
@@ -128,16 +129,27 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                     float *cp = a.C + (size_t)r * a.ldc + col;
                     if (col + 4 <= a.Nc) {
                         if (FUSE) {
-                            const float4 h = *reinterpret_cast<const float4 *>(a.H + (size_t)r * a.ldh + col);
-                            v.x = h.x > 0.f ? v.x * a.scale : 0.f; v.y = h.y > 0.f ? v.y * a.scale : 0.f;
-                            v.z = h.z > 0.f ? v.z * a.scale : 0.f; v.w = h.w > 0.f ? v.w * a.scale : 0.f;
+                            if (a.hbits) {                  // col % 4 == 0: the four bits sit in one word
+                                const uint32_t kb = a.hbits[(size_t)r * a.wpr + (col >> 5)] >> (col & 31);
+                                v.x = (kb & 1u) ? v.x * a.scale : 0.f; v.y = (kb & 2u) ? v.y * a.scale : 0.f;
+                                v.z = (kb & 4u) ? v.z * a.scale : 0.f; v.w = (kb & 8u) ? v.w * a.scale : 0.f;
+                            } else {
+                                const float4 h = *reinterpret_cast<const float4 *>(a.H + (size_t)r * a.ldh + col);
+                                v.x = h.x > 0.f ? v.x * a.scale : 0.f; v.y = h.y > 0.f ? v.y * a.scale : 0.f;
+                                v.z = h.z > 0.f ? v.z * a.scale : 0.f; v.w = h.w > 0.f ? v.w * a.scale : 0.f;
+                            }
                         }
                         *reinterpret_cast<float4 *>(cp) = v;
                     } else {
                         const float x[4] = {v.x, v.y, v.z, v.w};
                         for (int q = 0; col + q < a.Nc; q++) {
                             float y = x[q];
-                            if (FUSE) y = a.H[(size_t)r * a.ldh + col + q] > 0.f ? y * a.scale : 0.f;
+                            if (FUSE) {
+                                const int cq = col + q;
+                                const bool pos = a.hbits ? ((a.hbits[(size_t)r * a.wpr + (cq >> 5)] >> (cq & 31)) & 1u) != 0
+                                                         : a.H[(size_t)r * a.ldh + cq] > 0.f;
+                                y = pos ? y * a.scale : 0.f;
+                            }
                             cp[q] = y;
                         }
                     }
@@ -154,7 +166,11 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                     const int r = tile * 16 + 4 * kq + i;
                     if (r >= a.m) continue;
                     float v = acc[t][i];
-                    if (FUSE) v = a.H[(size_t)r * a.ldh + col] > 0.f ? v * a.scale : 0.f;
+                    if (FUSE) {
+                        const bool pos = a.hbits ? ((a.hbits[(size_t)r * a.wpr + (col >> 5)] >> (col & 31)) & 1u) != 0
+                                                 : a.H[(size_t)r * a.ldh + col] > 0.f;
+                        v = pos ? v * a.scale : 0.f;
+                    }
                     a.C[(size_t)r * a.ldc + col] = v;
                 }
             }
@@ -336,11 +352,13 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
 
 // C[m x Nc] = A[m x K] . Bs  (Bs from B, optionally transposed), optional epilogue
 static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float *B, int ldb, int transB,
-                            float *C, int ldc, int m, int K, int Nc, const float *H, int ldh, float scale) {
+                            float *C, int ldc, int m, int K, int Nc, const float *H, int ldh, float scale,
+                            const uint32_t *hbits = nullptr, int wpr = 0) {
     RowStreamArgs a;
+    a.hbits = hbits; a.wpr = wpr;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.transB = transB; a.C = C; a.ldc = ldc;
     a.m = m; a.K = K; a.Nc = Nc; a.H = H; a.ldh = ldh; a.scale = scale;
-    a.vec_out = (Nc >= 64 && ldc % 4 == 0 && aligned16(C) && (!H || (ldh % 4 == 0 && aligned16(H)))) ? 1 : 0;
+    a.vec_out = (Nc >= 64 && ldc % 4 == 0 && aligned16(C) && (!H || hbits || (ldh % 4 == 0 && aligned16(H)))) ? 1 : 0;
     const bool vec = lda % 4 == 0 && aligned16(A);
     const int nt_total = ceil_div(Nc, 16);
     const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 3 ? 4 : nt_total));
@@ -371,7 +389,7 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
     } while (0)
 #define RS(NT_)                                                                                           \
     do {                                                                                                  \
-        if (H) {                                                                                          \
+        if (H || hbits) {                                                                                 \
             if (vec) RS1(NT_, true, true); else RS1(NT_, false, true);                                    \
         } else {                                                                                          \
             if (vec) RS1(NT_, true, false); else RS1(NT_, false, false);                                  \

@@ -138,6 +138,22 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 }
 
+// bits[r*wpr + (c >> 5)] bit (c & 31) = h[r, c] > 0 — one wave per row, one ballot per 64 columns
+__global__ __launch_bounds__(256) void pack_positive_kernel(const float *h, int ld, int n_rows, int dim, uint32_t *bits, int wpr) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    for (int c0 = 0; c0 < wpr * 32; c0 += 64) {
+        const int c = c0 + lane;
+        const bool pos = c < dim && h[(size_t)r * ld + c] > 0.f;
+        const unsigned long long b = __ballot(pos);
+        if (lane == 0) {
+            bits[(size_t)r * wpr + (c0 >> 5)] = (uint32_t)b;
+            if ((c0 >> 5) + 1 < wpr) bits[(size_t)r * wpr + (c0 >> 5) + 1] = (uint32_t)(b >> 32);
+        }
+    }
+}
+
 // ----------------------------------------------------------- small utilities
 __global__ void counter_add_kernel(uint32_t *c, uint32_t inc) { *c += inc; }
 __global__ void metrics_record_kernel(float *ring, int capacity, int slot, const uint32_t *d_epoch,
@@ -191,6 +207,13 @@ int gcnhip_relu_dropout_bwd(gcnhip_ctx *c, float *grad, int ld_grad, const float
     if (!c || !grad || !h || ld_grad < dim || ld_h < dim) return -1;
     if (n_rows <= 0 || dim <= 0) return 0;
     relu_dropout_bwd_kernel<<<stream_grid((int64_t)n_rows * dim, 1024), 256, 0, c->stream>>>(grad, ld_grad, h, ld_h, n_rows, dim, scale);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_pack_positive(gcnhip_ctx *c, const float *h, int ld, int n_rows, int dim, uint32_t *bits, int words_per_row) {
+    if (!c || !h || !bits || ld < dim || dim <= 0 || words_per_row * 32 < dim) return -1;
+    if (n_rows <= 0) return 0;
+    pack_positive_kernel<<<ceil_div(n_rows, 4), 256, 0, c->stream>>>(h, ld, n_rows, dim, bits, words_per_row);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -47,4 +47,15 @@ int gcnhip_matmul_bwd_fused(gcnhip_ctx *c, const float *a, int lda, const float 
     return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, da, ldda, db, lddb, m, n, p, 1, relu_dropout_scale);
 }
 
+// da for ALL m rows from a bit mask instead of the forward activations (multi-GPU: every rank rebuilds the
+// whole dH1 from the gathered dZ0 and 1 bit per element of H1, instead of gathering dH1 itself)
+int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *c, const float *b, int ldb, const float *dc, int lddc,
+                              float *da, int ldda, int m, int n, int p,
+                              const uint32_t *h_pos_bits, int words_per_row, float scale) {
+    if (!c || !b || !dc || !da || !h_pos_bits || m < 0 || n <= 0 || p <= 0 || ldb < p || lddc < p || ldda < n) return -1;
+    if (words_per_row * 32 < n) return -1;
+    if (m == 0) return 0;
+    return launch_rowstream(c, dc, lddc, b, ldb, 1, da, ldda, m, p, n, nullptr, 0, scale, h_pos_bits, words_per_row);
+}
+
 }  // extern "C"

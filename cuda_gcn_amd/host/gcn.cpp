@@ -118,7 +118,8 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     if (replicate_l1) variables[1]->alloc_replicated(env.ctx, N, n_local, r0, H, true);   // H0: every row computed here
     else variables[1]->alloc(env.ctx, n_local, H, true, true, false, world, rank, rm);    // H0: data gathered
     variables[3]->alloc(env.ctx, n_local, H, true, false, true, world, rank, rm);    // H1: grad gathered
-    variables[4]->alloc(env.ctx, n_local, C, true, true, false, world, rank, rm);    // Z0: data gathered
+    rebuild_dh1 = world > 1 && !(flags & (HIPGCN_GATHER_DH1 | HIPGCN_MODULAR));
+    variables[4]->alloc(env.ctx, n_local, C, true, true, rebuild_dh1, world, rank, rm);   // Z0: data gathered (+ grad when dH1 is rebuilt)
     variables[6]->alloc(env.ctx, n_local, C, true, false, true, world, rank, rm);    // Z : grad gathered
     output = variables[6].get();
     HipVariable *W1 = variables[2].get(), *W2 = variables[5].get();
@@ -202,14 +203,20 @@ void HipGCN::build_modules() {
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, true));
     } else {
         const float scale = 1 / (1 - p);
-        {
-            auto *sm = new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, p, nnz_off);
-            auto *gs = new HipGraphSum(&env, H0, H1, graph, H, p, hid_off);
-            if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = graph_l1; }
-            modules.push_back(sm);
-            modules.push_back(gs);
+        auto *sm = new HipSparseMatmul(&env, &input_vals, W1, H0, feat, N, F, H, p, nnz_off);
+        auto *gs = new HipGraphSum(&env, H0, H1, graph, H, p, hid_off);
+        auto *mm = new HipMatmul(&env, H1, W2, Z0, N, H, C, scale);
+        if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = graph_l1; }
+        if (rebuild_dh1) {
+            const int world = env.comm->size(), wpr = (H + 31) / 32;
+            d_pos_bits = dev_upload(env.ctx, std::vector<uint32_t>((size_t)world * part.rows_max * wpr, 0u).data(),
+                                    (size_t)world * part.rows_max * wpr);
+            gs->pos_bits_full = d_pos_bits; gs->wpr = wpr; gs->rows_max = part.rows_max; gs->out_grad_complete = true;
+            mm->pos_bits_full = d_pos_bits; mm->wpr = wpr; mm->all_rows = world * part.rows_max;
         }
-        modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C, scale));
+        modules.push_back(sm);
+        modules.push_back(gs);
+        modules.push_back(mm);
         { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
     }
@@ -307,6 +314,7 @@ HipGCN::~HipGCN() {
     gcnhip_free(env.ctx, d_keep0);
     gcnhip_free(env.ctx, d_keep1);
     gcnhip_free(env.ctx, d_train_bits);
+    gcnhip_free(env.ctx, d_pos_bits);
     timers.reset();
     owned_comm.reset();
     gcnhip_ctx_destroy(env.ctx);

@@ -39,6 +39,7 @@ enum HipGCNFlags {
     HIPGCN_NO_EVAL_LANE = 32, // never (default: on when world > 1, where it hides the all-gathers)
     HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
     HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
+    HIPGCN_GATHER_DH1 = 256,     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
 
 struct HipGCNOptions {
@@ -106,6 +107,8 @@ private:
     gcnhip_graph *graph_l1 = nullptr;                          // this rank's rows, GLOBAL column ids
     const float *full_vals = nullptr;
     bool replicate_l1 = false;
+    bool rebuild_dh1 = false;                                  // multi-GPU backward: gather dZ0 + mask bits, rebuild dH1 everywhere
+    uint32_t *d_pos_bits = nullptr;                            // [world * rows_max * wpr]
     std::vector<std::unique_ptr<HipVariable>> variables;       // index = reference variable number
     HipVariable *input = nullptr, *output = nullptr;
     const float *input_vals = nullptr;                         // what SparseMatmul reads

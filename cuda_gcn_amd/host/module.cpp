@@ -13,7 +13,18 @@ void HipMatmul::forward(bool) {
 
 void HipMatmul::backward() {
     env->timers->start(TMR_MATMUL_BW);
-    if (fused_bwd_scale > 0.f)
+    if (pos_bits_full) {
+        // db from this rank's rows; da for every row of every rank from the gathered dc and mask bits
+        GCNHIP_CHECK(gcnhip_matmul_bwd(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
+                                       nullptr, a->ld, b->grad, b->ld, m, n, p));
+        env->timers->stop(TMR_MATMUL_BW);
+        env->timers->start(TMR_COMM);
+        env->comm->allgather_rows(c->full_grad, c->full_elems / env->comm->size());
+        env->timers->stop(TMR_COMM);
+        env->timers->start(TMR_MATMUL_BW);
+        GCNHIP_CHECK(gcnhip_matmul_bwd_da_bits(env->ctx, b->data, b->ld, c->full_grad, c->ld, a->full_grad, a->ld,
+                                               all_rows, n, p, pos_bits_full, wpr, fused_bwd_scale));
+    } else if (fused_bwd_scale > 0.f)
         GCNHIP_CHECK(gcnhip_matmul_bwd_fused(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                              a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale));
     else
@@ -77,11 +88,19 @@ void HipGraphSum::forward(bool training) {
         GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
     if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
     env->timers->stop(TMR_GRAPHSUM_FW);
+    if (pos_bits_full && training) {
+        uint32_t *mine = pos_bits_full + (size_t)env->comm->rank() * rows_max * wpr;
+        GCNHIP_CHECK(gcnhip_pack_positive(env->ctx, out->data, out->ld, out->rows, dim, mine, wpr));
+        env->timers->start(TMR_COMM);
+        env->comm->allgather_rows(reinterpret_cast<float *>(pos_bits_full), (size_t)rows_max * wpr);   // bytes are moved, not interpreted
+        env->timers->stop(TMR_COMM);
+    }
 }
 
 void HipGraphSum::backward() {
-    // same operator on the gradients (symmetric adjacency, module.cpp:103-119); out->grad is gathered
-    if (env->comm->size() > 1) {
+    // same operator on the gradients (symmetric adjacency, module.cpp:103-119); out->grad is gathered,
+    // unless every rank has already rebuilt all of it
+    if (env->comm->size() > 1 && !out_grad_complete) {
         env->timers->start(TMR_COMM);
         env->comm->allgather_rows(out->full_grad, out->full_elems / env->comm->size());
         env->timers->stop(TMR_COMM);

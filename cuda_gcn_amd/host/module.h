@@ -43,6 +43,10 @@ class HipMatmul : public Module {
     int m, n, p;
     float fused_bwd_scale;          // > 0: da = (a > 0) ? scale * da : 0 (ReLU+Dropout backward folded in)
 public:
+    // multi-GPU: instead of all-gathering da (n floats per row) the ranks all-gather dc (p floats per row) and
+    // one bit per element of a > 0, and every rank rebuilds da for ALL rows (gcnhip_matmul_bwd_da_bits)
+    const uint32_t *pos_bits_full = nullptr;    // [all_rows x wpr], gathered by the producer of `a`
+    int wpr = 0, all_rows = 0;
     HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
     void forward(bool) override;
     void backward() override;
@@ -76,6 +80,11 @@ class HipGraphSum : public Module {
     uint64_t elem_offset;           // global element index of this rank's first output element
 public:
     gcnhip_graph *fwd_graph_replicated = nullptr;   // global column ids: forward reads a replicated `in` without a gather
+    // multi-GPU, first layer: after a training forward publish bit = (out > 0) of this rank's rows to every rank;
+    // in exchange backward() finds out->full_grad already complete (rebuilt locally) and gathers nothing
+    uint32_t *pos_bits_full = nullptr;
+    int wpr = 0, rows_max = 0;
+    bool out_grad_complete = false;
     // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
     const uint32_t *const *bwd_row_bits = nullptr;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,

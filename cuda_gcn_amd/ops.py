@@ -188,6 +188,29 @@ class Device:
                                                             m, n, p, fused_scale), "gcnhip_matmul_bwd_fused")
         return da.download()[:, :n], db.download()[:, :p]
 
+    def pack_positive(self, h, ld=None):
+        """bit (r, c) = h[r, c] > 0, 32 columns per little-endian word -> uint32 [rows, ceil(dim/32)]"""
+        h = np.asarray(h, np.float32)
+        rows, dim = h.shape
+        ld = ld or dim
+        wpr = (dim + 31) // 32
+        hb = self.padded(h, ld)
+        bits = self.buf(np.full((rows, wpr), 0xFFFFFFFF, np.uint32))
+        _ck(self.lib, self.lib.gcnhip_pack_positive(self.ctx, hb.ptr, ld, rows, dim, bits.ptr, wpr), "gcnhip_pack_positive")
+        return bits.download()
+
+    def matmul_bwd_da_bits(self, b, dc, bits, scale, ldb=None, lddc=None, ldda=None):
+        b, dc = np.asarray(b, np.float32), np.asarray(dc, np.float32)
+        bits = np.ascontiguousarray(bits, np.uint32)
+        n, p = b.shape
+        m = dc.shape[0]
+        ldb, lddc, ldda = ldb or p, lddc or p, ldda or n
+        bb, dcb, bt = self.padded(b, ldb), self.padded(dc, lddc), self.buf(bits)
+        da = self.buf(np.full((m, ldda), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_matmul_bwd_da_bits(self.ctx, bb.ptr, ldb, dcb.ptr, lddc, da.ptr, ldda, m, n, p,
+                                                          bt.ptr, bits.shape[1], scale), "gcnhip_matmul_bwd_da_bits")
+        return da.download()[:, :n]
+
     def relu_fwd(self, x, training=True):
         x = np.ascontiguousarray(x, np.float32).reshape(-1)
         xb = self.buf(x)

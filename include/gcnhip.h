@@ -154,6 +154,15 @@ int gcnhip_matmul_bwd_fused(gcnhip_ctx *ctx, const float *a, int lda, const floa
                             const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
                             int m, int n, int p, float relu_dropout_scale);
 
+/* Multi-GPU form of the same backward.  dH1 = mask . (dZ0 . W2^T) is cheap to recompute and 128 floats wide,
+ * while its inputs are 48 floats (dZ0) and 1 bit per element (mask = H1 > 0): ranks all-gather those and each
+ * rebuilds dH1 for every row.  gcnhip_pack_positive writes bit (c & 31) of bits[r*words_per_row + (c >> 5)] =
+ * (h[r,c] > 0); gcnhip_matmul_bwd_da_bits computes da[m x n] = bit ? scale * (dc . b^T) : 0 for all m rows. */
+int gcnhip_pack_positive(gcnhip_ctx *ctx, const float *h, int ld, int n_rows, int dim, uint32_t *bits, int words_per_row);
+int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *ctx, const float *b, int ldb, const float *dc, int lddc,
+                              float *da, int ldda, int m, int n, int p,
+                              const uint32_t *h_pos_bits, int words_per_row, float scale);
+
 /* ---- ReLU (CUDAReLU: cuda_module.cu:164-186; cuda_kernel.cu:204-219) ---------
  * mask: one byte per element, written only when training (module.cpp:180). */
 int gcnhip_relu_fwd(gcnhip_ctx *ctx, float *x, uint8_t *mask, int64_t n, int training);

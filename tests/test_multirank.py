@@ -62,6 +62,9 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
     ("cora-syn", 2, 0.5, 1, 64),        # NO_REPLICATE_L1: H0 all-gathered instead of recomputed on every rank
     ("tiny-syn", 3, 0.5, 0, 64 | 32),   # ... and no validation lane
     ("cora-syn", 2, 0.5, 0, 2),         # HOST_MASKS: the reference's RNG stream sliced per rank
+    ("cora-syn", 2, 0.5, 1, 256),       # GATHER_DH1: all-gather dH1 instead of dZ0 + mask bits
+    ("tiny-syn", 3, 0.0, 0, 256 | 64),
+    ("reddit-mini", 2, 0.5, 1, 256),
     ("reddit-mini", 2, 0.5, 1, 0),      # dense 602-column X, hidden 128, hub rows: the bench's shapes at 1/10 scale
 ])
 def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, flags):

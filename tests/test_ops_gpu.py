@@ -288,6 +288,28 @@ def test_matmul_vs_oracle(dev, oracle, m, n, p, pad):
     close_mag(db2, ob, mb)
 
 
+@pytest.mark.parametrize("m,n,p", [(1000, 128, 41), (333, 16, 7), (70000, 128, 41), (65, 70, 3), (1, 1, 1), (4097, 200, 47)])
+def test_pack_positive_and_da_from_bits(dev, m, n, p):
+    """multi-GPU backward: the ReLU/dropout mask travels as one bit per element and
+    da = bit ? scale * (dc . b^T) : 0 must equal the fused backward that reads h itself"""
+    rng = np.random.default_rng(m * 7 + n)
+    h = rng.standard_normal((m, n)).astype(np.float32)
+    h[rng.random((m, n)) < 0.3] = 0
+    h[0, 0] = -0.0
+    ld = (n + 15) // 16 * 16
+    bits = dev.pack_positive(h, ld=ld)
+    want = np.zeros((m, (n + 31) // 32), np.uint32)
+    for c in range(n):
+        want[:, c // 32] |= (h[:, c] > 0).astype(np.uint32) << np.uint32(c % 32)
+    assert np.array_equal(bits, want)
+    b = rng.standard_normal((n, p)).astype(np.float32)
+    dc = rng.standard_normal((m, p)).astype(np.float32)
+    ldb = (p + 3) // 4 * 4 if p <= 32 else (p + 15) // 16 * 16
+    da_bits = dev.matmul_bwd_da_bits(b, dc, bits, 2.0, ldb=ldb, lddc=ldb, ldda=ld)
+    da_fused, _ = dev.matmul_bwd(h, b, dc, lda=ld, ldb=ldb, lddc=ldb, fused_scale=2.0)
+    assert np.array_equal(da_bits, da_fused)           # same kernel, same order: bit-identical
+
+
 @pytest.mark.parametrize("shape", [(34, 16, 7), (97, 128, 41), (5, 3, 2), (1, 1, 1)])
 def test_matmul_golden(dev, mods, shape):
     m, n, p = shape
