@@ -79,6 +79,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_d2h": (I, [P, P, P, C.c_size_t]),
     "gcnhip_d2d_async": (I, [P, P, P, C.c_size_t]),
     "gcnhip_graph_create": (I, [P, C.POINTER(P), P, P, I, I, P]),
+    "gcnhip_graph_create_grouped": (I, [P, C.POINTER(P), P, P, I, I, P, P]),
     "gcnhip_graph_destroy": (I, [P, P]),
     "gcnhip_graph_arrays": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
     "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),

@@ -155,6 +155,11 @@ extern "C" {
 
 int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, const int *h_indices,
                         int n_rows, int n_cols, const int *h_col_deg) {
+    return gcnhip_graph_create_grouped(c, out, h_indptr, h_indices, n_rows, n_cols, h_col_deg, nullptr);
+}
+
+int gcnhip_graph_create_grouped(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, const int *h_indices,
+                                int n_rows, int n_cols, const int *h_col_deg, const int *h_row_group) {
     if (!c || !out || !h_indptr || n_rows < 0) return -1;
     if (!h_col_deg && n_cols != n_rows) return -1;
     GCNHIP_TRY(hipSetDevice(c->device));
@@ -200,11 +205,13 @@ int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, 
     GCNHIP_TRY(hipStreamSynchronize(c->stream));
     if (d_col_deg) GCNHIP_TRY(hipFree(d_col_deg));
 
-    // Task list: rows in descending degree order (heavy work first, similar rows together); a row
+    // Task list: rows in descending degree order (heavy work first, similar rows together), group-major
+    // when the caller names communities; a row
     // above SPLIT_EDGES becomes consecutive segments whose partial sums a second kernel adds in order.
     std::vector<int> order(n_rows);
     for (int r = 0; r < n_rows; r++) order[r] = r;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (h_row_group && h_row_group[a] != h_row_group[b]) return h_row_group[a] < h_row_group[b];
         return h_indptr[a + 1] - h_indptr[a] > h_indptr[b + 1] - h_indptr[b];
     });
     int n_slots = 0;

@@ -166,6 +166,10 @@ int gcnhost_rccl_selftest(int device) {
             gcnhip_free(ctx, d);
             for (int i = 0; i < 1024; i++)
                 if (back[i] != h[i]) throw GcnHipFailure(-1, "RCCL self-test: data changed in a one-rank collective");
+            void *sa;
+            GCNHIP_CHECK(gcnhip_malloc(ctx, &sa, 256 * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_memset_async(ctx, sa, 0, 256 * sizeof(float)));
+            float *scratch_a = (float *)sa;
             double v[2] = {3.0, 4.0};
             comm->allreduce_sum_host(v, 2);
             if (v[0] != 3.0 || v[1] != 4.0) throw GcnHipFailure(-1, "RCCL self-test: host reduction");
@@ -177,8 +181,22 @@ int gcnhost_rccl_selftest(int device) {
                 double w2[1] = {5.0};
                 comm2->allreduce_sum_host(w2, 1);
                 if (w2[0] != 5.0) throw GcnHipFailure(-1, "RCCL self-test: split communicator");
+                // collectives alternating between the two lanes (serialised by the turnstile event)
+                void *d2;
+                GCNHIP_CHECK(gcnhip_malloc(ctx2, &d2, 256 * sizeof(float)));
+                GCNHIP_CHECK(gcnhip_memset_async(ctx2, d2, 0, 256 * sizeof(float)));
+                for (int it = 0; it < 4; it++) {
+                    comm->allreduce_sum(scratch_a, 256);
+                    comm2->allgather_rows((float *)d2, 256);
+                    comm2->allreduce_sum((float *)d2, 256);
+                    comm->allgather_rows(scratch_a, 256);
+                }
+                GCNHIP_CHECK(gcnhip_ctx_sync(ctx));
+                GCNHIP_CHECK(gcnhip_ctx_sync(ctx2));
+                gcnhip_free(ctx2, d2);
             }
             gcnhip_ctx_destroy(ctx2);
+            gcnhip_free(ctx, sa);
         }
         gcnhip_ctx_destroy(ctx);
     })

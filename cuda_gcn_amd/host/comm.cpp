@@ -1,5 +1,6 @@
 #include "comm.h"
 #include <cstring>
+#include <memory>
 #include <vector>
 #include <rccl/rccl.h>
 #include "hip_check.h"
@@ -26,19 +27,39 @@ int rccl_get_unique_id(char id[GCN_NCCL_ID_BYTES]) {
 
 namespace {
 
+// Two communicators of one process (training lane + validation lane) must never have collectives in
+// flight at the same time: RCCL kernels wait for their peers, and two of them queued in different orders
+// on different GPUs can wait for each other.  Every rank runs the same host program, so the enqueue
+// order is the same everywhere; the turnstile event makes the device execute the collectives in that
+// order too — the other lane's compute still overlaps, which is what the second lane is for.
+struct Turnstile {
+    void *ev = nullptr;
+    bool armed = false;
+    Turnstile() { GCNHIP_CHECK(gcnhip_event_create(&ev)); }
+    ~Turnstile() { gcnhip_event_destroy(ev); }
+};
+
 struct RcclComm : Comm {
     gcnhip_ctx *ctx;
     ncclComm_t comm;
     int r, w;
     float *scratch = nullptr;       // device staging for the init-time host reductions
+    std::shared_ptr<Turnstile> turn;
+    void enter() {
+        if (turn.use_count() > 1 && turn->armed) GCNHIP_CHECK(gcnhip_stream_wait_event(ctx, turn->ev));
+    }
+    void leave() {
+        if (turn.use_count() > 1) { GCNHIP_CHECK(gcnhip_event_record(ctx, turn->ev)); turn->armed = true; }
+    }
     RcclComm(gcnhip_ctx *c, int rank, int world, const char *id) : ctx(c), r(rank), w(world) {
         ncclUniqueId u;
         memcpy(&u, id, sizeof u);
         NCCL_CHECK(ncclCommInitRank(&comm, world, u, rank));
         alloc_scratch();
+        turn = std::make_shared<Turnstile>();
     }
-    RcclComm(gcnhip_ctx *c, int rank, int world, ncclComm_t parent) : ctx(c), r(rank), w(world) {
-        NCCL_CHECK(ncclCommSplit(parent, 0, rank, &comm, nullptr));
+    RcclComm(gcnhip_ctx *c, int rank, int world, const RcclComm &parent) : ctx(c), r(rank), w(world), turn(parent.turn) {
+        NCCL_CHECK(ncclCommSplit(parent.comm, 0, rank, &comm, nullptr));
         alloc_scratch();
     }
     void alloc_scratch() {
@@ -46,7 +67,7 @@ struct RcclComm : Comm {
         GCNHIP_CHECK(gcnhip_malloc(ctx, &p, 64 * sizeof(float)));
         scratch = (float *)p;
     }
-    Comm *clone_for(gcnhip_ctx *other) override { return new RcclComm(other, r, w, comm); }
+    Comm *clone_for(gcnhip_ctx *other) override { return new RcclComm(other, r, w, *this); }
     ~RcclComm() override {
         gcnhip_ctx_sync(ctx);
         ncclCommDestroy(comm);
@@ -56,10 +77,14 @@ struct RcclComm : Comm {
     int size() const override { return w; }
     void allgather_rows(float *base, size_t block) override {
         // in place: sendbuff == recvbuff + rank * count
+        enter();
         NCCL_CHECK(ncclAllGather(base + block * r, base, block, ncclFloat, comm, (hipStream_t)gcnhip_ctx_stream(ctx)));
+        leave();
     }
     void allreduce_sum(float *buf, size_t n) override {
+        enter();
         NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, comm, (hipStream_t)gcnhip_ctx_stream(ctx)));
+        leave();
     }
     void allreduce_sum_host(double *vals, int n) override {
         // counts and small scalars: exact in f32 up to 2^24, which bounds num_nodes here

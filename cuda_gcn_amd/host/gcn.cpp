@@ -47,11 +47,15 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
     n_local = r1 - r0;
     nnzA_local = (long)gp[r1] - gp[r0];
+    // locality hint for the aggregation: rows with the same label are scheduled together (on Reddit a label is
+    // a subreddit, i.e. a community whose posts share most of their neighbours); results do not depend on it
+    const int *groups = (flags & HIPGCN_NO_ROW_GROUPS) || (int)data->label.size() != N ? nullptr : data->label.data() + r0;
     if (world > 1) {
         const LocalGraph lg = build_local_graph(gp.data(), gi.data(), N, part, rank);
-        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
+        GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols,
+                                                 lg.col_deg.data(), groups));
     } else {
-        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
+        GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr, groups));
     }
     const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
     const long f0 = fp[r0], f1 = fp[r1];
@@ -72,7 +76,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         std::vector<int> lp(n_local + 1), deg(N);
         for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
         for (int j = 0; j < N; j++) deg[j] = gp[j + 1] - gp[j];
-        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data()));
+        GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data(), groups));
     }
     // truth per split, once (the reference rebuilds and re-uploads it per call: cuda_gcn.cu:85-97)
     {

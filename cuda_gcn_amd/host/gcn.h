@@ -39,7 +39,8 @@ enum HipGCNFlags {
     HIPGCN_NO_EVAL_LANE = 32, // never (default: on when world > 1, where it hides the all-gathers)
     HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
     HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
-    HIPGCN_GATHER_DH1 = 256,     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
+    HIPGCN_GATHER_DH1 = 256,
+    HIPGCN_NO_ROW_GROUPS = 512,  // do not schedule the aggregation's rows label by label     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
 
 struct HipGCNOptions {

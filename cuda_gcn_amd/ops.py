@@ -98,8 +98,8 @@ class Device:
         return self.buf(out)
 
     # ---- prepared objects
-    def graph(self, indptr, indices, n_cols=None, col_deg=None):
-        return Graph(self, indptr, indices, n_cols, col_deg)
+    def graph(self, indptr, indices, n_cols=None, col_deg=None, row_group=None):
+        return Graph(self, indptr, indices, n_cols, col_deg, row_group)
 
     def feat(self, indptr, indices, values, n_cols):
         return Feat(self, indptr, indices, values, n_cols)
@@ -306,16 +306,18 @@ class Device:
 
 
 class Graph:
-    def __init__(self, dev: Device, indptr, indices, n_cols=None, col_deg=None):
+    def __init__(self, dev: Device, indptr, indices, n_cols=None, col_deg=None, row_group=None):
         self.dev = dev
         indptr = np.ascontiguousarray(indptr, np.int32)
         indices = np.ascontiguousarray(indices, np.int32)
         self.n_rows = indptr.size - 1
         self.n_cols = int(n_cols) if n_cols is not None else self.n_rows
         cd = np.ascontiguousarray(col_deg, np.int32) if col_deg is not None else None
+        rg = np.ascontiguousarray(row_group, np.int32) if row_group is not None else None
         h = C.c_void_p()
-        _ck(dev.lib, dev.lib.gcnhip_graph_create(dev.ctx, C.byref(h), indptr.ctypes.data, indices.ctypes.data, self.n_rows, self.n_cols,
-                                                  cd.ctypes.data if cd is not None else None), "gcnhip_graph_create")
+        _ck(dev.lib, dev.lib.gcnhip_graph_create_grouped(dev.ctx, C.byref(h), indptr.ctypes.data, indices.ctypes.data, self.n_rows, self.n_cols,
+                                                          cd.ctypes.data if cd is not None else None,
+                                                          rg.ctypes.data if rg is not None else None), "gcnhip_graph_create_grouped")
         self.h = h
 
     def coef(self):

@@ -76,6 +76,13 @@ int gcnhip_d2d_async(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);
  * col_deg lets a row block of a partitioned graph name global degrees. */
 int gcnhip_graph_create(gcnhip_ctx *ctx, gcnhip_graph **g, const int *h_indptr, const int *h_indices,
                         int n_rows, int n_cols, const int *h_col_deg);
+/* As above, with a locality hint: h_row_group[r] >= 0 names the community of row r (any small integer
+ * key; the host passes the node's label).  Rows of one group are scheduled together — group-major, heavy rows
+ * first inside a group — so the neighbour rows they share stay in the XCD's L2 while the group is processed.
+ * Results are those of gcnhip_graph_create bit for bit: no node is renamed and the order of every row's own
+ * sum is unchanged; only the order in which rows are computed differs.  NULL = no hint. */
+int gcnhip_graph_create_grouped(gcnhip_ctx *ctx, gcnhip_graph **g, const int *h_indptr, const int *h_indices,
+                                int n_rows, int n_cols, const int *h_col_deg, const int *h_row_group);
 int gcnhip_graph_destroy(gcnhip_ctx *ctx, gcnhip_graph *g);
 /* device pointers of the prepared arrays (tests, diagnostics) */
 int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int **d_indices,

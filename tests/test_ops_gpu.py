@@ -135,6 +135,30 @@ def test_graphsum_vs_oracle(dev, oracle, gname, dim, ld):
     g.free()
 
 
+@pytest.mark.parametrize("gname", ["cora", "hub"])
+@pytest.mark.parametrize("dim,ld", [(16, 16), (41, 48), (128, 128)])
+def test_graphsum_row_groups_change_nothing(dev, gname, dim, ld):
+    """the locality hint only reorders WHICH row is computed when: every row's own sum, split rows
+    included, must come out bit for bit as without the hint"""
+    if gname == "cora":
+        ds = datagen.make_dataset("cora-syn"); gp, gi = ds["g_indptr"], ds["g_indices"]
+    else:
+        gp, gi = hub_graph()
+    n = gp.size - 1
+    rng = np.random.default_rng(dim + n)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    groups = rng.integers(0, 7, n).astype(np.int32)
+    g0, g1 = dev.graph(gp, gi), dev.graph(gp, gi, row_group=groups)
+    a, b = dev.graphsum(g0, x, ld_in=ld, ld_out=ld), dev.graphsum(g1, x, ld_in=ld, ld_out=ld)
+    assert np.array_equal(a, b)
+    keep = rng.random(n) < 0.5
+    xm = x * keep[:, None]
+    assert np.array_equal(dev.graphsum(g0, xm, ld_in=ld, ld_out=ld, row_nonzero=keep),
+                          dev.graphsum(g1, xm, ld_in=ld, ld_out=ld, row_nonzero=keep))
+    assert np.array_equal(g0.coef(), g1.coef())
+    g0.free(); g1.free()
+
+
 @pytest.mark.parametrize("g", ["karate", "tiny", "ragged"])
 @pytest.mark.parametrize("dim", [1, 7, 16, 41])
 def test_graphsum_golden(dev, mods, g, dim):

@@ -60,7 +60,7 @@ def main():
     nnzA = ds["g_indices"].size
     dev = Device(0)
     lib = dev.lib
-    g = dev.graph(ds["g_indptr"], ds["g_indices"])
+    g = dev.graph(ds["g_indptr"], ds["g_indices"], row_group=ds["label"])     # as HipGCN builds it
     f = dev.feat(ds["f_indptr"], ds["f_indices"], ds["f_val"], F)
     print("dense X:", f.dense, "nnzA", nnzA, flush=True)
     rng = np.random.default_rng(0)

@@ -23,8 +23,8 @@ def permuted(order):
     m = u < v
     return datagen.csr_with_self_loops(u[m], v[m], N)
 
-def bench(tag, p, i):
-    g = dev.graph(p, i)
+def bench(tag, p, i, group=None):
+    g = dev.graph(p, i, row_group=group)
     for dim, ld in ((128, 128), (41, 48)):
         x = dev.buf(rng.standard_normal((N, ld), dtype=np.float32)); o = dev.buf((N, ld))
         ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, ld, o.ptr, ld, dim), "gs"), iters=10)
@@ -33,7 +33,10 @@ def bench(tag, p, i):
     g.free()
 
 bench("generator order", gp, gi)
+bench("generator order, tasks grouped by label (no renaming)", gp, gi, lab)
 bench("grouped by label", *permuted(np.argsort(lab, kind="stable")))
 deg = np.diff(gp)
 bench("label, then degree desc", *permuted(np.lexsort((-deg, lab))))
 bench("degree desc only", *permuted(np.argsort(-deg, kind="stable")))
+o = np.lexsort((-deg, lab))
+bench("label+degree renaming, tasks grouped by label", *permuted(o), lab[o])
