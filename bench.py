@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL needs it)
 
 import numpy as np  # noqa: E402
 
@@ -35,31 +36,41 @@ def b_gs(n_rows, nnz, d):
 
 
 def cpu_baseline(ds_full, hidden, budget_s=30.0):
-    """the oracle (single-threaded C restatement of the reference's gcn-seq) timed on this
-    box's host cores, rank 0 only.  One epoch of the full workload when it fits the budget,
-    else the 1/10-scale graph scaled by 10 (cost is linear in nodes and edges)."""
+    """gcn-seq timed on this box's host cores, rank 0 only: the reference's own objects
+    (oracle/_ref/libref.so, built in the build container from the reference's sources where they lie;
+    kind "reference") when that library travelled with the repo, else the oracle, our single-threaded
+    C restatement pinned bit-for-bit to it (kind "port").  One epoch (train + validation) of the full
+    workload when it fits the budget, else the 1/10-scale graph scaled by 10 (cost is linear in nodes
+    and edges).  The other one of the two is timed on the 1/10-scale graph as a cross-check."""
     from cuda_gcn_amd import datagen
-    from oracle.pyoracle import Oracle
-    o = Oracle()
-    mini = datagen.make_dataset("reddit-mini")
-    m = o.model(mini, seed_time=1, hidden_dim=hidden, dropout=0.5)
-    t0 = time.perf_counter()
-    m.train_epoch(); m.eval(2)
-    t_mini = time.perf_counter() - t0
-    m.close()
-    scale = ds_full["num_nodes"] / mini["num_nodes"]
-    predicted = t_mini * scale
-    if predicted <= budget_s:
-        m = o.model(ds_full, seed_time=1, hidden_dim=hidden, dropout=0.5)
+    from oracle.pyoracle import Oracle, Ref
+
+    def one_epoch(factory, ds):
+        m = factory.model(ds, seed_time=1, hidden_dim=hidden, dropout=0.5)
         t0 = time.perf_counter()
         m.train_epoch(); m.eval(2)
-        t_full = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
         m.close()
-        return dict(value=1.0 / t_full, unit="epochs/s", cores=1, kind="port",
-                    sample=f"1 epoch (train+val) of the full workload, {t_full:.2f} s wall; oracle/gcn_oracle.c, gcc -O3, 1 thread")
-    return dict(value=1.0 / predicted, unit="epochs/s", cores=1, kind="port",
-                sample=f"1 epoch of reddit-mini (1/10 nodes and edges, same widths) = {t_mini:.2f} s, scaled x{scale:.1f} "
-                       f"to the full graph; oracle/gcn_oracle.c, gcc -O3, 1 thread")
+        return dt
+
+    port = Oracle()
+    ref = Ref() if Ref.available() else None
+    main_impl, kind, what = (ref, "reference", "the reference's src/seq objects (oracle/_ref/libref.so, g++ -O3)") if ref else \
+                            (port, "port", "oracle/gcn_oracle.c (gcc -O3)")
+    mini = datagen.make_dataset("reddit-mini")
+    t_mini = one_epoch(main_impl, mini)
+    scale = ds_full["num_nodes"] / mini["num_nodes"]
+    if t_mini * scale <= budget_s:
+        t_full = one_epoch(main_impl, ds_full)
+        out = dict(value=1.0 / t_full, unit="epochs/s", cores=1, kind=kind,
+                   sample=f"1 epoch (train+val) of the full workload, {t_full:.2f} s wall; {what}, 1 thread")
+    else:
+        out = dict(value=1.0 / (t_mini * scale), unit="epochs/s", cores=1, kind=kind,
+                   sample=f"1 epoch of reddit-mini (1/10 nodes and edges, same widths) = {t_mini:.2f} s, scaled x{scale:.1f} "
+                          f"to the full graph; {what}, 1 thread")
+    if ref:
+        out["port_cross_check"] = dict(mini_epoch_s_reference=round(t_mini, 3), mini_epoch_s_port=round(one_epoch(port, mini), 3))
+    return out
 
 
 def main():
@@ -119,7 +130,7 @@ def main():
     device = int(os.environ.get("GCN_BENCH_DEVICE", local_rank))
     model = HipGCNModel(ds, seed=1, device=device, flags=TIMERS | lane_flag, rank=rank, world=world, nccl_id=nccl_id,
                         host_allgather=host_ag, host_allreduce=host_ar,
-                        hidden_dim=args.hidden, dropout=0.5, epochs=args.steps + args.warmup)
+                        hidden_dim=args.hidden, dropout=0.5, epochs=2 * args.steps + args.warmup)
     info = model.info()
 
     model.run_epochs(args.warmup, want_trace=False)
@@ -146,6 +157,14 @@ def main():
         s, n = model.timer(name)
         if n:
             breakdown[name] = round(1e3 * s / args.steps, 4)      # ms per epoch
+    # train-only epochs (no validation forward; one host read-back per epoch), outside the timed region
+    n_tr = min(args.steps, 20)
+    barrier(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_tr):
+        model.train_epoch()
+    torch.cuda.synchronize(); barrier()
+    train_only_ms = 1e3 * (time.perf_counter() - t1) / n_tr
     out = None
     if rank == 0:
         # fabric traffic per launch of the same kernel from the committed rocprofv3 PMC passes
@@ -186,7 +205,7 @@ def main():
                                  if table_mb <= 256 else
                                  ("algorithmic gather-model bytes B_gs(d); the gathered table (%.0f MB) exceeds the 256 MiB Infinity "
                                   "Cache: HBM regime" % table_mb)},
-            "breakdown_ms_per_epoch": breakdown,
+            "breakdown_ms_per_epoch": breakdown, "train_only_ms_per_epoch": round(train_only_ms, 4),
             "final": {"train_loss": float(trace[-1, 0]), "train_acc": float(trace[-1, 1]),
                       "val_loss": float(trace[-1, 2]), "val_acc": float(trace[-1, 3])},
             "setup_s": {"dataset": round(t_data, 2)},

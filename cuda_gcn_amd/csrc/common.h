@@ -46,6 +46,7 @@ struct gcnhip_graph {
     int n_slots;
     // task ranges of equal edge count for 1, 2, 4 or 8 XCD groups: bounds[log2 G][g] .. bounds[log2 G][g+1]
     int bounds[4][9];
+    int *tmp_col_deg;   // only during construction
 };
 
 struct gcnhip_feat {

@@ -26,6 +26,7 @@ int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
     if (!out) return -1;
     GCNHIP_TRY(hipSetDevice(device));
     gcnhip_ctx *c = new gcnhip_ctx();
+    memset(c, 0, sizeof *c);
     c->device = device;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -35,15 +36,18 @@ int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
         if (e != hipSuccess) { delete c; return (int)e; }
         c->own_stream = true;
     }
-    hipDeviceProp_t prop;
-    GCNHIP_TRY(hipGetDeviceProperties(&prop, device));
-    c->n_cu = prop.multiProcessorCount;
-    GCNHIP_TRY(hipMalloc((void **)&c->red_f, RED_SLOTS * 4 * sizeof(float)));
-    GCNHIP_TRY(hipMalloc((void **)&c->red_i, RED_SLOTS * 4 * sizeof(int32_t)));
-    GCNHIP_TRY(hipMalloc((void **)&c->ticket, 64 * sizeof(uint32_t)));
-    GCNHIP_TRY(hipMemset(c->ticket, 0, 64 * sizeof(uint32_t)));
-    c->slab = nullptr;
-    c->slab_bytes = 0;
+    auto fill = [&]() -> int {
+        hipDeviceProp_t prop;
+        GCNHIP_TRY(hipGetDeviceProperties(&prop, device));
+        c->n_cu = prop.multiProcessorCount;
+        GCNHIP_TRY(hipMalloc((void **)&c->red_f, RED_SLOTS * 4 * sizeof(float)));
+        GCNHIP_TRY(hipMalloc((void **)&c->red_i, RED_SLOTS * 4 * sizeof(int32_t)));
+        GCNHIP_TRY(hipMalloc((void **)&c->ticket, 64 * sizeof(uint32_t)));
+        GCNHIP_TRY(hipMemset(c->ticket, 0, 64 * sizeof(uint32_t)));
+        return 0;
+    };
+    const int rc = fill();
+    if (rc != 0) { gcnhip_ctx_destroy(c); return rc; }        // frees whatever was allocated
     *out = c;
     return 0;
 }
@@ -52,9 +56,9 @@ int gcnhip_ctx_destroy(gcnhip_ctx *c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    hipFree(c->red_f);
-    hipFree(c->red_i);
-    hipFree(c->ticket);
+    if (c->red_f) hipFree(c->red_f);
+    if (c->red_i) hipFree(c->red_i);
+    if (c->ticket) hipFree(c->ticket);
     if (c->slab) hipFree(c->slab);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -158,16 +162,31 @@ int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, 
     return gcnhip_graph_create_grouped(c, out, h_indptr, h_indices, n_rows, n_cols, h_col_deg, nullptr);
 }
 
+static int graph_create_impl(gcnhip_ctx *c, gcnhip_graph *g, const int *h_indptr, const int *h_indices,
+                             int n_rows, int n_cols, const int *h_col_deg, const int *h_row_group);
+
 int gcnhip_graph_create_grouped(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, const int *h_indices,
                                 int n_rows, int n_cols, const int *h_col_deg, const int *h_row_group) {
     if (!c || !out || !h_indptr || n_rows < 0) return -1;
     if (!h_col_deg && n_cols != n_rows) return -1;
-    GCNHIP_TRY(hipSetDevice(c->device));
     const int nnz = h_indptr[n_rows];
+    if (nnz < 0 || (nnz > 0 && !h_indices)) return -1;
+    for (int r = 0; r < n_rows; r++)
+        if (h_indptr[r + 1] < h_indptr[r]) return -1;
     for (int e = 0; e < nnz; e++)
         if (h_indices[e] < 0 || h_indices[e] >= n_cols) return -1;    // a bad column would fault the gather
     gcnhip_graph *g = new gcnhip_graph();
     memset(g, 0, sizeof *g);
+    const int rc = graph_create_impl(c, g, h_indptr, h_indices, n_rows, n_cols, h_col_deg, h_row_group);
+    if (rc != 0) { gcnhip_graph_destroy(c, g); return rc; }   // frees whatever was allocated
+    *out = g;
+    return 0;
+}
+
+static int graph_create_impl(gcnhip_ctx *c, gcnhip_graph *g, const int *h_indptr, const int *h_indices,
+                             int n_rows, int n_cols, const int *h_col_deg, const int *h_row_group) {
+    GCNHIP_TRY(hipSetDevice(c->device));
+    const int nnz = h_indptr[n_rows];
     g->n_rows = n_rows; g->n_cols = n_cols; g->nnz = nnz;
     GCNHIP_TRY(hipMalloc((void **)&g->indptr, (size_t)(n_rows + 1) * sizeof(int)));
     GCNHIP_TRY(hipMalloc((void **)&g->indices, (size_t)std::max(nnz, 1) * sizeof(int)));
@@ -193,7 +212,7 @@ int gcnhip_graph_create_grouped(gcnhip_ctx *c, gcnhip_graph **out, const int *h_
         h_indices = sorted_idx.data();
         GCNHIP_TRY(hipMemcpy(g->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
     }
-    int *d_col_deg = nullptr;
+    int *&d_col_deg = g->tmp_col_deg;      // lives in the object so that a failure below still frees it
     if (h_col_deg) {
         GCNHIP_TRY(hipMalloc((void **)&d_col_deg, (size_t)std::max(n_cols, 1) * sizeof(int)));
         GCNHIP_TRY(hipMemcpy(d_col_deg, h_col_deg, (size_t)n_cols * sizeof(int), hipMemcpyHostToDevice));
@@ -203,7 +222,7 @@ int gcnhip_graph_create_grouped(gcnhip_ctx *c, gcnhip_graph **out, const int *h_
         GCNHIP_LAUNCH_CHECK();
     }
     GCNHIP_TRY(hipStreamSynchronize(c->stream));
-    if (d_col_deg) GCNHIP_TRY(hipFree(d_col_deg));
+    if (d_col_deg) { GCNHIP_TRY(hipFree(d_col_deg)); d_col_deg = nullptr; }
 
     // Task list: rows in descending degree order (heavy work first, similar rows together), group-major
     // when the caller names communities; a row
@@ -257,14 +276,16 @@ int gcnhip_graph_create_grouped(gcnhip_ctx *c, gcnhip_graph **out, const int *h_
         }
         for (int k = G; k <= 8; k++) g->bounds[lg][k] = n_units;
     }
-    *out = g;
     return 0;
 }
 
 int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
     if (!g) return 0;
     hipSetDevice(c->device);
-    hipFree(g->indptr); hipFree(g->indices); hipFree(g->coef);
+    if (g->indptr) hipFree(g->indptr);
+    if (g->indices) hipFree(g->indices);
+    if (g->coef) hipFree(g->coef);
+    if (g->tmp_col_deg) hipFree(g->tmp_col_deg);
     if (g->tasks) hipFree(g->tasks);
     if (g->split_rows) hipFree(g->split_rows);
     if (g->partials) hipFree(g->partials);

@@ -77,3 +77,27 @@ def test_empty_split_gives_nan_like_reference(oracle):
     va, vb = m.eval(2), om.eval(2)
     assert np.isnan(va[0]) and np.isnan(vb[0])
     m.close(); om.close()
+
+
+def test_c_abi_rejects_bad_arguments():
+    """the C-ABI never faults on bad operands: it returns -1 ("gcnhip: invalid argument") and the
+    Python front end raises; nothing is leaked into the context (the next call works)"""
+    from cuda_gcn_amd.ops import Device, GcnHipError
+    dev = Device(0)
+    gp = np.array([0, 2, 3], np.int32)
+    with pytest.raises(GcnHipError):
+        dev.graph(gp, np.array([0, 5, 1], np.int32))                  # column 5 of a 2-node graph
+    with pytest.raises(GcnHipError):
+        dev.graph(gp, np.array([0, -1, 1], np.int32))
+    with pytest.raises(GcnHipError):
+        dev.graph(np.array([0, 3, 2], np.int32), np.array([0, 1, 1], np.int32))   # indptr not monotone
+    with pytest.raises(GcnHipError):
+        dev.feat(np.array([0, 1, 2], np.int32), np.array([0, 9], np.int32), np.ones(2, np.float32), 4)
+    g = dev.graph(gp, np.array([0, 1, 1], np.int32))
+    x = np.ones((2, 300), np.float32)
+    with pytest.raises(GcnHipError):
+        dev.matmul_fwd(np.ones((3, 800), np.float32), np.ones((800, 40), np.float32))   # inner dim above the LDS panel limit
+    out = dev.graphsum(g, x)
+    assert np.isfinite(out).all()
+    g.free()
+    dev.close()

@@ -79,6 +79,11 @@ def main():
     gs(Cc, 48)
     gs(Cc, 64)
     gs(Cc, Cc)
+    if len(sys.argv) > 4 and sys.argv[4] == 'strides':      # row stride vs L2 channel interleave
+        for ld in (160, 224, 288, 192):
+            gs(h, ld)
+        for ld in (80, 96, 112, 160):
+            gs(Cc, ld)
     if only_gs:
         print(json.dumps(res)); return
 
