@@ -15,6 +15,28 @@ T *dev_upload(gcnhip_ctx *ctx, const T *h, size_t n) {
     if (n) GCNHIP_CHECK(gcnhip_h2d(ctx, p, h, n * sizeof(T)));
     return (T *)p;
 }
+
+// Are the labels communities of THIS graph?  Edge homophily (share of stored non-loop edges whose two ends carry
+// the same label) against what label frequencies alone would give; the hint is used at twice chance or more.
+bool labels_are_assortative(const GCNData &d, int N, int C) {
+    if ((int)d.label.size() != N || C <= 1) return false;
+    const std::vector<int> &gp = d.graph.indptr, &gi = d.graph.indices;
+    std::vector<double> freq(C, 0.0);
+    for (int i = 0; i < N; i++) {
+        if (d.label[i] < 0 || d.label[i] >= C) return false;
+        freq[d.label[i]] += 1.0;
+    }
+    double chance = 0;
+    for (int c = 0; c < C; c++) chance += (freq[c] / N) * (freq[c] / N);
+    long same = 0, total = 0;
+    for (int i = 0; i < N; i++)
+        for (int e = gp[i]; e < gp[i + 1]; e++) {
+            if (gi[e] == i) continue;
+            total++;
+            same += d.label[gi[e]] == d.label[i];
+        }
+    return total > 0 && (double)same / (double)total >= 2.0 * chance;
+}
 }  // namespace
 
 HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : params(p), data(input_data), flags(opt.flags) {
@@ -49,7 +71,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     nnzA_local = (long)gp[r1] - gp[r0];
     // locality hint for the aggregation: rows with the same label are scheduled together (on Reddit a label is
     // a subreddit, i.e. a community whose posts share most of their neighbours); results do not depend on it
-    const int *groups = (flags & HIPGCN_NO_ROW_GROUPS) || (int)data->label.size() != N ? nullptr : data->label.data() + r0;
+    const int *groups = (flags & HIPGCN_NO_ROW_GROUPS) || !labels_are_assortative(*data, N, C) ? nullptr : data->label.data() + r0;
     if (world > 1) {
         const LocalGraph lg = build_local_graph(gp.data(), gi.data(), N, part, rank);
         GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols,

@@ -238,12 +238,13 @@ def test_eval_lane_is_bit_identical():
 
 
 def test_row_groups_are_bit_identical():
-    """scheduling the aggregation label by label (the default) changes no number"""
+    """scheduling the aggregation label by label (the default when the labels are assortative on the
+    graph, as on reddit-*) changes no number"""
     from cuda_gcn_amd.model import HipGCNModel, NO_ROW_GROUPS
-    ds = datagen.make_dataset("pubmed-syn")
-    a = HipGCNModel(ds, seed=6, flags=NO_ROW_GROUPS, hidden_dim=16, dropout=0.5, epochs=10)
-    b = HipGCNModel(ds, seed=6, hidden_dim=16, dropout=0.5, epochs=10)
-    ta, tb = a.run_epochs(10), b.run_epochs(10)
+    ds = datagen.make_dataset("reddit-mini")
+    a = HipGCNModel(ds, seed=6, flags=NO_ROW_GROUPS, hidden_dim=32, dropout=0.5, epochs=4)
+    b = HipGCNModel(ds, seed=6, hidden_dim=32, dropout=0.5, epochs=4)
+    ta, tb = a.run_epochs(4), b.run_epochs(4)
     assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
     assert np.array_equal(a.var(2), b.var(2)) and np.array_equal(a.var(6), b.var(6))
     a.close(); b.close()

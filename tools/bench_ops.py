@@ -42,7 +42,8 @@ def main():
         del lo, hi
         N = 1 << scale
         dev = Device(0); lib = dev.lib
-        g = dev.graph(gp, gi)
+        groups = np.random.default_rng(1).integers(0, 41, N).astype(np.int32) if len(sys.argv) > 4 and sys.argv[4] == "random-groups" else None
+        g = dev.graph(gp, gi, row_group=groups)     # HipGCN uses label groups only when they are assortative
         deg = np.diff(gp)
         print(f"rmat scale {scale}: N={N} nnzA={gi.size} max_deg={deg.max()} built in {time.time() - t0:.1f}s", flush=True)
         rng = np.random.default_rng(0)
