@@ -194,7 +194,7 @@ def main():
                                    f"{ds['input_dim']}->{args.hidden}->{ds['output_dim']}, dropout 0.5, Adam; "
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
-                       "train_nodes": n_lab},
+                       "train_nodes": n_lab, "aggregation_schedule": model.schedule()},
             "roofline": {"bound": "hbm", "kernel": (f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})" if args.hidden > 64 else
                                     f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

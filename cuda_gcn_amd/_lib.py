@@ -80,6 +80,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_d2d_async": (I, [P, P, P, C.c_size_t]),
     "gcnhip_graph_create": (I, [P, C.POINTER(P), P, P, I, I, P]),
     "gcnhip_graph_create_grouped": (I, [P, C.POINTER(P), P, P, I, I, P, P]),
+    "gcnhip_graph_set_schedule": (I, [P, P, I, P, I]),
     "gcnhip_graph_destroy": (I, [P, P]),
     "gcnhip_graph_arrays": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
     "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),
@@ -150,6 +151,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_model_run": (I, [P]),
     "gcnhost_model_sync": (I, [P]),
     "gcnhost_model_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
+    "gcnhost_model_schedule": (I, [P, C.POINTER(I), C.POINTER(I)]),
     "gcnhost_model_get_var": (I, [P, I, I, P, C.POINTER(I), C.POINTER(I)]),
     "gcnhost_model_set_weights": (I, [P, P, P]),
     "gcnhost_model_timer": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),

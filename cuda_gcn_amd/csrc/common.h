@@ -2,6 +2,7 @@
 // Wave = 64 lanes everywhere in this directory (CDNA4); nothing here is
 // written for 32-wide warps.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -47,6 +48,7 @@ struct gcnhip_graph {
     // task ranges of equal edge count for 1, 2, 4 or 8 XCD groups: bounds[log2 G][g] .. bounds[log2 G][g+1]
     int bounds[4][9];
     int *tmp_col_deg;   // only during construction
+    std::vector<int> *h_indptr;   // host copy of the row pointers (the schedule can be rebuilt)
 };
 
 struct gcnhip_feat {

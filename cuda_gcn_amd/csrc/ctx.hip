@@ -155,6 +155,68 @@ __global__ void edge_coef_kernel(const int *__restrict__ indptr, const int *__re
 
 constexpr int SPLIT_EDGES = 1024;   // rows longer than this are cut into segments
 
+// (Re)build the row schedule: tasks ordered by (key[row] ascending, degree descending); key == nullptr: degree only.
+static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
+    const int n_rows = g->n_rows;
+    const int *h_indptr = g->h_indptr->data();
+    if (g->tasks) { GCNHIP_TRY(hipFree(g->tasks)); g->tasks = nullptr; }
+    if (g->split_rows) { GCNHIP_TRY(hipFree(g->split_rows)); g->split_rows = nullptr; }
+    // Task list: rows in descending degree order (heavy work first, similar rows together), group-major
+    // when the caller names communities; a row
+    // above SPLIT_EDGES becomes consecutive segments whose partial sums a second kernel adds in order.
+    std::vector<int> order(n_rows);
+    for (int r = 0; r < n_rows; r++) order[r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (h_row_group && h_row_group[a] != h_row_group[b]) return h_row_group[a] < h_row_group[b];
+        return h_indptr[a + 1] - h_indptr[a] > h_indptr[b + 1] - h_indptr[b];
+    });
+    int n_slots = 0;
+    std::vector<int4> tasks, srows;
+    tasks.reserve((size_t)n_rows + 64);
+    for (int r : order) {
+        const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
+        if (e1 - e0 <= SPLIT_EDGES) { tasks.push_back(make_int4(r, e0, e1, -1)); continue; }
+        const int ns = (e1 - e0 + SPLIT_EDGES - 1) / SPLIT_EDGES;
+        srows.push_back(make_int4(r, n_slots, ns, 0));
+        for (int q = 0; q < ns; q++)
+            tasks.push_back(make_int4(r, e0 + q * SPLIT_EDGES, std::min(e1, e0 + (q + 1) * SPLIT_EDGES), n_slots + q));
+        n_slots += ns;
+    }
+    g->n_tasks = (int)tasks.size();
+    g->n_split_rows = (int)srows.size();
+    g->n_slots = n_slots;
+    const int n_units = g->n_tasks;
+    std::vector<int64_t> prefix((size_t)n_units + 1);   // work before task t: edges + a per-task constant
+    prefix[0] = 0;
+    for (int t = 0; t < n_units; t++) prefix[t + 1] = prefix[t] + (tasks[t].z - tasks[t].y) + 8;
+    if (n_units) {
+        GCNHIP_TRY(hipMalloc((void **)&g->tasks, tasks.size() * sizeof(int4)));
+        GCNHIP_TRY(hipMemcpy(g->tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    if (!srows.empty()) {
+        GCNHIP_TRY(hipMalloc((void **)&g->split_rows, srows.size() * sizeof(int4)));
+        GCNHIP_TRY(hipMemcpy(g->split_rows, srows.data(), srows.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); }
+    g->part_ld = 0;           // partial buffer sized lazily for the widest dim seen
+    g->partials = nullptr;
+    // equal-work task ranges for 1/2/4/8 XCD groups, each starting on a multiple of 4 tasks (one workgroup)
+    for (int lg = 0; lg < 4; lg++) {
+        const int G = 1 << lg;
+        g->bounds[lg][0] = 0;
+        for (int k = 1; k < G; k++) {
+            const int64_t target = prefix[n_units] * k / G;
+            int t = (int)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+            t = (t + 3) / 4 * 4;
+            if (t > n_units) t = n_units;
+            if (t < g->bounds[lg][k - 1]) t = g->bounds[lg][k - 1];
+            g->bounds[lg][k] = t;
+        }
+        for (int k = G; k <= 8; k++) g->bounds[lg][k] = n_units;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int gcnhip_graph_create(gcnhip_ctx *c, gcnhip_graph **out, const int *h_indptr, const int *h_indices,
@@ -224,59 +286,8 @@ static int graph_create_impl(gcnhip_ctx *c, gcnhip_graph *g, const int *h_indptr
     GCNHIP_TRY(hipStreamSynchronize(c->stream));
     if (d_col_deg) { GCNHIP_TRY(hipFree(d_col_deg)); d_col_deg = nullptr; }
 
-    // Task list: rows in descending degree order (heavy work first, similar rows together), group-major
-    // when the caller names communities; a row
-    // above SPLIT_EDGES becomes consecutive segments whose partial sums a second kernel adds in order.
-    std::vector<int> order(n_rows);
-    for (int r = 0; r < n_rows; r++) order[r] = r;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (h_row_group && h_row_group[a] != h_row_group[b]) return h_row_group[a] < h_row_group[b];
-        return h_indptr[a + 1] - h_indptr[a] > h_indptr[b + 1] - h_indptr[b];
-    });
-    int n_slots = 0;
-    std::vector<int4> tasks, srows;
-    tasks.reserve((size_t)n_rows + 64);
-    for (int r : order) {
-        const int e0 = h_indptr[r], e1 = h_indptr[r + 1];
-        if (e1 - e0 <= SPLIT_EDGES) { tasks.push_back(make_int4(r, e0, e1, -1)); continue; }
-        const int ns = (e1 - e0 + SPLIT_EDGES - 1) / SPLIT_EDGES;
-        srows.push_back(make_int4(r, n_slots, ns, 0));
-        for (int q = 0; q < ns; q++)
-            tasks.push_back(make_int4(r, e0 + q * SPLIT_EDGES, std::min(e1, e0 + (q + 1) * SPLIT_EDGES), n_slots + q));
-        n_slots += ns;
-    }
-    g->n_tasks = (int)tasks.size();
-    g->n_split_rows = (int)srows.size();
-    g->n_slots = n_slots;
-    const int n_units = g->n_tasks;
-    std::vector<int64_t> prefix((size_t)n_units + 1);   // work before task t: edges + a per-task constant
-    prefix[0] = 0;
-    for (int t = 0; t < n_units; t++) prefix[t + 1] = prefix[t] + (tasks[t].z - tasks[t].y) + 8;
-    if (n_units) {
-        GCNHIP_TRY(hipMalloc((void **)&g->tasks, tasks.size() * sizeof(int4)));
-        GCNHIP_TRY(hipMemcpy(g->tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
-    }
-    if (!srows.empty()) {
-        GCNHIP_TRY(hipMalloc((void **)&g->split_rows, srows.size() * sizeof(int4)));
-        GCNHIP_TRY(hipMemcpy(g->split_rows, srows.data(), srows.size() * sizeof(int4), hipMemcpyHostToDevice));
-    }
-    g->part_ld = 0;           // partial buffer sized lazily for the widest dim seen
-    g->partials = nullptr;
-    // equal-work task ranges for 1/2/4/8 XCD groups, each starting on a multiple of 4 tasks (one workgroup)
-    for (int lg = 0; lg < 4; lg++) {
-        const int G = 1 << lg;
-        g->bounds[lg][0] = 0;
-        for (int k = 1; k < G; k++) {
-            const int64_t target = prefix[n_units] * k / G;
-            int t = (int)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
-            t = (t + 3) / 4 * 4;
-            if (t > n_units) t = n_units;
-            if (t < g->bounds[lg][k - 1]) t = g->bounds[lg][k - 1];
-            g->bounds[lg][k] = t;
-        }
-        for (int k = G; k <= 8; k++) g->bounds[lg][k] = n_units;
-    }
-    return 0;
+    g->h_indptr = new std::vector<int>(h_indptr, h_indptr + n_rows + 1);
+    return build_schedule(g, h_row_group);
 }
 
 int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
@@ -286,11 +297,31 @@ int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
     if (g->indices) hipFree(g->indices);
     if (g->coef) hipFree(g->coef);
     if (g->tmp_col_deg) hipFree(g->tmp_col_deg);
+    delete g->h_indptr;
     if (g->tasks) hipFree(g->tasks);
     if (g->split_rows) hipFree(g->split_rows);
     if (g->partials) hipFree(g->partials);
     delete g;
     return 0;
+}
+
+int gcnhip_graph_set_schedule(gcnhip_ctx *c, gcnhip_graph *g, int mode, const int *h_row_group, int n_groups) {
+    if (!c || !g || !g->h_indptr || mode < 0 || mode > 2) return -1;
+    if (mode == 1 && !h_row_group) return -1;
+    if (mode == 2 && n_groups < 1) return -1;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));       // no aggregation may still be reading the old task list
+    if (mode == 0) return build_schedule(g, nullptr);
+    if (mode == 1) return build_schedule(g, h_row_group);
+    // mode 2: rows ranked by descending degree, rank r goes to group r % n_groups — every group has the
+    // same degree mix, so hub rows and the long tail of short rows are in flight together
+    const int n = g->n_rows;
+    const int *ip = g->h_indptr->data();
+    std::vector<int> order(n), key(n);
+    for (int r = 0; r < n; r++) order[r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ip[a + 1] - ip[a] > ip[b + 1] - ip[b]; });
+    for (int k = 0; k < n; k++) key[order[k]] = k % n_groups;
+    return build_schedule(g, key.data());
 }
 
 int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int **d_indices,

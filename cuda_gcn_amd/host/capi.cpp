@@ -99,6 +99,12 @@ int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, 
         if (local_edges) *local_edges = m->gcn->n_edges_local();
     })
 }
+int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups) {
+    API_TRY({
+        if (mode) *mode = m->gcn->schedule_mode();
+        if (n_groups) *n_groups = m->gcn->schedule_groups();
+    })
+}
 int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *rows, int *cols) {
     API_TRY({
         std::vector<float> v;

@@ -69,15 +69,12 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
     n_local = r1 - r0;
     nnzA_local = (long)gp[r1] - gp[r0];
-    // locality hint for the aggregation: rows with the same label are scheduled together (on Reddit a label is
-    // a subreddit, i.e. a community whose posts share most of their neighbours); results do not depend on it
-    const int *groups = (flags & HIPGCN_NO_ROW_GROUPS) || !labels_are_assortative(*data, N, C) ? nullptr : data->label.data() + r0;
+    labels_assortative = !(flags & HIPGCN_NO_ROW_GROUPS) && labels_are_assortative(*data, N, C);
     if (world > 1) {
         const LocalGraph lg = build_local_graph(gp.data(), gi.data(), N, part, rank);
-        GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols,
-                                                 lg.col_deg.data(), groups));
+        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
     } else {
-        GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr, groups));
+        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
     }
     const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
     const long f0 = fp[r0], f1 = fp[r1];
@@ -98,7 +95,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         std::vector<int> lp(n_local + 1), deg(N);
         for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
         for (int j = 0; j < N; j++) deg[j] = gp[j + 1] - gp[j];
-        GCNHIP_CHECK(gcnhip_graph_create_grouped(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data(), groups));
+        GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data()));
     }
     // truth per split, once (the reference rebuilds and re-uploads it per call: cuda_gcn.cu:85-97)
     {
@@ -190,6 +187,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         env.keep_input_bwd = d_keep0 + (f0 - keep0_first);
         env.keep_hidden = d_keep1;
     }
+    if (!(flags & HIPGCN_NO_ROW_GROUPS)) tune_schedule();
     build_modules();
     if (!(flags & HIPGCN_NO_EVAL_LANE) && ((flags & HIPGCN_EVAL_LANE) || world > 1)) {
         try {
@@ -206,6 +204,52 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     optimizer.reset(new HipAdam());
     optimizer->init(&env, {{W1, true}, {W2, false}}, ap, params.epochs > 0 ? params.epochs + 8 : 8);   // gcn.cpp:62-65
     GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
+}
+
+// Which rows the aggregation has in flight together decides its speed (what the XCD L2s hold; whether hub rows
+// overlap with the tail of short rows) and nothing else: every schedule gives the same bits.  Candidates:
+// descending degree; label-major when the labels are communities of this graph (Reddit: subreddits); degree rank
+// dealt into 256 equal-mix groups (graphs with a long tail of short rows, e.g. R-MAT).  Each is timed on the
+// hidden-width aggregation of this rank's rows and the fastest is kept for all of this rank's adjacency objects.
+void HipGCN::apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g) {
+    const int *labels = data->label.data() + part.start[env.comm->rank()];
+    GCNHIP_CHECK(gcnhip_graph_set_schedule(ctx, g, sched_mode, sched_mode == 1 ? labels : nullptr, sched_groups));
+}
+
+void HipGCN::tune_schedule() {
+    if (n_local < 4096) return;                              // launch-bound graphs: nothing to gain
+    const int H = params.hidden_dim;
+    HipVariable *in = variables[1].get(), *out = variables[3].get();
+    float *src = in->full ? in->full : in->data;
+    const size_t src_elems = in->full ? in->full_elems : in->elems();
+    GCNHIP_CHECK(gcnhip_memset_async(env.ctx, src, 0, src_elems * sizeof(float)));
+    struct Cand { int mode, groups; };
+    std::vector<Cand> cands = {{0, 0}, {2, 256}};
+    if (labels_assortative) cands.push_back({1, 0});
+    void *e0, *e1;
+    GCNHIP_CHECK(gcnhip_event_create(&e0));
+    GCNHIP_CHECK(gcnhip_event_create(&e1));
+    float best = 0.f;
+    Cand pick = cands[0];
+    gcnhip_graph *g = replicate_l1 ? graph_l1 : graph;       // the layer-1 aggregation, the widest one
+    for (const Cand &c : cands) {
+        sched_mode = c.mode; sched_groups = c.groups;
+        apply_schedule(env.ctx, g);
+        float ms = 0.f;
+        for (int it = 0; it < 3; it++) {                     // first run warms the caches and sizes the scratch
+            if (it == 1) GCNHIP_CHECK(gcnhip_event_record(env.ctx, e0));
+            GCNHIP_CHECK(gcnhip_graphsum(env.ctx, g, src, in->ld, out->data, out->ld, H));
+        }
+        GCNHIP_CHECK(gcnhip_event_record(env.ctx, e1));
+        GCNHIP_CHECK(gcnhip_event_elapsed_ms(e0, e1, &ms));
+        if (best == 0.f || ms < best) { best = ms; pick = c; }
+    }
+    gcnhip_event_destroy(e0);
+    gcnhip_event_destroy(e1);
+    sched_mode = pick.mode; sched_groups = pick.groups;
+    apply_schedule(env.ctx, graph);
+    if (graph_l1) apply_schedule(env.ctx, graph_l1);
+    GCNHIP_CHECK(gcnhip_memset_async(env.ctx, out->data, 0, out->elems() * sizeof(float)));
 }
 
 void HipGCN::build_modules() {
@@ -274,6 +318,7 @@ void HipGCN::build_eval_lane() {
     } else {
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, gp.data(), gi.data(), params.num_nodes, params.num_nodes, nullptr));
     }
+    apply_schedule(L.env.ctx, L.graph);                     // the schedule the training lane measured as fastest
     const int rm = part.rows_max;
     L.H0.reset(new HipVariable()); L.H1.reset(new HipVariable()); L.Z0.reset(new HipVariable()); L.Z.reset(new HipVariable());
     if (replicate_l1) {
@@ -282,6 +327,7 @@ void HipGCN::build_eval_lane() {
         for (int r = 0; r <= N; r++) lp[r] = gp[r0 + r] - gp[r0];
         for (int j = 0; j < params.num_nodes; j++) deg[j] = gp[j + 1] - gp[j];
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph_l1, lp.data(), gi.data() + gp[r0], N, params.num_nodes, deg.data()));
+        apply_schedule(L.env.ctx, L.graph_l1);
         L.H0->alloc_replicated(L.env.ctx, params.num_nodes, N, r0, H, false);
     } else {
         L.H0->alloc(L.env.ctx, N, H, false, true, false, world, rank, rm);

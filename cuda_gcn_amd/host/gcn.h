@@ -40,7 +40,7 @@ enum HipGCNFlags {
     HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
     HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
     HIPGCN_GATHER_DH1 = 256,
-    HIPGCN_NO_ROW_GROUPS = 512,  // do not schedule the aggregation's rows label by label     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
+    HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
 
 struct HipGCNOptions {
@@ -75,6 +75,8 @@ public:
 
     // introspection for tests / bench
     int rank() const { return env.comm->rank(); }
+    int schedule_mode() const { return sched_mode; }
+    int schedule_groups() const { return sched_groups; }
     int world() const { return env.comm->size(); }
     int local_rows() const { return n_local; }
     int row_start() const { return part.start[env.comm->rank()]; }
@@ -157,6 +159,11 @@ private:
     void build_eval_lane();
     void eval_on_lane(int current_split);
 
+    // row schedule of the aggregation (gcnhip_graph_set_schedule): candidates timed once, fastest kept
+    int sched_mode = 0, sched_groups = 0;
+    bool labels_assortative = false;
+    void tune_schedule();
+    void apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g);
     void build_modules();
     void set_truth(int current_split);
     void host_masks_for_epoch();

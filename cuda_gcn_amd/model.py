@@ -109,6 +109,12 @@ class HipGCNModel:
         w1, w2 = np.ascontiguousarray(w1, np.float32), np.ascontiguousarray(w2, np.float32)
         _ck(self.lib, self.lib.gcnhost_model_set_weights(self.h, w1.ctypes.data, w2.ctypes.data), "set_weights")
 
+    def schedule(self):
+        """row schedule of the aggregation picked at construction: 'degree', 'label-major' or 'dealt-<G>'"""
+        m, g = C.c_int(), C.c_int()
+        _ck(self.lib, self.lib.gcnhost_model_schedule(self.h, C.byref(m), C.byref(g)), "schedule")
+        return {0: "degree", 1: "label-major", 2: f"dealt-{g.value}"}[m.value]
+
     def timer(self, name_or_id):
         i = TIMER_NAMES.index(name_or_id) if isinstance(name_or_id, str) else int(name_or_id)
         s, n = C.c_double(), C.c_long()

@@ -320,6 +320,11 @@ class Graph:
                                                           rg.ctypes.data if rg is not None else None), "gcnhip_graph_create_grouped")
         self.h = h
 
+    def set_schedule(self, mode, row_group=None, n_groups=0):
+        rg = np.ascontiguousarray(row_group, np.int32) if row_group is not None else None
+        _ck(self.dev.lib, self.dev.lib.gcnhip_graph_set_schedule(self.dev.ctx, self.h, mode, rg.ctypes.data if rg is not None else None,
+                                                                  n_groups), "gcnhip_graph_set_schedule")
+
     def coef(self):
         pc = C.c_void_p()
         nr, nnz = C.c_int(), C.c_int()

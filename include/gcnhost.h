@@ -76,6 +76,8 @@ int gcnhost_model_sync(gcnhost_model *m);
 
 /* introspection */
 int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges);
+/* the aggregation's row schedule this rank timed as fastest (gcnhip_graph_set_schedule modes; 0 when not tuned) */
+int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
 /* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
  * out == NULL: only report the shape. */
 int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *rows, int *cols);

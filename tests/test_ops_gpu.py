@@ -156,6 +156,9 @@ def test_graphsum_row_groups_change_nothing(dev, gname, dim, ld):
     assert np.array_equal(dev.graphsum(g0, xm, ld_in=ld, ld_out=ld, row_nonzero=keep),
                           dev.graphsum(g1, xm, ld_in=ld, ld_out=ld, row_nonzero=keep))
     assert np.array_equal(g0.coef(), g1.coef())
+    for mode, kw in ((2, dict(n_groups=5)), (1, dict(row_group=groups[::-1].copy())), (0, {}), (2, dict(n_groups=1))):
+        g1.set_schedule(mode, **kw)                        # rebuilt in place, any number of times
+        assert np.array_equal(a, dev.graphsum(g1, x, ld_in=ld, ld_out=ld))
     g0.free(); g1.free()
 
 

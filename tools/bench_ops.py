@@ -41,19 +41,26 @@ def main():
         gp, gi = datagen.csr_with_self_loops(lo, hi, 1 << scale)
         del lo, hi
         N = 1 << scale
-        dev = Device(0); lib = dev.lib
-        groups = np.random.default_rng(1).integers(0, 41, N).astype(np.int32) if len(sys.argv) > 4 and sys.argv[4] == "random-groups" else None
-        g = dev.graph(gp, gi, row_group=groups)     # HipGCN uses label groups only when they are assortative
         deg = np.diff(gp)
         print(f"rmat scale {scale}: N={N} nnzA={gi.size} max_deg={deg.max()} built in {time.time() - t0:.1f}s", flush=True)
         rng = np.random.default_rng(0)
-        for dim in (128, 256, 48):
-            x = dev.buf(rng.standard_normal((N, dim), dtype=np.float32)); o = dev.buf((N, dim))
-            d_eff = 41 if dim == 48 else dim
-            ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, dim, o.ptr, dim, d_eff), "gs"), iters=10)
-            bgs = 4 * (N + 1) + 4 * gi.size + 4 * gi.size * d_eff + 4 * N * d_eff
-            print(f"graphsum d={d_eff} ld={dim} table={N * dim * 4 / 2**20:.0f} MiB: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
-            x.free(); o.free()
+        variants = [("degree order", None)]
+        if len(sys.argv) > 4 and sys.argv[4] == "orders":     # which task order suits a graph whose ids carry locality?
+            variants += [("random 41 groups", np.random.default_rng(1).integers(0, 41, N).astype(np.int32))]
+            variants += [(f"id >> {k}", (np.arange(N, dtype=np.int64) >> k).astype(np.int32)) for k in (16, 12)]
+            rank = np.empty(N, np.int64); rank[np.argsort(-deg, kind="stable")] = np.arange(N)
+            variants += [(f"degree rank dealt into {G} groups", (rank % G).astype(np.int32)) for G in (8, 41, 256, 2048)]
+        for tag, groups in variants:
+            dev = Device(0); lib = dev.lib
+            g = dev.graph(gp, gi, row_group=groups)
+            for dim in (128, 256, 48):
+                x = dev.buf(rng.standard_normal((N, dim), dtype=np.float32)); o = dev.buf((N, dim))
+                d_eff = 41 if dim == 48 else dim
+                ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, dim, o.ptr, dim, d_eff), "gs"), iters=10)
+                bgs = 4 * (N + 1) + 4 * gi.size + 4 * gi.size * d_eff + 4 * N * d_eff
+                print(f"[{tag}] graphsum d={d_eff} ld={dim} table={N * dim * 4 / 2**20:.0f} MiB: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
+                x.free(); o.free()
+            g.free(); dev.close()
         return
     ds = datagen.make_dataset(name)
     print("dataset", name, "built in %.1fs" % (time.time() - t0), flush=True)

@@ -40,3 +40,10 @@ bench("label, then degree desc", *permuted(np.lexsort((-deg, lab))))
 bench("degree desc only", *permuted(np.argsort(-deg, kind="stable")))
 o = np.lexsort((-deg, lab))
 bench("label+degree renaming, tasks grouped by label", *permuted(o), lab[o])
+bench("generator order, 41 RANDOM groups (control: blending without communities)", gp, gi, np.random.default_rng(1).integers(0, 41, N).astype(np.int32))
+rank = np.empty(N, np.int64); rank[np.argsort(-deg, kind="stable")] = np.arange(N)
+for G in (8, 41, 256):
+    bench(f"degree rank dealt round-robin into {G} groups", gp, gi, (rank % G).astype(np.int32))
+# communities, each dealt into sub-groups: label-major, then blended inside the label
+for G in (4,):
+    bench(f"label x {G} dealt sub-groups", gp, gi, (lab.astype(np.int64) * G + rank % G).astype(np.int32))
