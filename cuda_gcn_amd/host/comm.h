@@ -31,6 +31,20 @@ struct SelfComm : Comm {
     Comm *clone_for(gcnhip_ctx *) override { return new SelfComm(); }
 };
 
+// Timing aid: rank r of `world` with collectives that do nothing.  The rank computes exactly what it would in
+// a real run (its row block, its share of every kernel) on whatever the gather buffers hold, so per-rank
+// compute time can be measured on one GPU; losses and weights are meaningless.  Never used by bench.py's number.
+struct NullComm : Comm {
+    int r, w;
+    NullComm(int rank, int world) : r(rank), w(world) {}
+    int rank() const override { return r; }
+    int size() const override { return w; }
+    void allgather_rows(float *, size_t) override {}
+    void allreduce_sum(float *, size_t) override {}
+    void allreduce_sum_host(double *, int) override {}
+    Comm *clone_for(gcnhip_ctx *) override { return new NullComm(r, w); }
+};
+
 // RCCL (librccl; "nccl" API) on the context's stream
 #define GCN_NCCL_ID_BYTES 128
 int rccl_get_unique_id(char id[GCN_NCCL_ID_BYTES]);

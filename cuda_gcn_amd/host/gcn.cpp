@@ -51,6 +51,9 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     } else if (opt.world > 1 && opt.host_allgather) {
         owned_comm.reset(make_host_comm(env.ctx, opt.rank, opt.world, opt.host_allgather, opt.host_allreduce, opt.host_user));
         env.comm = owned_comm.get();
+    } else if (opt.world > 1 && (flags & HIPGCN_NULL_COMM)) {
+        owned_comm.reset(new NullComm(opt.rank, opt.world));
+        env.comm = owned_comm.get();
     } else if (opt.world > 1) {
         if (!opt.nccl_id) throw GcnHipFailure(-1, "world > 1 needs an RCCL unique id");
         owned_comm.reset(make_rccl_comm(env.ctx, opt.rank, opt.world, opt.nccl_id));

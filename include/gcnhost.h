@@ -39,7 +39,8 @@ enum {
     GCNHOST_NO_REPLICATE_L1 = 64, /* multi-GPU: all-gather H0 instead of replicating the first-layer product */
     GCNHOST_REPLICATE_L1 = 128,   /* force the replication (default: on for 2-4 GPUs, off for 8) */
     GCNHOST_GATHER_DH1 = 256,     /* multi-GPU backward: all-gather dH1 instead of dZ0 + mask bits */
-    GCNHOST_NO_ROW_GROUPS = 512   /* do not schedule the aggregation's rows label by label (locality hint off) */
+    GCNHOST_NO_ROW_GROUPS = 512,  /* keep the plain descending-degree row schedule (no load-time timing of alternatives) */
+    GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 
 #define GCNHOST_NCCL_ID_BYTES 128

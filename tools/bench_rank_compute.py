@@ -1,0 +1,45 @@
+"""Per-rank COMPUTE time of the row-partitioned epoch, measured on one GPU (no 8-GPU box this round):
+rank r of P is built exactly as in a real run (its row block, replicated first layer for P <= 4, the
+rebuilt dH1, its own row schedule) but with no-op collectives (NULL_COMM), and K epochs are timed.
+The slowest rank bounds the epoch from below; what a real run adds is the all-gathers' time that the
+validation lane does not hide.  Losses are meaningless here (gather buffers are never filled).
+
+    python tools/bench_rank_compute.py [dataset] [hidden] [P ...]
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (one HIP runtime in the process)
+from cuda_gcn_amd import datagen
+from cuda_gcn_amd.model import HipGCNModel, NULL_COMM, NO_EVAL_LANE, TIMERS
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "reddit-syn"
+    hidden = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    worlds = [int(a) for a in sys.argv[3:]] or [1, 2, 4, 8]
+    ds = datagen.make_dataset(name)
+    out = {}
+    for P in worlds:
+        per_rank = []
+        for r in range(P):
+            flags = NO_EVAL_LANE | (NULL_COMM if P > 1 else 0)
+            m = HipGCNModel(ds, seed=1, flags=flags, rank=r, world=P, hidden_dim=hidden, dropout=0.5, epochs=40)
+            m.run_epochs(3, want_trace=False)
+            m.sync()
+            t0 = time.perf_counter()
+            m.run_epochs(10, want_trace=False)
+            m.sync()
+            ms = 1e3 * (time.perf_counter() - t0) / 10
+            info = m.info()
+            per_rank.append(dict(rank=r, ms=round(ms, 3), rows=info["local_rows"], edges=info["local_edges"], schedule=m.schedule()))
+            m.close()
+            if P == 8 and r >= 1:
+                break                      # blocks are balanced by edges; two ranks are enough at P = 8
+        out[P] = per_rank
+        worst = max(x["ms"] for x in per_rank)
+        print(f"P={P}: slowest rank {worst:.3f} ms per epoch (compute only) -> ceiling {1e3 / worst:.0f} epochs/s; {per_rank}", flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
