@@ -153,12 +153,22 @@ __global__ void edge_coef_kernel(const int *__restrict__ indptr, const int *__re
     }
 }
 
-constexpr int SPLIT_EDGES = 1024;   // rows longer than this are cut into segments
+// Rows longer than the split length are cut into segments (one wave each).  A segment is a serial walk, so it
+// must stay short against the work one wave slot gets: nnz / (256 CUs x 32 waves), clamped to [128, 1024]
+// (a full Reddit graph keeps 1024; a 1/8 row block of it gets 256, which removed a 50 us critical path
+// from a 130 us launch).
+static int split_length(int64_t nnz) {
+    if (const char *e = getenv("GCNHIP_SPLIT_EDGES")) { const int v = atoi(e); if (v >= 16) return v; }   // experiments
+    int s = 1024;
+    while (s > 128 && (int64_t)s * 8192 > nnz) s >>= 1;
+    return s;
+}
 
 // (Re)build the row schedule: tasks ordered by (key[row] ascending, degree descending); key == nullptr: degree only.
 static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
     const int n_rows = g->n_rows;
     const int *h_indptr = g->h_indptr->data();
+    const int SPLIT_EDGES = split_length(g->nnz);
     if (g->tasks) { GCNHIP_TRY(hipFree(g->tasks)); g->tasks = nullptr; }
     if (g->split_rows) { GCNHIP_TRY(hipFree(g->split_rows)); g->split_rows = nullptr; }
     // Task list: rows in descending degree order (heavy work first, similar rows together), group-major

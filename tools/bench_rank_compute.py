@@ -22,15 +22,23 @@ def main():
     for P in worlds:
         per_rank = []
         for r in range(P):
-            flags = NO_EVAL_LANE | (NULL_COMM if P > 1 else 0)
+            flags = NO_EVAL_LANE | (NULL_COMM if P > 1 else 0) | (TIMERS if os.environ.get("RANK_TIMERS") else 0)
             m = HipGCNModel(ds, seed=1, flags=flags, rank=r, world=P, hidden_dim=hidden, dropout=0.5, epochs=40)
             m.run_epochs(3, want_trace=False)
             m.sync()
+            m.timers_reset()
             t0 = time.perf_counter()
             m.run_epochs(10, want_trace=False)
             m.sync()
             ms = 1e3 * (time.perf_counter() - t0) / 10
             info = m.info()
+            if os.environ.get("RANK_TIMERS") and r == 0:
+                bd = {}
+                for nm in ("spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw", "matmul_fw", "matmul_bw", "loss_fw", "adam", "comm"):
+                    sec, n = m.timer(nm)
+                    if n:
+                        bd[nm] = round(1e3 * sec / 10, 4)
+                print(f"  P={P} rank 0 timers (ms per epoch): {bd}  sum={sum(bd.values()):.3f}", flush=True)
             per_rank.append(dict(rank=r, ms=round(ms, 3), rows=info["local_rows"], edges=info["local_edges"], schedule=m.schedule()))
             m.close()
             if P == 8 and r >= 1:
