@@ -382,11 +382,11 @@ static int feat_create_impl(gcnhip_ctx *c, gcnhip_feat *f, const int *h_indptr, 
     GCNHIP_TRY(hipMemcpy(f->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
     GCNHIP_TRY(hipMalloc((void **)&f->values, (size_t)std::max<int64_t>(nnz, 4) * sizeof(float)));
     if (nnz) GCNHIP_TRY(hipMemcpy(f->values, h_values, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
-    GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (size_t)(nnz / 32 + 2) * sizeof(uint32_t)));
-    if (dense && n_cols % 4 != 0 && n_cols >= 64) {
-        // the MFMA tiles stage X with 16-byte lane loads when every row starts on a 16-byte boundary
-        // (7 % faster than 8-byte loads at 602 columns); HBM has room for the second copy
-        f->ld_pad = (n_cols + 3) / 4 * 4;
+    GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (size_t)(nnz / 32 + 32) * sizeof(uint32_t)));   // slack: tiles read bits of pad columns
+    if (dense && n_cols % 128 != 0 && n_cols >= 64) {
+        // the MFMA tiles stage X with unconditional 16-byte lane loads when every row starts on a 16-byte
+        // boundary and its stride covers whole 128-column tiles (zero padded); HBM has room for the second copy
+        f->ld_pad = (n_cols + 127) / 128 * 128;
         GCNHIP_TRY(hipMalloc((void **)&f->values_pad, (size_t)n_rows * f->ld_pad * sizeof(float)));
         GCNHIP_TRY(hipMemset(f->values_pad, 0, (size_t)n_rows * f->ld_pad * sizeof(float)));
         GCNHIP_TRY(hipMemcpy2D(f->values_pad, (size_t)f->ld_pad * sizeof(float), f->values, (size_t)n_cols * sizeof(float),

@@ -74,7 +74,12 @@ __device__ inline uint32_t bits_at(const uint32_t *bits, uint64_t e) {
 constexpr int T_BM = 128, T_BN = 128, T_BK = 32;
 constexpr int T_ALD = T_BK + 1;       // A tile [row][k]: lanes of a half-wave walk rows -> odd stride, conflict-free
 
-template <int VX>
+// FAST: the launch site guarantees 16-byte aligned rows of X whose stride covers round_up(K, 32) columns
+// (zero padded), ldw % 4 == 0 and full 128-column output tiles.  Then every load of the K loop is
+// unconditional — rows past m are clamped to the last row and dropped at the store, W rows past K are read
+// clamped and zeroed by a select — so the compiler issues the whole prefetch as one clause instead of a
+// chain of divergent branches with a wait in each.
+template <int VX, bool FAST = false>
 __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
     __shared__ float As[T_BM * T_ALD];
     __shared__ __attribute__((aligned(16))) float Bs[T_BK * T_BN];
@@ -89,6 +94,29 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
     float4 breg[4];                                       // wait for the loads before the MFMA loop starts
 
     auto fetch = [&](int k0) {
+        if constexpr (FAST) {
+            static_assert(!FAST || VX == 4, "fast path stages X with 16-byte loads");
+#pragma unroll
+            for (int pc = 0; pc < A_PIECES; pc++) {
+                const int idx = pc * 256 + tid;
+                const int r = idx / LPR, c = (idx % LPR) * VX;
+                const int row = min(row_base + r, a.m - 1), col = k0 + c;
+                const float4 v = *reinterpret_cast<const float4 *>(a.x + (size_t)row * a.ldx + col);
+                areg[pc][0] = v.x; areg[pc][1] = v.y; areg[pc][2] = v.z; areg[pc][3] = v.w;
+                if (a.bits) {
+                    const uint64_t w = ((uint64_t)row * a.K + col) >> 5;
+                    kreg[pc] = (uint64_t)a.bits[w] | ((uint64_t)a.bits[w + 1] << 32);
+                }
+            }
+#pragma unroll
+            for (int pc = 0; pc < 4; pc++) {
+                const int idx = (pc * 256 + tid) * 4;
+                const int k = idx / T_BN, c = idx % T_BN;
+                const int gk = k0 + k;
+                breg[pc] = *reinterpret_cast<const float4 *>(a.w + (size_t)min(gk, a.K - 1) * a.ldw + col_base + c);   // zeroed in stash()
+            }
+            return;
+        }
 #pragma unroll
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
@@ -129,7 +157,8 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
             const int r = idx / LPR, c = (idx % LPR) * VX;
-            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)(row_base + r) * a.K + cur_k0 + c) & 31)) : 0xFu;
+            const int brow = FAST ? min(row_base + r, a.m - 1) : row_base + r;
+            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)brow * a.K + cur_k0 + c) & 31)) : 0xFu;
 #pragma unroll
             for (int s = 0; s < VX; s++)
                 As[r * T_ALD + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
@@ -137,7 +166,10 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
 #pragma unroll
         for (int pc = 0; pc < 4; pc++) {
             const int idx = (pc * 256 + tid) * 4;
-            *reinterpret_cast<float4 *>(&Bs[idx]) = breg[pc];
+            float4 v = breg[pc];
+            // any ALU on a prefetched register belongs HERE, after the MFMA loop the loads were hidden behind
+            if (FAST && cur_k0 + idx / T_BN >= a.K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&Bs[idx]) = v;
         }
     };
 
@@ -154,7 +186,7 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
         __syncthreads();
         stash(k0);
         __syncthreads();
-        if (k0 + T_BK < a.K) fetch(k0 + T_BK);
+        if (k0 + T_BK < a.K) fetch(k0 + T_BK);      // FAST: k0 + 32 <= round_up(K, 32) <= ldx
         const float *Ap = &As[(wm * 64 + li) * T_ALD + kq];
         const float *Bp = &Bs[kq * T_BN + wn * 64 + li];
 #pragma unroll
@@ -185,7 +217,9 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
 // grid (S splits of the row range, K tiles of 128 X-columns, p tiles of 128).
 // LDS tiles are k-major exactly as loaded: As[k][xcol], Bs[k][pcol]; both MFMA
 // operands read 32 consecutive floats per half-wave (conflict-free).
-template <int VX>
+// FAST: 16-byte aligned rows of X whose stride covers round_up(K, 128) columns (zero padded), ldw % 4 == 0,
+// full 128-column tiles of dH0.  Rows past the split's end are read clamped and zeroed by selects.
+template <int VX, bool FAST = false>
 __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
     __shared__ __attribute__((aligned(16))) float As[T_BK * 128];
     __shared__ __attribute__((aligned(16))) float Bs[T_BK * 128];
@@ -202,6 +236,28 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
     float4 breg[4];
 
     auto fetch = [&](int r0) {
+        if constexpr (FAST) {
+            static_assert(!FAST || VX == 4, "fast path stages X with 16-byte loads");
+#pragma unroll
+            for (int pc = 0; pc < A_PIECES; pc++) {
+                const int idx = pc * 256 + tid;
+                const int k = idx / LPR, c = (idx % LPR) * VX;
+                const int row = min(r0 + k, r_end - 1), col = xc_base + c;
+                const float4 v = *reinterpret_cast<const float4 *>(a.x + (size_t)row * a.ldx + col);   // rows past r_end: zeroed in stash()
+                areg[pc][0] = v.x; areg[pc][1] = v.y; areg[pc][2] = v.z; areg[pc][3] = v.w;
+                if (a.bits) {
+                    const uint64_t w = ((uint64_t)row * a.K + col) >> 5;
+                    kreg[pc] = (uint64_t)a.bits[w] | ((uint64_t)a.bits[w + 1] << 32);
+                }
+            }
+#pragma unroll
+            for (int pc = 0; pc < 4; pc++) {
+                const int idx = (pc * 256 + tid) * 4;
+                const int k = idx / 128, c = idx % 128;
+                breg[pc] = *reinterpret_cast<const float4 *>(a.w + (size_t)min(r0 + k, r_end - 1) * a.ldw + pc_base + c);
+            }
+            return;
+        }
 #pragma unroll
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
@@ -242,7 +298,8 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
         for (int pc = 0; pc < A_PIECES; pc++) {
             const int idx = pc * 256 + tid;
             const int k = idx / LPR, c = (idx % LPR) * VX;
-            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)(cur_r0 + k) * a.K + xc_base + c) & 31)) : 0xFu;
+            const int brow = FAST ? min(cur_r0 + k, r_end - 1) : cur_r0 + k;
+            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)brow * a.K + xc_base + c) & 31)) : 0xFu;
 #pragma unroll
             for (int s = 0; s < VX; s++)
                 As[k * 128 + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
@@ -250,7 +307,9 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
 #pragma unroll
         for (int pc = 0; pc < 4; pc++) {
             const int idx = (pc * 256 + tid) * 4;
-            *reinterpret_cast<float4 *>(&Bs[idx]) = breg[pc];
+            float4 v = breg[pc];
+            if (FAST && cur_r0 + idx / 128 >= r_end) v = make_float4(0.f, 0.f, 0.f, 0.f);   // dH0 rows past the split: A may then hold anything finite
+            *reinterpret_cast<float4 *>(&Bs[idx]) = v;
         }
     };
 

@@ -328,7 +328,9 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }   // aligned copy of the pristine X
         t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = 0;
         dim3 grid(ceil_div(f->n_rows, T_BM), ceil_div(p, T_BN));
-        if (vx == 4) dense_fwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
+        const bool fast = vx == 4 && t.ldx % 4 == 0 && (t.K + 31) / 32 * 32 <= t.ldx && ld_w % 4 == 0 && p % T_BN == 0 && aligned16(w);
+        if (fast) dense_fwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);
+        else if (vx == 4) dense_fwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
         else if (vx == 2) dense_fwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
         else dense_fwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
         GCNHIP_LAUNCH_CHECK();
@@ -394,7 +396,9 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }
         t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps;
         dim3 grid(S, kt, pt);
-        if (vx == 4) dense_bwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
+        const bool fast = vx == 4 && t.ldx % 4 == 0 && kt * 128 <= t.ldx && ld_dout % 4 == 0 && p % 128 == 0 && aligned16(dout);
+        if (fast) dense_bwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);
+        else if (vx == 4) dense_bwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
         else if (vx == 2) dense_bwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
         else dense_bwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
         GCNHIP_LAUNCH_CHECK();
