@@ -97,6 +97,8 @@ GCNHIP_SYMBOLS = {
     "gcnhip_matmul_bwd": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd_fused": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F]),
     "gcnhip_pack_positive": (I, [P, P, I, I, I, P, I]),
+    "gcnhip_f32_to_bf16": (I, [P, P, I, P, I, I64, I]),
+    "gcnhip_graphsum_bf16": (I, [P, P, P, I, P, I, I, P, I, I, F, U64, P, U64, P]),
     "gcnhip_matmul_bwd_da_bits": (I, [P, P, I, P, I, P, I, I, I, I, P, I, F]),
     "gcnhip_relu_fwd": (I, [P, P, P, I64, I]),
     "gcnhip_relu_bwd": (I, [P, P, P, I64]),

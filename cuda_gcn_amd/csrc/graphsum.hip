@@ -29,6 +29,7 @@ struct GsArgs {
     const int4 *tasks;
     int n_tasks, n_rows;
     const float *in;
+    const uint16_t *in_bf;   // bf16 copy of the gathered table (opt-in storage format); row stride ld_in values
     float *out;
     float *partials;
     int ld_in, ld_out, part_ld, dim;
@@ -152,6 +153,119 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     }
 }
 
+// ---- bf16 table, f32 accumulate (opt-in storage format) ------------------------
+// The gathered rows are stored as bfloat16 (round-to-nearest-even of the f32 values, made by
+// gcnhip_f32_to_bf16), so a row of d values is d*2 bytes: half the 128-byte lines per edge.  coef, the
+// sum and the output stay f32.  L lanes per row slice, 8 values (16 bytes) per lane; slices of 64 columns
+// = one line, bound to XCD groups like the f32 kernel.
+__device__ inline void bf8_fma(float c, const uint4 v, float4 &lo, float4 &hi) {
+    lo.x += c * __uint_as_float(v.x << 16); lo.y += c * __uint_as_float(v.x & 0xFFFF0000u);
+    lo.z += c * __uint_as_float(v.y << 16); lo.w += c * __uint_as_float(v.y & 0xFFFF0000u);
+    hi.x += c * __uint_as_float(v.z << 16); hi.y += c * __uint_as_float(v.z & 0xFFFF0000u);
+    hi.z += c * __uint_as_float(v.w << 16); hi.w += c * __uint_as_float(v.w & 0xFFFF0000u);
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void graphsum_bf16_kernel(GsArgs a) {
+    constexpr int G = WAVE / L;
+    const int lane = threadIdx.x & 63;
+    int t, cslice;
+    {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        cslice = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
+        const int g_id = xcd / a.n_slices;
+        t = a.bounds[g_id] + q * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (t >= a.bounds[g_id + 1]) return;
+    }
+    int row, e0, e1, slot;
+    if (a.n_tasks) {
+        const int4 tk = a.tasks[t];
+        row = tk.x; e0 = tk.y; e1 = tk.z; slot = tk.w;
+    } else {
+        row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
+    }
+    const int g = lane / L, l = lane % L;
+    const int col0 = (cslice * L + l) * 8;
+    const bool active = col0 < a.dim;
+    const uint16_t *in = a.in_bf + col0;
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    for (int base = e0; base < e1; base += WAVE) {
+        const int cnt = min(WAVE, e1 - base);
+        int my_idx = 0;
+        float my_c = 0.f;
+        if (lane < cnt) {
+            my_idx = a.indices[base + lane];
+            my_c = a.coef[base + lane];
+            if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
+        }
+        const int iters = (cnt + G - 1) / G;
+#pragma unroll 8
+        for (int k = 0; k < iters; k++) {
+            const int src = k * G + g;
+            const int j = __shfl(my_idx, src, WAVE);
+            const float c = __shfl(my_c, src, WAVE);
+            if (active && src < cnt && c != 0.f) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(in + (size_t)j * a.ld_in);
+                bf8_fma(c, v, lo, hi);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = L; m < WAVE; m <<= 1) { lo = f4_add(lo, f4_shfl_xor(lo, m)); hi = f4_add(hi, f4_shfl_xor(hi, m)); }
+    if (g == 0 && active) {
+        if (slot >= 0) {
+            float *pp = a.partials + (size_t)slot * a.part_ld + col0;
+            *reinterpret_cast<float4 *>(pp) = lo;
+            *reinterpret_cast<float4 *>(pp + 4) = hi;
+        } else {
+            if (a.fuse) { lo = relu_dropout4(lo, a, row, col0); hi = relu_dropout4(hi, a, row, col0 + 4); }
+            float *o = a.out + (size_t)row * a.ld_out + col0;
+            const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (col0 + 8 <= a.dim && (a.ld_out & 3) == 0) {
+                *reinterpret_cast<float4 *>(o) = lo;
+                *reinterpret_cast<float4 *>(o + 4) = hi;
+            } else {
+                for (int i = 0; i < 8 && col0 + i < a.dim; i++) o[i] = x[i];
+            }
+        }
+    }
+}
+
+// f32 -> bf16 (round to nearest even; NaN stays NaN), columns dim..ld_dst-1 of every row written as 0
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ src, int ld_src, uint16_t *__restrict__ dst, int ld_dst,
+                                                          int64_t rows, int dim) {
+    const int per_row = ld_dst / 8;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c0 = (int)(i % per_row) * 8;
+        uint32_t h[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float f = c0 + k < dim ? src[r * ld_src + c0 + k] : 0.f;
+            const uint32_t u = __float_as_uint(f);
+            h[k] = (f != f) ? ((u >> 16) | 0x40u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        }
+        uint4 v;
+        v.x = (h[0] & 0xFFFFu) | (h[1] << 16); v.y = (h[2] & 0xFFFFu) | (h[3] << 16);
+        v.z = (h[4] & 0xFFFFu) | (h[5] << 16); v.w = (h[6] & 0xFFFFu) | (h[7] << 16);
+        *reinterpret_cast<uint4 *>(dst + r * ld_dst + c0) = v;
+    }
+}
+
+template <int L>
+static void launch_bf16(GsArgs a, const gcnhip_graph *g, hipStream_t s) {
+    const int ychunks = ceil_div(a.dim, L * 8);
+    const bool sliced = ychunks > 1 && 8 % ychunks == 0;
+    a.n_slices = sliced ? ychunks : 1;
+    const int G = 8 / a.n_slices;
+    const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
+    int max_blocks = 1;
+    for (int k = 0; k <= 8; k++) a.bounds[k] = g->bounds[lg][k];
+    for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
+    graphsum_bf16_kernel<L><<<dim3(max_blocks * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
+}
+
 // Any ld / alignment: scalar loads, lane l owns columns l, l+L, ...
 template <int L>
 __global__ __launch_bounds__(256) void graphsum_scalar_kernel(GsArgs a) {
@@ -265,21 +379,23 @@ static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
 
 static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in, float *out, int ld_out,
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
-                         uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr) {
-    if (!c || !g || !in || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
+                         uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
+                         const uint16_t *in_bf = nullptr) {
+    if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
+    if (in_bf && (ld_in % 8 != 0 || !aligned16(in_bf))) return -1;
     if (g->n_rows == 0) return 0;
     gcnhip_graph *gm = const_cast<gcnhip_graph *>(g);
-    if (g->n_slots && g->part_ld < dim) {      // first call at this width: size the segment scratch
+    if (g->n_slots && g->part_ld < (dim + 7) / 8 * 8) {      // first call at this width: size the segment scratch
         GCNHIP_TRY(hipStreamSynchronize(c->stream));
         if (gm->partials) GCNHIP_TRY(hipFree(gm->partials));
-        gm->part_ld = (dim + 3) / 4 * 4;
+        gm->part_ld = (dim + 7) / 8 * 8;
         if (gm->part_ld < 256) gm->part_ld = 256;
         GCNHIP_TRY(hipMalloc((void **)&gm->partials, (size_t)g->n_slots * gm->part_ld * sizeof(float)));
     }
     GsArgs a;
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
     a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows;
-    a.in = in; a.out = out; a.partials = g->partials;
+    a.in = in; a.in_bf = in_bf; a.out = out; a.partials = g->partials;
     a.ld_in = ld_in; a.ld_out = ld_out; a.part_ld = g->part_ld; a.dim = dim;
     a.fuse = fuse; a.training = training; a.thr = dropout_threshold(p);
     a.scale = 1 / (1 - p);                                  // module.cpp:212
@@ -289,7 +405,13 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
     a.n_slices = 1;
-    if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
+    if (in_bf) {
+        const int d8 = (dim + 7) / 8;                       // 16-byte pieces per row
+        if (d8 <= 1) launch_bf16<1>(a, g, c->stream);
+        else if (d8 <= 2) launch_bf16<2>(a, g, c->stream);
+        else if (d8 <= 4) launch_bf16<4>(a, g, c->stream);
+        else launch_bf16<8>(a, g, c->stream);               // 64-column (one line) slices, one per XCD group when 8 % slices == 0
+    } else if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
         // rows of whole 128-byte lines: one 32-float column slice per XCD group (measured at
         // Reddit scale, d = 128: 1.42 ms unsliced -> 1.26 ms; L2 hit rate of the gather rises
         // because each XCD's L2 holds a quarter of the table)
@@ -337,6 +459,25 @@ int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const flo
                                  const uint8_t *keep_mask) {
     if (training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 1, training, p, seed, d_epoch, elem_offset, keep_mask);
+}
+
+int gcnhip_f32_to_bf16(gcnhip_ctx *c, const float *src, int ld_src, uint16_t *dst, int ld_dst, int64_t rows, int dim) {
+    if (!c || !src || !dst || rows < 0 || dim <= 0 || ld_src < dim || ld_dst < dim || ld_dst % 8 != 0 || !aligned16(dst)) return -1;
+    if (rows == 0) return 0;
+    int64_t blocks = (rows * (ld_dst / 8) + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    f32_to_bf16_kernel<<<(int)blocks, 256, 0, c->stream>>>(src, ld_src, dst, ld_dst, rows, dim);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int gcnhip_graphsum_bf16(gcnhip_ctx *c, const gcnhip_graph *g, const uint16_t *in_bf16, int ld_in,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits,
+                         int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
+                         uint64_t elem_offset, const uint8_t *keep_mask) {
+    if (relu_dropout && training && !(p >= 0.f && p < 1.f)) return -1;
+    return graphsum_impl(c, g, nullptr, ld_in, out, ld_out, dim, relu_dropout ? 1 : 0, training, relu_dropout ? p : 0.f, seed, d_epoch,
+                         elem_offset, keep_mask, in_row_bits, in_bf16);
 }
 
 }  // extern "C"

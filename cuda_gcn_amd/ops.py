@@ -121,6 +121,37 @@ class Device:
             _ck(self.lib, self.lib.gcnhip_graphsum_rowmask(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr), "gcnhip_graphsum_rowmask")
         return out.download()[:, :dim]
 
+    def to_bf16(self, x, ld_dst=None):
+        """f32 rows -> bf16 table (uint16 [rows, ld_dst]) through gcnhip_f32_to_bf16"""
+        x = np.asarray(x, np.float32)
+        rows, dim = x.shape
+        ld_dst = ld_dst or (dim + 7) // 8 * 8
+        xb = self.buf(np.ascontiguousarray(x))
+        dst = self.buf(np.full((rows, ld_dst), 0xFFFF, np.uint16))
+        _ck(self.lib, self.lib.gcnhip_f32_to_bf16(self.ctx, xb.ptr, dim, dst.ptr, ld_dst, rows, dim), "gcnhip_f32_to_bf16")
+        return dst.download()
+
+    def graphsum_bf16(self, g: "Graph", table_u16, dim, ld_out=None, row_nonzero=None, relu_dropout=None):
+        """GraphSum over a bf16 table (uint16 [n_cols, ld]); relu_dropout = dict(training, p, seed, epoch, elem_offset, keep_mask)"""
+        t = np.ascontiguousarray(table_u16, np.uint16)
+        ld_in = t.shape[1]
+        ld_out = ld_out or dim
+        tb = self.buf(t)
+        out = self.buf(np.full((g.n_rows, ld_out), np.nan, np.float32))
+        bb = None
+        if row_nonzero is not None:
+            bits = np.packbits(np.asarray(row_nonzero, bool), bitorder="little")
+            bits = np.concatenate([bits, np.zeros((-bits.size) % 4 + 4, np.uint8)]).view(np.uint32)
+            bb = self.buf(bits)
+        rd = relu_dropout or {}
+        ep = self.buf(np.array([rd.get("epoch", 0)], np.uint32))
+        km = self.buf(np.ascontiguousarray(rd["keep_mask"], np.uint8)) if rd.get("keep_mask") is not None else None
+        _ck(self.lib, self.lib.gcnhip_graphsum_bf16(self.ctx, g.h, tb.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr if bb else None,
+                                                     1 if relu_dropout is not None else 0, int(rd.get("training", 0)), float(rd.get("p", 0.0)),
+                                                     int(rd.get("seed", 0)), ep.ptr, int(rd.get("elem_offset", 0)), km.ptr if km else None),
+            "gcnhip_graphsum_bf16")
+        return out.download()[:, :dim]
+
     def graphsum_relu_dropout(self, g, x, training, p, seed=0, epoch=0, elem_offset=0, keep_mask=None, ld=None):
         x = np.asarray(x, np.float32)
         dim = x.shape[1]

@@ -154,6 +154,20 @@ int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, co
                     float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
                     uint64_t nnz_offset, const uint8_t *keep_mask);
 
+/* ---- opt-in storage format: bfloat16 gathered tables (beyond the reference) ----------
+ * gcnhip_f32_to_bf16 rounds rows of f32 to bf16 (nearest even; NaN kept) into a table with row stride ld_dst
+ * (multiple of 8, 16-byte aligned; columns dim..ld_dst-1 are written as zero).  gcnhip_graphsum_bf16 is
+ * GraphSum reading that table: coef, the running sum and `out` are f32, so the ONLY difference to
+ * gcnhip_graphsum* is the rounding of the gathered values — on a table that holds bf16-representable numbers
+ * the two agree bit for bit.  A row of d values is 2d bytes: half the cache lines per edge.
+ * in_row_bits (optional) as in gcnhip_graphsum_rowmask; relu_dropout != 0 selects the fused epilogue of
+ * gcnhip_graphsum_relu_dropout with the arguments that follow. */
+int gcnhip_f32_to_bf16(gcnhip_ctx *ctx, const float *src, int ld_src, uint16_t *dst, int ld_dst, int64_t rows, int dim);
+int gcnhip_graphsum_bf16(gcnhip_ctx *ctx, const gcnhip_graph *g, const uint16_t *in_bf16, int ld_in,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits,
+                         int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
+                         uint64_t elem_offset, const uint8_t *keep_mask);
+
 /* ---- Matmul (CUDAMatmul: cuda_module.cu:8-34; kernels cuda_kernel.cu:6-96;
  *      CPU: src/seq/module.cpp:11-42) -------------------------------------------
  * forward : c[m x p] = a[m x n] . b[n x p]

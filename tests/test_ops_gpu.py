@@ -162,6 +162,48 @@ def test_graphsum_row_groups_change_nothing(dev, gname, dim, ld):
     g0.free(); g1.free()
 
 
+def bf16_round(x):
+    """numpy restatement of gcnhip_f32_to_bf16 (round to nearest even) -> (uint16 codes, f32 values)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    h = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    return h, (h.astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.mark.parametrize("gname", ["cora", "hub"])
+@pytest.mark.parametrize("dim,ld", [(128, 128), (41, 64), (41, 48), (16, 16), (7, 8), (200, 256), (192, 192)])
+def test_graphsum_bf16_table(dev, oracle, gname, dim, ld):
+    """opt-in bf16 storage of the gathered table: the converter rounds to nearest even, and the
+    aggregation differs from the f32 one ONLY by that rounding — against the oracle on the rounded
+    values it meets the f32 bound, at d = 128 (same lane grouping) it is bit-identical to the f32 kernel"""
+    if gname == "cora":
+        ds = datagen.make_dataset("cora-syn"); gp, gi = ds["g_indptr"], ds["g_indices"]
+    else:
+        gp, gi = hub_graph()
+    n = gp.size - 1
+    rng = np.random.default_rng(dim * 3 + n)
+    x = (rng.standard_normal((n, dim)) * np.exp(rng.uniform(-8, 8, (n, dim)))).astype(np.float32)
+    x[0, 0] = 0.0; x[1, 0] = -0.0; x[2, 0] = np.float32(1.0) + np.float32(2.0 ** -8)      # a tie: rounds to even
+    codes, xr = bf16_round(x)
+    tab = dev.to_bf16(x, ld_dst=ld)
+    assert np.array_equal(tab[:, :dim], codes) and not tab[:, dim:].any()
+    g = dev.graph(gp, gi)
+    got = dev.graphsum_bf16(g, tab, dim)
+    close_mag(got, oracle.graphsum(gp, gi, xr, dim), oracle.graphsum(gp, gi, np.abs(xr), dim))
+    if dim == 128:
+        assert np.array_equal(got, dev.graphsum(g, xr))
+    keep = rng.random(n) < 0.5
+    tm = tab * keep[:, None].astype(np.uint16)
+    got_m = dev.graphsum_bf16(g, tm, dim, row_nonzero=keep)
+    xm = xr * keep[:, None]
+    close_mag(got_m, oracle.graphsum(gp, gi, xm, dim), oracle.graphsum(gp, gi, np.abs(xm), dim))
+    # fused ReLU + dropout epilogue with explicit decisions
+    km = (rng.random((n, dim)) < 0.6).astype(np.uint8)
+    got_f = dev.graphsum_bf16(g, tab, dim, relu_dropout=dict(training=1, p=0.25, keep_mask=km))
+    want_f = np.maximum(got, 0) * km * np.float32(1 / (1 - 0.25))
+    assert np.allclose(got_f, want_f, rtol=1e-6, atol=0)
+    g.free()
+
+
 @pytest.mark.parametrize("g", ["karate", "tiny", "ragged"])
 @pytest.mark.parametrize("dim", [1, 7, 16, 41])
 def test_graphsum_golden(dev, mods, g, dim):
