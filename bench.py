@@ -29,10 +29,10 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def b_gs(n_rows, nnz, d):
-    """algorithmic bytes of one GraphSum call: indptr + indices + one d-float
-    neighbour row per edge + one output row per node"""
-    return 4 * (n_rows + 1) + 4 * nnz + 4 * nnz * d + 4 * n_rows * d
+def b_gs(n_rows, nnz, d, in_bytes=4):
+    """algorithmic bytes of one GraphSum call: indptr + indices + one d-value
+    neighbour row per edge (f32, or 2-byte bf16 with --bf16-tables) + one f32 output row per node"""
+    return 4 * (n_rows + 1) + 4 * nnz + in_bytes * nnz * d + 4 * n_rows * d
 
 
 def cpu_baseline(ds_full, hidden, budget_s=30.0):
@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--dataset", default="reddit-syn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16-tables", action="store_true",
+                    help="opt-in, NOT the headline: GraphSum gathers bfloat16 copies of its inputs (f32 sums); reported as dtype f32+bf16-tables")
     ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
                     help="validation forward on a second stream (auto: only with more than one GPU)")
     args = ap.parse_args()
@@ -103,7 +105,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)    # control plane; data plane is RCCL in libgcnhost
 
     from cuda_gcn_amd import datagen
-    from cuda_gcn_amd.model import HipGCNModel, TIMERS, EVAL_LANE, NO_EVAL_LANE, nccl_unique_id
+    from cuda_gcn_amd.model import HipGCNModel, TIMERS, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, nccl_unique_id
 
     def barrier():
         if world > 1:
@@ -129,7 +131,7 @@ def main():
     lane_flag = {"auto": 0, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
     device = int(os.environ.get("GCN_BENCH_DEVICE", local_rank))
     t0 = time.perf_counter()
-    model = HipGCNModel(ds, seed=1, device=device, flags=TIMERS | lane_flag, rank=rank, world=world, nccl_id=nccl_id,
+    model = HipGCNModel(ds, seed=1, device=device, flags=TIMERS | lane_flag | (BF16_TABLES if args.bf16_tables else 0), rank=rank, world=world, nccl_id=nccl_id,
                         host_allgather=host_ag, host_allreduce=host_ar,
                         hidden_dim=args.hidden, dropout=0.5, epochs=2 * args.steps + args.warmup)
     t_build = time.perf_counter() - t0     # host preprocessing (edge order, schedules) + every H2D copy + schedule timing
@@ -173,16 +175,17 @@ def main():
         # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be collected live here)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_graphsum_pmc.json")
-        if world == 1 and args.dataset == "reddit-syn" and args.hidden == 128 and os.path.exists(pmc):
+        if world == 1 and args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and os.path.exists(pmc):
             k = json.load(open(pmc)).get("graphsum_vec_kernel<8>", {})
             if "traffic_bytes_per_launch" in k:
                 traffic = k["traffic_bytes_per_launch"]
                 traffic_src = "profiles/r01_graphsum_pmc.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, rocprofv3 --pmc in separate passes"
+        ib = 2 if args.bf16_tables else 4
         if args.hidden > 64:
-            bytes_per_launch = b_gs(info["local_rows"], info["local_edges"], args.hidden)
+            bytes_per_launch = b_gs(info["local_rows"], info["local_edges"], args.hidden, ib)
         else:                                         # average over the hidden- and class-width launches (3 + 3 per epoch)
-            bytes_per_launch = (b_gs(info["local_rows"], info["local_edges"], args.hidden) +
-                                b_gs(info["local_rows"], info["local_edges"], ds["output_dim"])) / 2
+            bytes_per_launch = (b_gs(info["local_rows"], info["local_edges"], args.hidden, ib) +
+                                b_gs(info["local_rows"], info["local_edges"], ds["output_dim"], ib)) / 2
         table_mb = ds["num_nodes"] * args.hidden * 4 / 1e6
         avg_s = s_wide / max(n_wide, 1)
         achieved = bytes_per_launch / avg_s / 1e9
@@ -190,14 +193,15 @@ def main():
         out = {
             "metric": "epochs_per_sec", "value": args.steps / dt, "unit": "epochs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+bf16-tables" if args.bf16_tables else "f32", "data": "synthetic",
             "config": {"workload": f"{args.dataset} full-batch 2-layer GCN, N={ds['num_nodes']}, "
                                    f"{(ds['g_indices'].size - ds['num_nodes']) // 2} undirected edges, "
                                    f"{ds['input_dim']}->{args.hidden}->{ds['output_dim']}, dropout 0.5, Adam; "
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": model.schedule()},
-            "roofline": {"bound": "hbm", "kernel": (f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})" if args.hidden > 64 else
+            "roofline": {"bound": "hbm", "kernel": ("graphsum_bf16_kernel<8> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
+                                                     f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})" if args.hidden > 64 else
                                     f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s,

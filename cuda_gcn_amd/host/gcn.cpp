@@ -63,6 +63,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         env.comm = owned_comm.get();
     }
     env.seed = (uint64_t)opt.seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    env.bf16_tables = (flags & HIPGCN_BF16_TABLES) != 0;
     const int world = env.comm->size(), rank = env.comm->rank();
     const int N = params.num_nodes, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
 
@@ -307,6 +308,7 @@ void HipGCN::build_eval_lane() {
     L.comm.reset(env.comm->clone_for(L.env.ctx));
     L.env.comm = L.comm.get();
     L.env.seed = env.seed;
+    L.env.bf16_tables = env.bf16_tables;
     void *q;
     GCNHIP_CHECK(gcnhip_malloc(L.env.ctx, &q, sizeof(uint32_t)));
     L.env.d_epoch = (uint32_t *)q;

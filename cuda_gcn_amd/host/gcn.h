@@ -40,6 +40,7 @@ enum HipGCNFlags {
     HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
     HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
     HIPGCN_GATHER_DH1 = 256,
+    HIPGCN_BF16_TABLES = 2048,   // opt-in, beyond the reference: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate)
     HIPGCN_NULL_COMM = 1024,     // world > 1 without transport: collectives are no-ops (per-rank compute timing only)
     HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };

@@ -1,4 +1,5 @@
 #include "module.h"
+#include <algorithm>
 #include "hip_check.h"
 
 // ------------------------------------------------------------------- Matmul
@@ -66,30 +67,76 @@ void HipSparseMatmul::backward() {
 HipGraphSum::HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim, float frd, uint64_t off)
     : env(env), in(in), out(out), graph(graph), dim(dim), fused_relu_dropout(frd), elem_offset(off) {}
 
+HipGraphSum::~HipGraphSum() { if (bf_table) gcnhip_free(env->ctx, bf_table); }
+
+size_t HipGraphSum::full_rows(const HipVariable *v, bool grad) {
+    const float *full = grad ? v->full_grad : v->full;
+    return full ? v->full_elems / v->ld : (size_t)v->rows;
+}
+
+// bf16 rows: one 128-byte line for up to 64 columns, whole lines above (d = 128: 2 lines instead of 4;
+// 41 classes: 1 line instead of 2)
+uint16_t *HipGraphSum::table() {
+    if (!bf_table) {
+        ld_bf = dim <= 8 ? 8 : (dim <= 16 ? 16 : (dim <= 32 ? 32 : (dim + 63) / 64 * 64));
+        bf_rows = std::max(full_rows(in, false), full_rows(out, true));
+        void *p;
+        GCNHIP_CHECK(gcnhip_malloc(env->ctx, &p, bf_rows * ld_bf * sizeof(uint16_t)));
+        GCNHIP_CHECK(gcnhip_memset_async(env->ctx, p, 0, bf_rows * ld_bf * sizeof(uint16_t)));
+        bf_table = (uint16_t *)p;
+    }
+    return bf_table;
+}
+
 void HipGraphSum::forward(bool training) {
     // rows of `in` named by this rank's columns live on other ranks: gather them first — unless every
     // rank computed all of `in` itself (replicated first-layer product)
     gcnhip_graph *graph = this->graph;
-    if (in->replicated && fwd_graph_replicated) {
-        graph = fwd_graph_replicated;
-    } else if (env->comm->size() > 1) {
-        env->timers->start(TMR_COMM);
-        env->comm->allgather_rows(in->full, in->full_elems / env->comm->size());
-        env->timers->stop(TMR_COMM);
+    const int world = env->comm->size(), rank = env->comm->rank();
+    const bool replicated = in->replicated && fwd_graph_replicated;
+    if (replicated) graph = fwd_graph_replicated;
+    if (env->bf16_tables) {
+        // the table travels (and is gathered) as bfloat16: half the lines per edge, half the bytes per all-gather
+        uint16_t *tab = table();
+        env->timers->start(TMR_GRAPHSUM_FW);
+        if (replicated) {
+            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, in->full, in->ld, tab, ld_bf, (int64_t)full_rows(in, false), dim));
+        } else {
+            const size_t block_rows = world > 1 ? full_rows(in, false) / world : 0;
+            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, in->data, in->ld, tab + (size_t)rank * block_rows * ld_bf, ld_bf, in->rows, dim));
+            if (world > 1) {
+                env->timers->start(TMR_COMM);
+                env->comm->allgather_rows(reinterpret_cast<float *>(tab), block_rows * ld_bf / 2);   // bytes are moved, not interpreted
+                env->timers->stop(TMR_COMM);
+            }
+        }
+        if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+        const bool fused = fused_relu_dropout >= 0.f;
+        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, out->data, out->ld, dim, nullptr, fused ? 1 : 0, training ? 1 : 0,
+                                          fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
+                                          training ? env->keep_hidden : nullptr));
+        if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+        env->timers->stop(TMR_GRAPHSUM_FW);
+    } else {
+        if (!replicated && world > 1) {
+            env->timers->start(TMR_COMM);
+            env->comm->allgather_rows(in->full, in->full_elems / world);
+            env->timers->stop(TMR_COMM);
+        }
+        const float *src = in->full ? in->full : in->data;
+        env->timers->start(TMR_GRAPHSUM_FW);
+        if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+        if (fused_relu_dropout >= 0.f)
+            GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
+                                                      fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
+                                                      training ? env->keep_hidden : nullptr));
+        else
+            GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
+        if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+        env->timers->stop(TMR_GRAPHSUM_FW);
     }
-    const float *src = in->full ? in->full : in->data;
-    env->timers->start(TMR_GRAPHSUM_FW);
-    if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-    if (fused_relu_dropout >= 0.f)
-        GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
-                                                  fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
-                                                  training ? env->keep_hidden : nullptr));
-    else
-        GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
-    if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
-    env->timers->stop(TMR_GRAPHSUM_FW);
     if (pos_bits_full && training) {
-        uint32_t *mine = pos_bits_full + (size_t)env->comm->rank() * rows_max * wpr;
+        uint32_t *mine = pos_bits_full + (size_t)rank * rows_max * wpr;
         GCNHIP_CHECK(gcnhip_pack_positive(env->ctx, out->data, out->ld, out->rows, dim, mine, wpr));
         env->timers->start(TMR_COMM);
         env->comm->allgather_rows(reinterpret_cast<float *>(pos_bits_full), (size_t)rows_max * wpr);   // bytes are moved, not interpreted
@@ -100,16 +147,38 @@ void HipGraphSum::forward(bool training) {
 void HipGraphSum::backward() {
     // same operator on the gradients (symmetric adjacency, module.cpp:103-119); out->grad is gathered,
     // unless every rank has already rebuilt all of it
-    if (env->comm->size() > 1 && !out_grad_complete) {
+    const int world = env->comm->size(), rank = env->comm->rank();
+    const uint32_t *row_bits = bwd_row_bits ? *bwd_row_bits : nullptr;
+    if (env->bf16_tables) {
+        uint16_t *tab = table();
+        env->timers->start(TMR_GRAPHSUM_BW);
+        if (world > 1 && out_grad_complete) {
+            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, out->full_grad, out->ld, tab, ld_bf, (int64_t)full_rows(out, true), dim));
+        } else {
+            const size_t block_rows = world > 1 ? full_rows(out, true) / world : 0;
+            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, out->grad, out->ld, tab + (size_t)rank * block_rows * ld_bf, ld_bf, out->rows, dim));
+            if (world > 1) {
+                env->timers->start(TMR_COMM);
+                env->comm->allgather_rows(reinterpret_cast<float *>(tab), block_rows * ld_bf / 2);
+                env->timers->stop(TMR_COMM);
+            }
+        }
+        if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, in->grad, in->ld, dim, row_bits, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+        env->timers->stop(TMR_GRAPHSUM_BW);
+        return;
+    }
+    if (world > 1 && !out_grad_complete) {
         env->timers->start(TMR_COMM);
-        env->comm->allgather_rows(out->full_grad, out->full_elems / env->comm->size());
+        env->comm->allgather_rows(out->full_grad, out->full_elems / world);
         env->timers->stop(TMR_COMM);
     }
     const float *src = out->full_grad ? out->full_grad : out->grad;
     env->timers->start(TMR_GRAPHSUM_BW);
     if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-    if (bwd_row_bits && *bwd_row_bits)
-        GCNHIP_CHECK(gcnhip_graphsum_rowmask(env->ctx, graph, src, out->ld, in->grad, in->ld, dim, *bwd_row_bits));
+    if (row_bits)
+        GCNHIP_CHECK(gcnhip_graphsum_rowmask(env->ctx, graph, src, out->ld, in->grad, in->ld, dim, row_bits));
     else
         GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, out->ld, in->grad, in->ld, dim));
     if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);

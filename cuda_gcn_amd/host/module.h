@@ -28,6 +28,8 @@ struct HipEnv {
     const uint8_t *keep_input = nullptr;     // [nnz of the X the forward multiplies: local rows, or all rows when replicated]
     const uint8_t *keep_input_bwd = nullptr; // [local nnz of X] (same decisions, this rank's slice)
     const uint8_t *keep_hidden = nullptr;    // [local rows * hidden]
+    // opt-in: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate); beyond the reference's f32 path
+    bool bf16_tables = false;
 };
 
 class Module {
@@ -89,8 +91,16 @@ public:
     const uint32_t *const *bwd_row_bits = nullptr;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
+    ~HipGraphSum() override;
     void forward(bool) override;
     void backward() override;
+private:
+    // bf16 storage mode: one table [padded rows x ld_bf], used by forward (copy of `in`) and backward (copy of out->grad)
+    uint16_t *bf_table = nullptr;
+    int ld_bf = 0;
+    size_t bf_rows = 0;
+    uint16_t *table();
+    static size_t full_rows(const HipVariable *v, bool grad);
 };
 
 class HipCrossEntropyLoss : public Module {

@@ -40,6 +40,7 @@ enum {
     GCNHOST_REPLICATE_L1 = 128,   /* force the replication (default: on for 2-4 GPUs, off for 8) */
     GCNHOST_GATHER_DH1 = 256,     /* multi-GPU backward: all-gather dH1 instead of dZ0 + mask bits */
     GCNHOST_NO_ROW_GROUPS = 512,  /* keep the plain descending-degree row schedule (no load-time timing of alternatives) */
+    GCNHOST_BF16_TABLES = 2048,   /* opt-in, beyond the reference: the aggregation gathers bfloat16 copies of H0, Z0, dZ, dH1 (f32 sums) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 

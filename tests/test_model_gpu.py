@@ -250,6 +250,24 @@ def test_row_groups_are_bit_identical():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,hidden,epochs", [("cora-syn", 16, 40), ("reddit-mini", 128, 10)])
+def test_bf16_tables_track_the_f32_trace(oracle, name, hidden, epochs):
+    """opt-in storage format (beyond the reference): GraphSum gathers bfloat16 copies of H0, Z0, dZ, dH1
+    and sums in f32.  Not the parity path — the stated envelope is |dloss| <= 5e-3 and |dacc| <= 0.03
+    against the f32 oracle with the same dropout decisions (measured: 1.2e-3 / 0.021 over 100 epochs)"""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS, BF16_TABLES
+    ds = datagen.make_dataset(name)
+    want, want_test, om = oracle_trace(oracle, ds, 5, epochs, hidden_dim=hidden, dropout=0.5)
+    m = HipGCNModel(ds, seed=5, flags=HOST_MASKS | BF16_TABLES, hidden_dim=hidden, dropout=0.5, epochs=epochs)
+    got = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float64)
+    assert np.abs(got[:, [0, 2]] - want[:, [0, 2]]).max() <= 5e-3
+    assert np.abs(got[:, [1, 3]] - want[:, [1, 3]]).max() <= 0.03
+    t = m.eval(3)
+    assert abs(t[0] - want_test[0]) <= 5e-3 and abs(t[1] - want_test[1]) <= 0.03
+    assert np.abs(got - want).max() > 0          # it IS a different arithmetic: must not silently be the f32 path
+    m.close(); om.close()
+
+
 def _run_cli(binary, td, args, env):
     r = subprocess.run([binary] + args, cwd=td, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -65,6 +65,8 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
     ("cora-syn", 2, 0.5, 1, 256),       # GATHER_DH1: all-gather dH1 instead of dZ0 + mask bits
     ("tiny-syn", 3, 0.0, 0, 256 | 64),
     ("reddit-mini", 2, 0.5, 1, 256),
+    ("cora-syn", 2, 0.5, 1, 2048),      # BF16_TABLES: bf16 blocks are what the ranks all-gather
+    ("reddit-mini", 2, 0.5, 0, 2048),
     ("reddit-mini", 2, 0.5, 1, 0),      # dense 602-column X, hidden 128, hub rows: the bench's shapes at 1/10 scale
 ])
 def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, flags):
@@ -77,9 +79,16 @@ def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, fla
         launch(world, ["gpu", name, out, epochs, flags, dropout], extra_env={"MR_ASYNC": str(run_async), "MR_HIDDEN": str(hidden)})
         got = np.load(out)
     ds = datagen.make_dataset(name)
-    m = HipGCNModel(ds, seed=4, flags=flags & 2, hidden_dim=hidden, dropout=dropout, epochs=epochs)
+    m = HipGCNModel(ds, seed=4, flags=flags & (2 | 2048), hidden_dim=hidden, dropout=dropout, epochs=epochs)
     want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
     wtest = m.eval(3)
+    if flags & 2048:
+        # bf16 tables: rounding to 8 bits is discontinuous, so the last-bit differences of the cross-rank gradient
+        # sum flip single roundings; the partitioned run stays inside the format's own envelope (2e-3), not 2e-5
+        assert np.abs(got["trace"] - want).max() <= 2e-3, np.abs(got["trace"] - want).max()
+        assert np.abs(got["test"] - np.array(wtest, np.float32)).max() <= 2e-3
+        m.close()
+        return
     # same kernels on the same rows; only the order of the cross-rank gradient sum differs
     assert np.abs(got["trace"] - want).max() <= (2e-4 if hidden > 16 else 2e-5), np.abs(got["trace"] - want).max()
     assert np.abs(got["test"] - np.array(wtest, np.float32)).max() <= 2e-5

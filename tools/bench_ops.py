@@ -81,7 +81,19 @@ def main():
         bgs = 4 * (N + 1) + 4 * nnzA + 4 * nnzA * dim + 4 * N * dim
         res[f"graphsum_d{dim}_ld{ld}"] = dict(ms=ms, GBps=bgs / ms / 1e6)
         print(f"graphsum d={dim} ld={ld}: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
+    def gs_bf16(dim, ld):
+        x = dev.buf(rng.standard_normal((N, dim)).astype(np.float32))
+        t = dev.buf(np.zeros((N, ld), np.uint16))
+        o = dev.buf((N, (dim + 3) // 4 * 4))
+        ms_c = timeit(dev, lambda: _ck(lib, lib.gcnhip_f32_to_bf16(dev.ctx, x.ptr, dim, t.ptr, ld, N, dim), "cv"))
+        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum_bf16(dev.ctx, g.h, t.ptr, ld, o.ptr, (dim + 3) // 4 * 4, dim, None, 0, 0, 0.0, 0, None, 0, None), "gsb"))
+        res[f"graphsum_bf16_d{dim}_ld{ld}"] = dict(ms=ms, convert_ms=ms_c)
+        print(f"graphsum bf16 table d={dim} ld={ld}: {ms:.3f} ms (+ f32->bf16 convert {ms_c:.3f} ms)", flush=True)
     only_gs = len(sys.argv) > 3 and sys.argv[3] == 'graphsum'
+    if len(sys.argv) > 4 and sys.argv[4] == 'bf16':
+        gs(h, h); gs(Cc, 48)
+        gs_bf16(h, h); gs_bf16(Cc, 64); gs_bf16(Cc, 48)
+        return
     gs(h, h)
     gs(Cc, (Cc + 3) // 4 * 4)
     gs(Cc, 48)
