@@ -10,7 +10,8 @@
 // "-" keeps a default; num_nodes/input_dim/output_dim always come from the
 // data.  Environment: GCN_SEED (plays time(NULL) of rand.cpp:7), GCN_DATA_ROOT,
 // GCN_GPUS=N (row-partition over N GPUs of this node, one host thread per GPU,
-// RCCL over xGMI), GCN_MODULAR=1, GCN_HOST_MASKS=1, GCN_TIMERS=1.
+// RCCL over xGMI), GCN_MODULAR=1, GCN_HOST_MASKS=1, GCN_TIMERS=1,
+// GCN_BF16_TABLES=1 (opt-in storage format of the aggregation inputs, beyond the reference).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,7 +66,7 @@ int main(int argc, char **argv) {
     const char *seed = getenv("GCN_SEED");
     base.seed = seed ? atol(seed) : (long)time(NULL);
     base.flags = (env_int("GCN_MODULAR", 0) ? HIPGCN_MODULAR : 0) | (env_int("GCN_HOST_MASKS", 0) ? HIPGCN_HOST_MASKS : 0) |
-                 (env_int("GCN_TIMERS", 0) ? HIPGCN_TIMERS : 0);
+                 (env_int("GCN_TIMERS", 0) ? HIPGCN_TIMERS : 0) | (env_int("GCN_BF16_TABLES", 0) ? HIPGCN_BF16_TABLES : 0);
     std::cout << "RUNNING ON GPU" << std::endl;
 
     int rc = EXIT_SUCCESS;
