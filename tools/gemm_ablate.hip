@@ -76,12 +76,12 @@ __global__ __launch_bounds__(256) void probe(const float *x, int ldx, const floa
 }
 
 template <int ABL, int BM = 128, int BK = 32>
-void run(const char *tag, const float *x, int ldx, const float *w, float *out, int m, int K) {
+void run(const char *tag, const float *x, int ldx, const float *w, float *out, int m, int K, int dyn_lds = 0) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = (m + BM - 1) / BM;
-    for (int it = 0; it < 3; it++) probe<ABL, BM, BK><<<grid, 256>>>(x, ldx, w, 128, out, 128, m, K);
+    for (int it = 0; it < 3; it++) probe<ABL, BM, BK><<<grid, 256, dyn_lds>>>(x, ldx, w, 128, out, 128, m, K);
     hipEventRecord(e0);
-    for (int it = 0; it < 10; it++) probe<ABL, BM, BK><<<grid, 256>>>(x, ldx, w, 128, out, 128, m, K);
+    for (int it = 0; it < 10; it++) probe<ABL, BM, BK><<<grid, 256, dyn_lds>>>(x, ldx, w, 128, out, 128, m, K);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     printf("%-58s %.3f ms  %.1f TF-equivalent\n", tag, ms, 2.0 * m * K * 128 / ms / 1e9);
@@ -100,6 +100,9 @@ int main() {
     run<1 | 2>("no refetch, no LDS reads (writes + barriers + MFMA)", x, ldx, w, out, m, K);
     run<8>("everything but MFMA (fma instead)", x, ldx, w, out, m, K);
     run<2>("full minus LDS reads", x, ldx, w, out, m, K);
+    run<0>("full, occupancy capped at 2 workgroups per CU (22 KB dummy LDS)", x, ldx, w, out, m, K, 22 * 1024);
+    run<1 | 2 | 4 | 16>("MFMA only, occupancy 2", x, ldx, w, out, m, K, 22 * 1024);
+    run<0>("full, occupancy capped at 1 workgroup per CU", x, ldx, w, out, m, K, 60 * 1024);
     run<0, 128, 64>("full, BK=64", x, ldx, w, out, m, K);
     run<0, 64, 32>("full, BM=64", x, ldx, w, out, m, K);
     run<0, 64, 64>("full, BM=64 BK=64", x, ldx, w, out, m, K);
