@@ -38,8 +38,26 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
     const float cnt = (float)(a.count > 0 ? a.count : (a.d_count ? *a.d_count : 0));
     float loss = 0.f;
     int correct = 0, total = 0;
+    // the next row's logits and label are loaded while this row's reductions run (a wave walks ~50 rows at
+    // Reddit scale; without the prefetch every row paid a full memory latency: 90 us for 233 K rows)
+    float nv[XENT_MAXC_REG];
+    int nt = -1;
+    auto prefetch = [&](int r) {
+        nt = a.truth[r];
+        const float *lg = a.logits + (size_t)r * a.ld;
+#pragma unroll
+        for (int q = 0; q < XENT_MAXC_REG; q++) {
+            const int j = lane + q * WAVE;
+            nv[q] = j < a.C ? lg[j] : -INFINITY;
+        }
+    };
+    if (r0 < r1) prefetch(r0);
     for (int r = r0; r < r1; r++) {
-        const int t = a.truth[r];
+        const int t = nt;
+        float v[XENT_MAXC_REG];
+#pragma unroll
+        for (int q = 0; q < XENT_MAXC_REG; q++) v[q] = nv[q];
+        if (r + 1 < r1) prefetch(r + 1);
         float *lg = a.logits + (size_t)r * a.ld;
         float *gr = a.grad ? a.grad + (size_t)r * a.ld_grad : nullptr;
         if (t < 0) {                                   // unlabelled: grad row stays 0 (module.cpp:129,132)
@@ -48,12 +66,10 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
             continue;
         }
         total++;
-        float v[XENT_MAXC_REG];
         float mx = -1e30f;                             // module.cpp:135
 #pragma unroll
         for (int q = 0; q < XENT_MAXC_REG; q++) {
             const int j = lane + q * WAVE;
-            v[q] = j < a.C ? lg[j] : -INFINITY;
             if (j < a.C) mx = fmaxf(mx, v[q]);
         }
         mx = wave_max(mx);
@@ -148,7 +164,7 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
     if (a.C > XENT_MAXC_REG * WAVE) return -1;
     int blocks = ceil_div(a.n_rows, 4 * 8);             // ~8 rows per wave
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;                   // part_i holds 2 ints per block in red_i[0, 4096)
     if (a.n_rows == 0) blocks = 1;                      // a rank that owns no rows still reports zeros
     a.part_f = c->red_f + 2048;
     a.part_i = c->red_i;
