@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
 #pragma unroll
         for (int u = 0; u < VB; u++) acc[s][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int validA = a.n - colA, validB = a.p - colB;
-#pragma unroll 4
+#pragma unroll 8
     for (int k0 = r0; k0 < r1; k0 += 4) {
         const int row = k0 + kq;
         float av[VA], bv[VB];
@@ -321,7 +321,8 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     const size_t slab_per_worker = (size_t)n * a.p_ld * sizeof(float);
     int per_cu = slab_per_worker <= (256u << 10) ? 16 : 4;
     int workers = ceil_div((int64_t)c->n_cu * per_cu, (int64_t)gy * gz);
-    while (workers > 4 && (size_t)workers * slab_per_worker > (12u << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials
+    static const size_t cap_mb = getenv("GCNHIP_ATB_CAP_MB") ? (size_t)atoi(getenv("GCNHIP_ATB_CAP_MB")) : 12;   // experiments
+    while (workers > 4 && (size_t)workers * slab_per_worker > (cap_mb << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials
     if (workers > ceil_div(m, 256)) workers = ceil_div(m, 256);      // at least 64 K-steps per worker
     if (workers < 1) workers = 1;
     workers = (workers + 3) / 4 * 4;
