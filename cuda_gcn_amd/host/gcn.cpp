@@ -442,15 +442,16 @@ void HipGCN::host_masks_for_epoch() {
     GCNHIP_CHECK(gcnhip_h2d(env.ctx, d_keep1, h_keep1.data(), h_keep1.size()));
 }
 
-void HipGCN::train_epoch_async() {              // gcn.cpp:107-118
+void HipGCN::train_begin() {
     GCNHIP_CHECK(gcnhip_counter_add(env.ctx, env.d_epoch, 1u));
     epochs_done++;
     if (flags & HIPGCN_MODULAR)                  // set_input (gcn.cpp:73-76): device-to-device, never from the host
         GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
     if (flags & HIPGCN_HOST_MASKS) host_masks_for_epoch();
     set_truth(1);
-    for (auto m : modules) m->forward(true);
-    for (int i = (int)modules.size() - 1; i >= 0; i--) modules[i]->backward();
+}
+
+void HipGCN::train_end() {
     if (env.comm->size() > 1) {
         timers->start(TMR_COMM);
         env.comm->allreduce_sum(gradbuf, gradbuf_elems);
@@ -466,14 +467,27 @@ void HipGCN::train_epoch_async() {              // gcn.cpp:107-118
     if (lane) GCNHIP_CHECK(gcnhip_event_record(env.ctx, lane->ev_weights));
 }
 
+void HipGCN::train_epoch_async() {              // gcn.cpp:107-118
+    train_begin();
+    for (auto m : modules) m->forward(true);
+    for (int i = (int)modules.size() - 1; i >= 0; i--) modules[i]->backward();
+    train_end();
+}
+
 // validation forward of the epoch that just finished, on the second stream
-void HipGCN::eval_on_lane(int s) {
+void HipGCN::lane_begin(int s) {
     EvalLane &L = *lane;
     GCNHIP_CHECK(gcnhip_stream_wait_event(L.env.ctx, L.ev_weights));
-    GCNHIP_CHECK(gcnhip_counter_add(L.env.ctx, L.env.d_epoch, 1u));
+    // the lane's epoch word names the ring row: the epoch whose weights are evaluated, whatever was called in between
+    const long want = epochs_done - 1;
+    GCNHIP_CHECK(gcnhip_counter_add(L.env.ctx, L.env.d_epoch, (uint32_t)(want - L.epoch_word)));
+    L.epoch_word = want;
     L.truth = d_truth[s];
     L.count = split_count[s];
-    for (auto m : L.modules) m->forward(false);
+}
+
+void HipGCN::lane_end(int s) {
+    EvalLane &L = *lane;
     if (L.env.comm->size() > 1) {
         L.timers->start(TMR_COMM);
         L.env.comm->allreduce_sum(L.d_result, 4);
@@ -482,6 +496,30 @@ void HipGCN::eval_on_lane(int s) {
     GCNHIP_CHECK(gcnhip_metrics_record(L.env.ctx, d_ring, RING, s == 2 ? 1 : 2, L.env.d_epoch, L.d_result, nullptr, optimizer->d_sumsq));
     GCNHIP_CHECK(gcnhip_event_record(L.env.ctx, L.ev_done));
     L.pending = true;
+}
+
+void HipGCN::eval_on_lane(int s) {
+    lane_begin(s);
+    for (auto m : lane->modules) m->forward(false);
+    lane_end(s);
+}
+
+// eval(e) on the lane and train(e+1) on the main stream, enqueued stage by stage in alternation.  Both need only
+// the weights Adam(e) wrote.  The collectives of the two communicators execute in enqueue order (comm.cpp,
+// turnstile), so enqueueing all of eval(e) first would make train(e+1)'s first all-gather wait for the whole
+// validation pass; zipped, each collective waits only for the other lane's previous one, and the lanes' compute
+// overlaps with each other's exchanges.
+void HipGCN::eval_then_train_zipped(int s) {
+    lane_begin(s);
+    train_begin();
+    const size_t nb = lane->modules.size(), na = modules.size();
+    for (size_t i = 0; i < std::max(na, nb); i++) {
+        if (i < nb) lane->modules[i]->forward(false);
+        if (i < na) modules[i]->forward(true);
+    }
+    lane_end(s);
+    for (int i = (int)na - 1; i >= 0; i--) modules[i]->backward();
+    train_end();
 }
 
 void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
@@ -541,9 +579,13 @@ void HipGCN::run_epochs(int n, float *trace) {
                 GCNHIP_CHECK(gcnhip_graph_launch(env.ctx, epoch_graph));
                 epochs_done++;
                 optimizer->note_replayed(1);
+            } else if (lane) {
+                // validation of epoch i-1 zipped with training of epoch i; the chunk's last validation runs alone
+                if (i == 0) train_epoch_async(); else eval_then_train_zipped(2);
+                if (i == chunk - 1) eval_on_lane(2);
             } else {
                 train_epoch_async();
-                if (lane) eval_on_lane(2); else eval_async(2);
+                eval_async(2);
             }
         }
         sync();

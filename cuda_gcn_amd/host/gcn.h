@@ -156,10 +156,16 @@ private:
         int count = 0;
         void *ev_weights = nullptr, *ev_done = nullptr;        // Adam(e) -> eval(e);  eval(e) -> Adam(e+1)
         bool pending = false;
+        long epoch_word = -1;                                  // host shadow of *env.d_epoch (starts at 0xFFFFFFFF)
     };
     std::unique_ptr<EvalLane> lane;
     void build_eval_lane();
     void eval_on_lane(int current_split);
+    void lane_begin(int current_split);
+    void lane_end(int current_split);
+    void eval_then_train_zipped(int current_split);
+    void train_begin();
+    void train_end();
 
     // row schedule of the aggregation (gcnhip_graph_set_schedule): candidates timed once, fastest kept
     int sched_mode = 0, sched_groups = 0;

@@ -230,7 +230,17 @@ def test_eval_lane_is_bit_identical():
     ds = datagen.make_dataset("pubmed-syn")
     a = HipGCNModel(ds, seed=6, flags=NO_GRAPH, hidden_dim=16, dropout=0.5, epochs=30)
     b = HipGCNModel(ds, seed=6, flags=EVAL_LANE, hidden_dim=16, dropout=0.5, epochs=30)
-    ta, tb = a.run_epochs(30), b.run_epochs(30)
+    ta, tb = a.run_epochs(12), b.run_epochs(12)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    # stepwise calls in between (train only, then a direct eval), then the zipped schedule again: the lane's
+    # ring row must follow the epoch it evaluates, not its own call count
+    for m in (a, b):
+        for _ in range(3):
+            m.train_epoch()
+    assert a.eval(2) == b.eval(2)
+    ta, tb = a.run_epochs(15), b.run_epochs(15)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    ta, tb = a.run_epochs(1), b.run_epochs(1)
     assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
     assert a.eval(3) == b.eval(3)
     assert np.array_equal(a.var(2), b.var(2))
