@@ -301,7 +301,8 @@ def test_spmm_sparse_vs_oracle(dev, oracle, name, p):
     f.free()
 
 
-@pytest.mark.parametrize("N,F,p", [(300, 50, 16), (257, 602, 128), (130, 36, 41), (64, 33, 7)])
+@pytest.mark.parametrize("N,F,p", [(300, 50, 16), (257, 602, 128), (130, 36, 41), (64, 33, 7),
+                                   (100100, 70, 128)])    # more row tiles than resident workgroups
 def test_spmm_dense_vs_oracle(dev, oracle, N, F, p):
     """X stored as CSR with every column present (the Reddit case) takes the MFMA path"""
     rng = np.random.default_rng(N + F)
