@@ -188,6 +188,7 @@ struct AtbArgs {
     // dropout on A (the input dropout of a dense X): element index = row*n + col
     int drop; int thr; float scale;
     uint64_t seed, off; const uint32_t *d_epoch; const uint8_t *keep_mask;
+    const uint32_t *bits;         // optional: precomputed keep bits, bit (e & 31) of word (e >> 5), e = row*n + col
 };
 
 template <int V>
@@ -234,7 +235,11 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
             if (a.drop && validA > 0) {
                 const uint64_t e0 = (uint64_t)row * a.n + colA;
                 uint32_t bits = 0;
-                if (a.keep_mask) {
+                if (a.bits) {                                   // built once per call, 128 decisions per Philox block
+                    const uint32_t sh = (uint32_t)(e0 & 31);
+                    bits = a.bits[e0 >> 5] >> sh;
+                    if (VA > 1 && sh + VA > 32) bits |= a.bits[(e0 >> 5) + 1] << (32 - sh);
+                } else if (a.keep_mask) {
 #pragma unroll
                     for (int s = 0; s < VA; s++) bits |= (s < validA && a.keep_mask[e0 + s] != 0 ? 1u : 0u) << s;
                 } else if (((a.off + e0) & (VA - 1)) == 0) {
@@ -306,8 +311,9 @@ static inline int ensure_slab(gcnhip_ctx *c, size_t bytes) {
 // S[n x p] = A^T . Bm   (A: m x n, Bm: m x p), optional dropout on A
 static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, int ldb, float *out, int ld_out,
                       int m, int n, int p, int drop, float p_drop, uint64_t seed, const uint32_t *d_epoch,
-                      uint64_t off, const uint8_t *keep_mask) {
+                      uint64_t off, const uint8_t *keep_mask, const uint32_t *keep_bits = nullptr) {
     AtbArgs a;
+    a.bits = drop ? keep_bits : nullptr;
     a.A = A; a.lda = lda; a.Bm = Bm; a.ldb = ldb;
     a.m = m; a.n = n; a.p = p; a.p_ld = (p + 3) / 4 * 4;
     a.drop = drop; a.thr = dropout_threshold(p_drop); a.scale = drop ? 1 / (1 - p_drop) : 1.f;

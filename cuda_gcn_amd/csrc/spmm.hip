@@ -408,9 +408,11 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         GCNHIP_LAUNCH_CHECK();
         return 0;
     }
-    if (f->dense)
+    if (f->dense) {                                   // narrow outputs (p <= 64)
+        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }     // not one Philox block per float4 in the GEMM
         return launch_atb(c, vals, f->n_cols, dout, ld_dout, dw, ld_dw, f->n_rows, f->n_cols, p,
-                          d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask);   // narrow outputs (p <= 64)
+                          d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask, d.on ? f->keep_bits : nullptr);
+    }
     SpBwdArgs a;
     a.csc_ptr = f->csc_ptr; a.csc_row = f->csc_row; a.csc_pos = f->csc_pos;
     a.vals = vals; a.dout = dout; a.dw = dw;
