@@ -2,11 +2,11 @@
 the reference's text parser (src/common/parser.cpp through oracle/_ref/libref.so) vs our single-pass
 text parser vs the .gcnbin cache, on the same files; all three must return identical arrays.
 
-    python tools/bench_loader.py [dataset ...]          (default: pubmed-syn reddit-mini)
+    python tests/validation/bench_loader.py [dataset ...]          (default: pubmed-syn reddit-mini)
 """
 import os, sys, tempfile, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cuda_gcn_amd import datagen
 from cuda_gcn_amd.model import load_dataset, save_binary
 from oracle.pyoracle import Ref

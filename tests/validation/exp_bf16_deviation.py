@@ -1,7 +1,7 @@
 """How far does the opt-in bf16 table storage move the training trace from the f32 reference path?"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from cuda_gcn_amd import datagen
 from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS, BF16_TABLES

@@ -3,11 +3,11 @@ train + validation on the HIP path against the CPU checker with the reference's 
 replayed (HOST_MASKS), then the test split.  Uses the reference's own objects when
 oracle/_ref/libref.so travelled with the repo, else the pinned C restatement.  Writes one JSON.
 
-    python tools/validate_fullsize.py [epochs=10] [out.json]
+    python tests/validation/validate_fullsize.py [epochs=10] [out.json]
 """
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: F401
 from cuda_gcn_amd import datagen
 from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
