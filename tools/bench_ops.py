@@ -90,6 +90,9 @@ def main():
         res[f"graphsum_bf16_d{dim}_ld{ld}"] = dict(ms=ms, convert_ms=ms_c)
         print(f"graphsum bf16 table d={dim} ld={ld}: {ms:.3f} ms (+ f32->bf16 convert {ms_c:.3f} ms)", flush=True)
     only_gs = len(sys.argv) > 3 and sys.argv[3] == 'graphsum'
+    if len(sys.argv) > 4 and sys.argv[4] == 'split41':      # would two narrower tables (32 + 9 columns) beat one 48-wide row?
+        gs(Cc, 48); gs(32, 32); gs(9, 12); gs(9, 16); gs(16, 16)
+        return
     if len(sys.argv) > 4 and sys.argv[4] == 'bf16':
         gs(h, h); gs(Cc, 48)
         gs_bf16(h, h); gs_bf16(Cc, 64); gs_bf16(Cc, 48)
