@@ -9,14 +9,33 @@ configs[2]: 232 965 nodes, 11 606 919 undirected edges, 602 dense features ->
 available offline).  All inputs are resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU; the adjacency is
-     row-partitioned, H rows are all-gathered over RCCL before every GraphSum)
+
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+RANK / WORLD_SIZE are then set), or this file does: a parent that has not
+touched the GPU (no torch import, no native library) starts the N ranks with
+torch.distributed.run as CHILD processes, relays rank 0's JSON line and exits
+with their return code.  A hung child group is killed after GCN_BENCH_TIMEOUT
+seconds (default 900) and, once, started again as fresh children without the
+validation lane.
 
 Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
+  * `value` / `ms_per_step`: exactly K epochs, barrier + synchronize on both sides, max over ranks,
+    on the product's default path (per-op timers OFF: one GPU replays the captured hipGraph epoch);
+  * `bursts`: the same timed region repeated, median / min / max epochs/s;
+  * `roofline`: the dominant kernel (GraphSum at the hidden width) timed with HIP events on its own
+    stream in a separate pass of the same process (timers ON), against the bound that binds it;
+  * `roofline.hbm_regime`: the same kernel on an R-MAT graph whose table (1 GiB) is far beyond the
+    Infinity Cache — the fraction of the HBM roofline proper;
+  * `value_no_row_groups`: the headline with the label-major aggregation schedule disabled.
 """
 import argparse
 import json
 import os
+import signal
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -24,9 +43,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL needs it)
 
-import numpy as np  # noqa: E402
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
+# MI355X_MICROARCH.md "Indexed rows": a CU gathers rows served by its XCD's L2 at 66-73 GB/s and rows served by the
+# Infinity Cache at 33.5 GB/s (256 CUs: 18.4 and 8.6 TB/s chip-wide)
+L2_ROW_GBPS_PER_CU, MALL_ROW_GBPS_PER_CU, N_CU = 72.0, 33.5, 256
+PMC_FILES = ["r02_graphsum_pmc.json", "r01_graphsum_pmc.json"]           # newest first (profiles/)
+PMC_RMAT_FILES = ["r02_graphsum_pmc_rmat.json"]
 
-HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
 
 
 def b_gs(n_rows, nnz, d, in_bytes=4):
@@ -35,6 +61,74 @@ def b_gs(n_rows, nnz, d, in_bytes=4):
     return 4 * (n_rows + 1) + 4 * nnz + in_bytes * nnz * d + 4 * n_rows * d
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--dataset", default="reddit-syn")
+    ap.add_argument("--bursts", type=int, default=4, help="extra repetitions of the K-step timed region (median/min/max)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the HBM-regime leg and the structure-blind rerun")
+    ap.add_argument("--hbm-scale", type=int, default=21, help="R-MAT scale of the HBM-regime leg (21: 1 GiB table at d=128)")
+    ap.add_argument("--no-row-groups", action="store_true", help="plain descending-degree aggregation schedule (no label hint)")
+    ap.add_argument("--bf16-tables", action="store_true",
+                    help="opt-in, NOT the headline: GraphSum gathers bfloat16 copies of its inputs (f32 sums); reported as dtype f32+bf16-tables")
+    ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
+                    help="validation forward on a second stream (auto: only with more than one GPU)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------- launcher (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n_gpus, argv):
+    """Parent of an N-rank run.  Runs before torch or any native library is imported: this process
+    never initialises the GPU, it only starts children, so nothing here is an exec from a GPU process."""
+    timeout = float(os.environ.get("GCN_BENCH_TIMEOUT", "900"))
+    attempts = [list(argv), list(argv) + ["--eval-lane", "off"]]        # argparse: the last --eval-lane wins
+    rc = 1
+    for k, extra in enumerate(attempts):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
+        log("starting", n_gpus, "ranks:", " ".join(cmd[1:]))
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            log(f"ranks still running after {timeout:.0f} s: killing process group {p.pid}")
+            try:
+                os.killpg(p.pid, signal.SIGKILL)       # exactly the group this parent started
+            except ProcessLookupError:
+                pass
+            out, _ = p.communicate()
+            rc = 124
+        line = None
+        for ln in (out or "").splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+            else:
+                print(ln, file=sys.stderr)
+        if rc == 0 and line is not None:
+            print(line, flush=True)
+            return 0
+        log(f"attempt {k + 1} failed (rc {rc}{'' if line else ', no JSON line'})")
+        if rc == 0:
+            rc = 1
+        if "--eval-lane" in argv:                       # the caller chose the lane mode: no second variant to try
+            break
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(ds_full, hidden, budget_s=30.0):
     """gcn-seq timed on this box's host cores, rank 0 only: the reference's own objects
     (oracle/_ref/libref.so, built in the build container from the reference's sources where they lie;
@@ -73,39 +167,92 @@ def cpu_baseline(ds_full, hidden, budget_s=30.0):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--hidden", type=int, default=128)
-    ap.add_argument("--dataset", default="reddit-syn")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bf16-tables", action="store_true",
-                    help="opt-in, NOT the headline: GraphSum gathers bfloat16 copies of its inputs (f32 sums); reported as dtype f32+bf16-tables")
-    ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
-                    help="validation forward on a second stream (auto: only with more than one GPU)")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------- HBM-regime leg
+def _pmc(files, kernel):
+    for f in files:
+        p = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(p):
+            k = json.load(open(p)).get(kernel)
+            if k:
+                return k, "profiles/" + f
+    return None, None
 
+
+def hbm_regime_leg(scale, dim, device, launches=10):
+    """GraphSum at the hidden width on an R-MAT graph (BASELINE configs[4] family) whose gathered table is far
+    larger than the 256 MiB Infinity Cache, through the same C-ABI entry point the model calls, with the
+    `dealt-256` row schedule HipGCN picks for such graphs.  B_gs(d) / HIP-event time against the 8 TB/s HBM peak."""
+    import ctypes as C
+    import numpy as np
+    from cuda_gcn_amd import datagen
+    from cuda_gcn_amd.ops import Device, _ck
+    t0 = time.perf_counter()
+    gp, gi = datagen.rmat_graph(scale)
+    N, nnz = gp.size - 1, int(gi.size)
+    t_gen = time.perf_counter() - t0
+    dev = Device(device)
+    lib = dev.lib
+    t0 = time.perf_counter()
+    g = dev.graph(gp, gi)
+    _ck(lib, lib.gcnhip_graph_set_schedule(dev.ctx, g.h, 2, None, 256), "set_schedule")
+    t_prep = time.perf_counter() - t0
+    ld = (dim + 15) // 16 * 16 if dim > 32 else (dim + 3) // 4 * 4
+    x = dev.buf(np.random.default_rng(0).standard_normal((N, ld), dtype=np.float32))
+    o = dev.buf((N, ld))
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.gcnhip_event_create(C.byref(e0)); lib.gcnhip_event_create(C.byref(e1))
+
+    def run():
+        _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, ld, o.ptr, ld, dim), "gcnhip_graphsum")
+    for _ in range(2):
+        run()
+    dev.sync()
+    lib.gcnhip_event_record(dev.ctx, e0)
+    for _ in range(launches):
+        run()
+    lib.gcnhip_event_record(dev.ctx, e1)
+    ms = C.c_float()
+    _ck(lib, lib.gcnhip_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+    lib.gcnhip_event_destroy(e0); lib.gcnhip_event_destroy(e1)
+    avg_s = ms.value * 1e-3 / launches
+    x.free(); o.free(); g.free(); dev.close()
+    bytes_per_launch = b_gs(N, nnz, dim)
+    achieved = bytes_per_launch / avg_s / 1e9
+    k, src = _pmc(PMC_RMAT_FILES, "graphsum_vec_kernel<8>" if dim >= 64 and dim % 32 == 0 else "graphsum_vec_kernel<16>")
+    traffic = k.get("traffic_bytes_per_launch") if k else None
+    return {"workload": f"GraphSum d={dim} on rmat-{scale} (N={N}, {nnz} stored edges, max degree {int(np.diff(gp).max())}); "
+                        f"gathered table {N * ld * 4 / 2**20:.0f} MiB >> 256 MiB Infinity Cache; schedule dealt-256",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s, "launches": launches,
+            "traffic": traffic, "traffic_source": src,
+            "traffic_frac_of_peak": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBPS,
+            "setup_s": {"generate": round(t_gen, 2), "graph_create_and_schedule": round(t_prep, 2)}}
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     import torch                       # device plumbing + rendezvous only; imported BEFORE the native libs so
     import torch.distributed as dist   # that one HIP runtime / one RCCL is loaded in the process
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    torch.cuda.set_device(int(os.environ.get("GCN_BENCH_DEVICE", local_rank)))
+    device = int(os.environ.get("GCN_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)    # control plane; data plane is RCCL in libgcnhost
 
     from cuda_gcn_amd import datagen
-    from cuda_gcn_amd.model import HipGCNModel, TIMERS, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, nccl_unique_id
+    from cuda_gcn_amd.model import (HipGCNModel, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, NO_ROW_GROUPS, nccl_unique_id)
 
     def barrier():
         if world > 1:
@@ -114,6 +261,8 @@ def main():
     t0 = time.perf_counter()
     ds = datagen.make_dataset(args.dataset)          # same seed on every rank -> identical graph
     t_data = time.perf_counter() - t0
+    if rank == 0:
+        log(f"dataset {args.dataset} ready in {t_data:.1f} s")
     nccl_id, host_ag, host_ar = None, None, None
     if world > 1 and os.environ.get("GCN_BENCH_TRANSPORT") == "host":
         # rehearsal without RCCL (e.g. several ranks sharing one GPU): collectives staged through the host
@@ -129,28 +278,47 @@ def main():
         dist.broadcast_object_list(box, src=0)
         nccl_id = box[0]
     lane_flag = {"auto": 0, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
-    device = int(os.environ.get("GCN_BENCH_DEVICE", local_rank))
-    t0 = time.perf_counter()
-    model = HipGCNModel(ds, seed=1, device=device, flags=TIMERS | lane_flag | (BF16_TABLES if args.bf16_tables else 0), rank=rank, world=world, nccl_id=nccl_id,
+    base_flags = lane_flag | (BF16_TABLES if args.bf16_tables else 0)
+    n_epochs_total = args.warmup + args.steps * (2 + args.bursts) + 64
+
+    def build(flags):
+        t0 = time.perf_counter()
+        m = HipGCNModel(ds, seed=1, device=device, flags=flags, rank=rank, world=world, nccl_id=nccl_id,
                         host_allgather=host_ag, host_allreduce=host_ar,
-                        hidden_dim=args.hidden, dropout=0.5, epochs=2 * args.steps + args.warmup)
-    t_build = time.perf_counter() - t0     # host preprocessing (edge order, schedules) + every H2D copy + schedule timing
+                        hidden_dim=args.hidden, dropout=0.5, epochs=n_epochs_total)
+        return m, time.perf_counter() - t0     # host preprocessing (edge order, schedules) + every H2D copy + schedule timing
+
+    def timed_region(m, k):
+        """EXACTLY k epochs, bracketed by barrier + synchronize on both sides; max over ranks; returns (seconds, trace)"""
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr = m.run_epochs(k)                         # k epochs enqueued back to back, one sync at the end
+        torch.cuda.synchronize(); barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt, tr
+
+    model, t_build = build(base_flags | (NO_ROW_GROUPS if args.no_row_groups else 0))
     info = model.info()
-
     model.run_epochs(args.warmup, want_trace=False)
-    model.timers_reset()
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    trace = model.run_epochs(args.steps)             # K epochs enqueued back to back, one sync at the end
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    dt, trace = timed_region(model, args.steps)      # <- the headline: default product path, per-op timers off
+    burst_eps = [args.steps / dt]
+    for _ in range(args.bursts):
+        d, _tr = timed_region(model, args.steps)
+        burst_eps.append(args.steps / d)
+    if rank == 0:
+        log(f"timed: {args.steps / dt:.2f} epochs/s; bursts {['%.1f' % b for b in burst_eps]}")
 
-    # dominant kernel: GraphSum at the hidden width (3 launches per epoch), timed with HIP events
-    # on the stream it runs on, inside the timed region
+    # ---- separate pass, same process and model: per-op HIP-event timers on (the epoch then runs eagerly, one
+    # event pair per op on the stream the op runs on).  The dominant kernel's launches are timed here.
+    n_tm = min(args.steps, 20)
+    model.set_timers(True)
+    model.run_epochs(2, want_trace=False)
+    model.timers_reset()
+    dt_tm, _ = timed_region(model, n_tm)
     s_wide, n_wide = model.timer("graphsum_wide")
     if n_wide == 0:                                   # hidden <= 64: the wide timer never fires; use all GraphSum launches
         s_f, n_f = model.timer("graphsum_fw")
@@ -160,7 +328,8 @@ def main():
     for name in ("spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw", "matmul_fw", "matmul_bw", "loss_fw", "adam", "comm"):
         s, n = model.timer(name)
         if n:
-            breakdown[name] = round(1e3 * s / args.steps, 4)      # ms per epoch
+            breakdown[name] = round(1e3 * s / n_tm, 4)      # ms per epoch
+    model.set_timers(False)
     # train-only epochs (no validation forward; one host read-back per epoch), outside the timed region
     n_tr = min(args.steps, 20)
     barrier(); torch.cuda.synchronize()
@@ -169,31 +338,57 @@ def main():
         model.train_epoch()
     torch.cuda.synchronize(); barrier()
     train_only_ms = 1e3 * (time.perf_counter() - t1) / n_tr
+    schedule = model.schedule()
+    model.close()
+
     out = None
     if rank == 0:
-        # fabric traffic per launch of the same kernel from the committed rocprofv3 PMC passes
-        # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be collected live here)
-        traffic, traffic_src, gather_ceiling = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_graphsum_pmc.json")
-        if world == 1 and args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and os.path.exists(pmc):
-            k = json.load(open(pmc)).get("graphsum_vec_kernel<8>", {})
-            if "l2_hit_rate" in k:
-                # MI355X_MICROARCH.md "Indexed rows": ~30 B/clk/CU for rows served by the XCD's L2, ~14 B/clk/CU from the
-                # Infinity Cache; blended by the measured hit rate, 256 CUs at 2.4 GHz
-                h_l2 = k["l2_hit_rate"]
-                gather_ceiling = 1.0 / (h_l2 / 30.0 + (1.0 - h_l2) / 14.0) * 256 * 2.4       # GB/s of gathered lines
-            if "traffic_bytes_per_launch" in k:
-                traffic = k["traffic_bytes_per_launch"]
-                traffic_src = "profiles/r01_graphsum_pmc.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, rocprofv3 --pmc in separate passes"
         ib = 2 if args.bf16_tables else 4
         if args.hidden > 64:
+            d_eff = float(args.hidden)
             bytes_per_launch = b_gs(info["local_rows"], info["local_edges"], args.hidden, ib)
         else:                                         # average over the hidden- and class-width launches (3 + 3 per epoch)
+            d_eff = (args.hidden + ds["output_dim"]) / 2
             bytes_per_launch = (b_gs(info["local_rows"], info["local_edges"], args.hidden, ib) +
                                 b_gs(info["local_rows"], info["local_edges"], ds["output_dim"], ib)) / 2
         table_mb = ds["num_nodes"] * args.hidden * 4 / 1e6
         avg_s = s_wide / max(n_wide, 1)
-        achieved = bytes_per_launch / avg_s / 1e9
+        algorithmic = bytes_per_launch / avg_s / 1e9
+        gathered = ib * info["local_edges"] * d_eff / avg_s / 1e9
+        kernel = ("graphsum_bf16_kernel<8> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
+                  f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})" if args.hidden > 64 else
+                  f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)")
+        # fabric traffic and L2 hit rate per launch of the same kernel from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE, WRITE_SIZE and the TCC hit counters need separate runs, so they cannot be collected live here)
+        pmc, pmc_src = (None, None)
+        if args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and not args.no_row_groups:
+            pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<8>")
+        traffic = pmc.get("traffic_bytes_per_launch") if (pmc and world == 1) else None
+        cache_resident = table_mb * 1e6 <= 256 * 2**20
+        if cache_resident and pmc and "l2_hit_rate" in pmc:
+            # The gathered table sits in the Infinity Cache: HBM is not what bounds the kernel (B_gs / t exceeds the HBM
+            # peak).  What does is the rate at which the CUs can gather 128-byte lines from their XCD's L2 and, past it,
+            # from the Infinity Cache: the guide's two per-CU row-gather rates blended at the PMC-measured L2 hit rate.
+            h = pmc["l2_hit_rate"]
+            peak = N_CU / (h / L2_ROW_GBPS_PER_CU + (1.0 - h) / MALL_ROW_GBPS_PER_CU)
+            roof = {"bound": "cache-gather", "kernel": kernel, "achieved": gathered, "peak": peak, "unit": "GB/s", "frac": gathered / peak,
+                    "traffic": traffic, "l2_hit_rate": h,
+                    "what": "achieved = gathered neighbour-row bytes (4*nnz*d) / HIP-event launch time; peak = 256 CUs / (h/72 + (1-h)/33.5) GB/s: "
+                            "MI355X_MICROARCH.md 'Indexed rows' per-CU gather rates from L2 and from the Infinity Cache, blended at the "
+                            "PMC-measured L2 hit rate h" + ("" if world == 1 else " of the 1-GPU schedule (not re-measured per partition)")}
+        else:
+            roof = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": algorithmic / HBM_PEAK_GBPS, "traffic": traffic,
+                    "what": "B_gs(d) / HIP-event launch time against the HBM peak" +
+                            ("; the table is Infinity-Cache resident and no PMC hit rate is committed for this configuration, so this may exceed 1"
+                             if cache_resident else "")}
+        roof.update({"traffic_source": pmc_src, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s, "launches": n_wide,
+                     "table_MB": round(table_mb, 1),
+                     "hbm_algorithmic": {"achieved": algorithmic, "peak": HBM_PEAK_GBPS, "frac": algorithmic / HBM_PEAK_GBPS,
+                                         "what": "SURVEY §8(d) contract figure B_gs(d)/t; > 1 means cache-served"},
+                     "hbm_traffic": None if traffic is None else {"achieved": traffic / avg_s / 1e9, "peak": HBM_PEAK_GBPS,
+                                                                  "frac": traffic / avg_s / 1e9 / HBM_PEAK_GBPS,
+                                                                  "what": "PMC fabric bytes (2*FETCH_SIZE + WRITE_SIZE) per launch / launch time"}})
         n_lab = int((ds["split"] == 1).sum())
         out = {
             "metric": "epochs_per_sec", "value": args.steps / dt, "unit": "epochs/s",
@@ -204,28 +399,33 @@ def main():
                                    f"{ds['input_dim']}->{args.hidden}->{ds['output_dim']}, dropout 0.5, Adam; "
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
-                       "train_nodes": n_lab, "aggregation_schedule": model.schedule()},
-            "roofline": {"bound": "hbm", "kernel": ("graphsum_bf16_kernel<8> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
-                                                     f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})" if args.hidden > 64 else
-                                    f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s,
-                         "launches": n_wide,
-                         "gather_ceiling": None if gather_ceiling is None else {
-                             "GBps": gather_ceiling, "frac": 4.0 * info["local_edges"] * args.hidden / avg_s / 1e9 / gather_ceiling,
-                             "what": "gathered neighbour-row bytes only (4*nnz*d) against the blend of the guide's L2-hit and Infinity-Cache "
-                                     "row-gather rates at the PMC-measured L2 hit rate"},
-                         "note": ("algorithmic gather-model bytes B_gs(d); the gathered table (%.0f MB) is Infinity-Cache resident, "
-                                  "so achieved may exceed both HBM traffic and the HBM peak (see DESIGN.md, profiles/)" % table_mb)
-                                 if table_mb <= 256 else
-                                 ("algorithmic gather-model bytes B_gs(d); the gathered table (%.0f MB) exceeds the 256 MiB Infinity "
-                                  "Cache: HBM regime" % table_mb)},
-            "breakdown_ms_per_epoch": breakdown, "train_only_ms_per_epoch": round(train_only_ms, 4),
+                       "train_nodes": n_lab, "aggregation_schedule": schedule},
+            "bursts": {"epochs_per_s": [round(b, 2) for b in burst_eps], "median": statistics.median(burst_eps), "min": min(burst_eps),
+                       "max": max(burst_eps), "steps_each": args.steps},
+            "roofline": roof,
+            "breakdown_ms_per_epoch": breakdown, "timers_pass_ms_per_epoch": round(1e3 * dt_tm / n_tm, 4),
+            "train_only_ms_per_epoch": round(train_only_ms, 4),
             "final": {"train_loss": float(trace[-1, 0]), "train_acc": float(trace[-1, 1]),
                       "val_loss": float(trace[-1, 2]), "val_acc": float(trace[-1, 3])},
             "setup_s": {"dataset": round(t_data, 2), "model_build_incl_h2d": round(t_build, 2)},
         }
-    model.close()
+
+    extras = world == 1 and not args.no_extras
+    if extras and not args.no_row_groups and schedule != "degree":
+        # the same headline without the label hint (structure-blind schedule: plain descending degree)
+        m2, _ = build(base_flags | NO_ROW_GROUPS)
+        m2.run_epochs(args.warmup, want_trace=False)
+        d2, _tr = timed_region(m2, args.steps)
+        out["value_no_row_groups"] = args.steps / d2
+        m2.close()
+        log(f"no row groups: {args.steps / d2:.2f} epochs/s")
+    if extras:
+        try:
+            out["roofline"]["hbm_regime"] = hbm_regime_leg(args.hbm_scale, args.hidden if args.hidden > 64 else 128, device)
+            log("hbm regime leg:", "%.0f GB/s" % out["roofline"]["hbm_regime"]["achieved"])
+        except Exception as e:          # the leg is an extra: report its failure, keep the headline
+            out["roofline"]["hbm_regime"] = {"error": repr(e)}
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ds, args.hidden)

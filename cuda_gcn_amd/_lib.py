@@ -81,6 +81,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graph_create": (I, [P, C.POINTER(P), P, P, I, I, P]),
     "gcnhip_graph_create_grouped": (I, [P, C.POINTER(P), P, P, I, I, P, P]),
     "gcnhip_graph_set_schedule": (I, [P, P, I, P, I]),
+    "gcnhip_graph_reserve_width": (I, [P, P, I]),
     "gcnhip_graph_destroy": (I, [P, P]),
     "gcnhip_graph_arrays": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
     "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),
@@ -158,15 +159,19 @@ GCNHOST_SYMBOLS = {
     "gcnhost_model_set_weights": (I, [P, P, P]),
     "gcnhost_model_timer": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "gcnhost_model_timers_reset": (I, [P]),
+    "gcnhost_model_set_timers": (I, [P, I]),
     "gcnhost_dataset_load": (I, [PP, C.c_char_p, C.c_char_p, C.POINTER(HostParams)]),
     "gcnhost_dataset_arrays": (I, [P, PP, PP, C.POINTER(I64), PP, PP, PP, C.POINTER(I64), PP, C.POINTER(I64), PP, C.POINTER(I64)]),
     "gcnhost_dataset_save_binary": (I, [P, C.POINTER(HostParams), C.c_char_p]),
     "gcnhost_dataset_free": (I, [P]),
     "gcnhost_rccl_selftest": (I, [I]),
+    "gcnhost_rccl_selftest_world": (I, [I, I, I, C.c_char_p]),
     "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
     "gcnhost_local_graph": (I, [P, P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
     "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),
+    "gcnhost_rmat_graph": (I, [I, I, U64, PP, PP, C.POINTER(I64)]),
+    "gcnhost_free_array": (None, [P]),
 }
 
 

@@ -207,9 +207,11 @@ static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
         GCNHIP_TRY(hipMalloc((void **)&g->split_rows, srows.size() * sizeof(int4)));
         GCNHIP_TRY(hipMemcpy(g->split_rows, srows.data(), srows.size() * sizeof(int4), hipMemcpyHostToDevice));
     }
-    if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); }
-    g->part_ld = 0;           // partial buffer sized lazily for the widest dim seen
-    g->partials = nullptr;
+    // segment scratch for the widest aggregation this object will serve: sized HERE (and by
+    // gcnhip_graph_reserve_width), never inside a launch path
+    if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); g->partials = nullptr; }
+    if (g->part_ld < 256) g->part_ld = 256;
+    if (n_slots) GCNHIP_TRY(hipMalloc((void **)&g->partials, (size_t)n_slots * g->part_ld * sizeof(float)));
     // equal-work task ranges for 1/2/4/8 XCD groups, each starting on a multiple of 4 tasks (one workgroup)
     for (int lg = 0; lg < 4; lg++) {
         const int G = 1 << lg;
@@ -332,6 +334,18 @@ int gcnhip_graph_set_schedule(gcnhip_ctx *c, gcnhip_graph *g, int mode, const in
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ip[a + 1] - ip[a] > ip[b + 1] - ip[b]; });
     for (int k = 0; k < n; k++) key[order[k]] = k % n_groups;
     return build_schedule(g, key.data());
+}
+
+int gcnhip_graph_reserve_width(gcnhip_ctx *c, gcnhip_graph *g, int max_dim) {
+    if (!c || !g || max_dim <= 0) return -1;
+    const int want = (max_dim + 7) / 8 * 8;
+    if (want <= g->part_ld) return 0;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));       // no aggregation may still be writing the old scratch
+    if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); g->partials = nullptr; }
+    g->part_ld = want;
+    if (g->n_slots) GCNHIP_TRY(hipMalloc((void **)&g->partials, (size_t)g->n_slots * g->part_ld * sizeof(float)));
+    return 0;
 }
 
 int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int **d_indices,

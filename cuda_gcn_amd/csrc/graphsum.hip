@@ -384,14 +384,9 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (in_bf && (ld_in % 8 != 0 || !aligned16(in_bf))) return -1;
     if (g->n_rows == 0) return 0;
-    gcnhip_graph *gm = const_cast<gcnhip_graph *>(g);
-    if (g->n_slots && g->part_ld < (dim + 7) / 8 * 8) {      // first call at this width: size the segment scratch
-        GCNHIP_TRY(hipStreamSynchronize(c->stream));
-        if (gm->partials) GCNHIP_TRY(hipFree(gm->partials));
-        gm->part_ld = (dim + 7) / 8 * 8;
-        if (gm->part_ld < 256) gm->part_ld = 256;
-        GCNHIP_TRY(hipMalloc((void **)&gm->partials, (size_t)g->n_slots * gm->part_ld * sizeof(float)));
-    }
+    // the segment scratch of split rows is sized when the object is built (256 columns) or by
+    // gcnhip_graph_reserve_width; a launch never allocates, synchronises or touches the object
+    if (g->n_slots && g->part_ld < (dim + 7) / 8 * 8) return -1;
     GsArgs a;
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
     a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows;

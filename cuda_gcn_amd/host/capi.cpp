@@ -121,6 +121,7 @@ int gcnhost_model_timer(gcnhost_model *m, int id, double *seconds, long *count) 
     API_TRY({ *seconds = m->gcn->timer_total((timer_instance)id, count); })
 }
 int gcnhost_model_timers_reset(gcnhost_model *m) { API_TRY({ m->gcn->timers_reset(); }) }
+int gcnhost_model_set_timers(gcnhost_model *m, int on) { API_TRY({ m->gcn->set_timers(on != 0); }) }
 
 int gcnhost_dataset_load(gcnhost_dataset **out, const char *root, const char *name, gcnhost_params *p) {
     API_TRY({
@@ -151,34 +152,42 @@ int gcnhost_dataset_save_binary(gcnhost_dataset *d, const gcnhost_params *p, con
 }
 int gcnhost_dataset_free(gcnhost_dataset *d) { delete d; return 0; }
 
-int gcnhost_rccl_selftest(int device) {
+// RCCL round trip with `world` ranks (one per process; world == 1: a single-rank communicator): communicator
+// init from the shared unique id, in-place all-gather of distinct blocks, all-reduce, the validation lane's
+// split communicator on a second stream, and collectives alternating between the two (turnstile order).
+int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *nccl_id) {
+    if (world < 1 || rank < 0 || rank >= world || !nccl_id) { g_err = "bad rank/world/id"; return -1; }
     API_TRY({
         gcnhip_ctx *ctx = nullptr;
         GCNHIP_CHECK(gcnhip_ctx_create(&ctx, device, nullptr));
-        char id[GCN_NCCL_ID_BYTES];
-        int rc = rccl_get_unique_id(id);
-        if (rc) throw GcnHipFailure(rc, "ncclGetUniqueId failed");
         {
-            std::unique_ptr<Comm> comm(make_rccl_comm(ctx, 0, 1, id));
-            std::vector<float> h(1024);
-            for (int i = 0; i < 1024; i++) h[i] = (float)i * 0.5f;
+            std::unique_ptr<Comm> comm(make_rccl_comm(ctx, rank, world, nccl_id));
+            const size_t B = 1024;
+            std::vector<float> h(B * world, -1.f);
+            for (size_t i = 0; i < B; i++) h[rank * B + i] = (float)(rank * 1000) + (float)i * 0.5f;
             void *d;
             GCNHIP_CHECK(gcnhip_malloc(ctx, &d, h.size() * sizeof(float)));
             GCNHIP_CHECK(gcnhip_h2d(ctx, d, h.data(), h.size() * sizeof(float)));
-            comm->allgather_rows((float *)d, h.size());
-            comm->allreduce_sum((float *)d, h.size());
-            std::vector<float> back(1024);
+            comm->allgather_rows((float *)d, B);
+            std::vector<float> back(h.size());
             GCNHIP_CHECK(gcnhip_d2h(ctx, back.data(), d, back.size() * sizeof(float)));
+            for (int q = 0; q < world; q++)
+                for (size_t i = 0; i < B; i++)
+                    if (back[q * B + i] != (float)(q * 1000) + (float)i * 0.5f)
+                        throw GcnHipFailure(-1, "RCCL self-test: all-gather block mismatch");
+            comm->allreduce_sum((float *)d, B);        // block 0 of every rank is now identical: sum = world * value
+            GCNHIP_CHECK(gcnhip_d2h(ctx, back.data(), d, B * sizeof(float)));
+            for (size_t i = 0; i < B; i++)
+                if (back[i] != (float)world * ((float)i * 0.5f)) throw GcnHipFailure(-1, "RCCL self-test: all-reduce mismatch");
             gcnhip_free(ctx, d);
-            for (int i = 0; i < 1024; i++)
-                if (back[i] != h[i]) throw GcnHipFailure(-1, "RCCL self-test: data changed in a one-rank collective");
             void *sa;
-            GCNHIP_CHECK(gcnhip_malloc(ctx, &sa, 256 * sizeof(float)));
-            GCNHIP_CHECK(gcnhip_memset_async(ctx, sa, 0, 256 * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_malloc(ctx, &sa, 256 * world * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_memset_async(ctx, sa, 0, 256 * world * sizeof(float)));
             float *scratch_a = (float *)sa;
-            double v[2] = {3.0, 4.0};
+            double v[2] = {3.0, 4.0 + rank};
             comm->allreduce_sum_host(v, 2);
-            if (v[0] != 3.0 || v[1] != 4.0) throw GcnHipFailure(-1, "RCCL self-test: host reduction");
+            if (v[0] != 3.0 * world || v[1] != 4.0 * world + world * (world - 1) / 2.0)
+                throw GcnHipFailure(-1, "RCCL self-test: host reduction");
             // the validation lane's communicator (ncclCommSplit) on a second stream
             gcnhip_ctx *ctx2 = nullptr;
             GCNHIP_CHECK(gcnhip_ctx_create(&ctx2, device, nullptr));
@@ -186,11 +195,11 @@ int gcnhost_rccl_selftest(int device) {
                 std::unique_ptr<Comm> comm2(comm->clone_for(ctx2));
                 double w2[1] = {5.0};
                 comm2->allreduce_sum_host(w2, 1);
-                if (w2[0] != 5.0) throw GcnHipFailure(-1, "RCCL self-test: split communicator");
+                if (w2[0] != 5.0 * world) throw GcnHipFailure(-1, "RCCL self-test: split communicator");
                 // collectives alternating between the two lanes (serialised by the turnstile event)
                 void *d2;
-                GCNHIP_CHECK(gcnhip_malloc(ctx2, &d2, 256 * sizeof(float)));
-                GCNHIP_CHECK(gcnhip_memset_async(ctx2, d2, 0, 256 * sizeof(float)));
+                GCNHIP_CHECK(gcnhip_malloc(ctx2, &d2, 256 * world * sizeof(float)));
+                GCNHIP_CHECK(gcnhip_memset_async(ctx2, d2, 0, 256 * world * sizeof(float)));
                 for (int it = 0; it < 4; it++) {
                     comm->allreduce_sum(scratch_a, 256);
                     comm2->allgather_rows((float *)d2, 256);
@@ -206,6 +215,13 @@ int gcnhost_rccl_selftest(int device) {
         }
         gcnhip_ctx_destroy(ctx);
     })
+}
+
+int gcnhost_rccl_selftest(int device) {
+    char id[GCN_NCCL_ID_BYTES];
+    const int rc = rccl_get_unique_id(id);
+    if (rc) { g_err = "ncclGetUniqueId failed"; return rc; }
+    return gcnhost_rccl_selftest_world(device, 0, 1, id);
 }
 
 int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start, int *rows_max) {

@@ -77,8 +77,10 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     if (world > 1) {
         const LocalGraph lg = build_local_graph(gp.data(), gi.data(), N, part, rank);
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
+        GCNHIP_CHECK(gcnhip_graph_reserve_width(env.ctx, graph, std::max(params.hidden_dim, params.output_dim)));
     } else {
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
+        GCNHIP_CHECK(gcnhip_graph_reserve_width(env.ctx, graph, std::max(params.hidden_dim, params.output_dim)));
     }
     const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
     const long f0 = fp[r0], f1 = fp[r1];
@@ -100,6 +102,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
         for (int j = 0; j < N; j++) deg[j] = gp[j + 1] - gp[j];
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data()));
+        GCNHIP_CHECK(gcnhip_graph_reserve_width(env.ctx, graph_l1, std::max(params.hidden_dim, params.output_dim)));
     }
     // truth per split, once (the reference rebuilds and re-uploads it per call: cuda_gcn.cu:85-97)
     {
@@ -320,8 +323,10 @@ void HipGCN::build_eval_lane() {
     if (world > 1) {
         const LocalGraph lg = build_local_graph(gp.data(), gi.data(), params.num_nodes, part, rank);
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
+        GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph, std::max(params.hidden_dim, params.output_dim)));
     } else {
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, gp.data(), gi.data(), params.num_nodes, params.num_nodes, nullptr));
+        GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph, std::max(params.hidden_dim, params.output_dim)));
     }
     apply_schedule(L.env.ctx, L.graph);                     // the schedule the training lane measured as fastest
     const int rm = part.rows_max;
@@ -332,6 +337,7 @@ void HipGCN::build_eval_lane() {
         for (int r = 0; r <= N; r++) lp[r] = gp[r0 + r] - gp[r0];
         for (int j = 0; j < params.num_nodes; j++) deg[j] = gp[j + 1] - gp[j];
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph_l1, lp.data(), gi.data() + gp[r0], N, params.num_nodes, deg.data()));
+        GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph_l1, std::max(params.hidden_dim, params.output_dim)));
         apply_schedule(L.env.ctx, L.graph_l1);
         L.H0->alloc_replicated(L.env.ctx, params.num_nodes, N, r0, H, false);
     } else {
@@ -413,6 +419,12 @@ double HipGCN::timer_total(timer_instance t, long *count) {
 void HipGCN::timers_reset() {
     timers->reset();
     if (lane) lane->timers->reset();
+}
+
+void HipGCN::set_timers(bool on) {
+    sync();
+    timers->enabled = on;
+    if (lane) lane->timers->enabled = on;
 }
 
 void HipGCN::set_truth(int s) {                 // gcn.cpp:78-81: here a pointer switch
@@ -561,20 +573,33 @@ void HipGCN::run_epochs(int n, float *trace) {
     // One epoch (train + validation) is a fixed launch sequence whose epoch-dependent inputs all live in
     // device memory, so it is captured once into a hipGraph and replayed (single GPU, device RNG, no
     // per-op timers).  The first epoch runs eagerly so every scratch buffer has its final size.
-    const bool graph_ok = env.comm->size() == 1 && !lane && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_TIMERS | HIPGCN_NO_GRAPH));
+    const bool graph_ok = env.comm->size() == 1 && !lane && !timers->enabled && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_NO_GRAPH));
     while (done < n) {
         const int chunk = std::min(n - done, RING);
         const long first = epochs_done;
         for (int i = 0; i < chunk; i++) {
             if (graph_ok && epochs_done >= 1 && optimizer->can_replay(1)) {
                 if (!epoch_graph) {
+                    const long epochs_before = epochs_done;
+                    const int steps_before = optimizer->steps();
                     GCNHIP_CHECK(gcnhip_capture_begin(env.ctx));
-                    train_epoch_async();
-                    eval_async(2);
+                    try {
+                        train_epoch_async();
+                        eval_async(2);
+                    } catch (...) {
+                        // never leave the stream capturing: end the capture, drop whatever it recorded, restore
+                        // the host-side counters, then let the caller see the failure
+                        void *broken = nullptr;
+                        gcnhip_capture_end(env.ctx, &broken);
+                        if (broken) gcnhip_graph_exec_destroy(broken);
+                        epochs_done = epochs_before;
+                        optimizer->note_replayed(steps_before - optimizer->steps());
+                        throw;
+                    }
                     GCNHIP_CHECK(gcnhip_capture_end(env.ctx, &epoch_graph));
                     // the capture only recorded: undo its host-side bookkeeping, then run it for real
-                    epochs_done--;
-                    optimizer->note_replayed(-1);
+                    epochs_done = epochs_before;
+                    optimizer->note_replayed(steps_before - optimizer->steps());
                 }
                 GCNHIP_CHECK(gcnhip_graph_launch(env.ctx, epoch_graph));
                 epochs_done++;

@@ -89,6 +89,9 @@ public:
     DeviceTimers &device_timers() { return *timers; }
     double timer_total(timer_instance t, long *count);        // both lanes
     void timers_reset();
+    // switch the per-op device-event timers on or off (both lanes).  While they are on, run_epochs does not
+    // replay the captured epoch (event records per op are not part of it).
+    void set_timers(bool on);
     long n_edges_local() const { return nnzA_local; }
 
 private:

@@ -29,4 +29,5 @@ public:
     // graph replay: n steps happened on the device; true if all of them were inside the table
     bool can_replay(int n) const { return step_count + n <= table_len; }
     void note_replayed(int n) { step_count += n; }
+    int steps() const { return step_count; }
 };

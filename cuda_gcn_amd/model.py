@@ -124,6 +124,9 @@ class HipGCNModel:
     def timers_reset(self):
         _ck(self.lib, self.lib.gcnhost_model_timers_reset(self.h), "timers_reset")
 
+    def set_timers(self, on):
+        _ck(self.lib, self.lib.gcnhost_model_set_timers(self.h, int(bool(on))), "set_timers")
+
     def close(self):
         if self.h:
             self.lib.gcnhost_model_destroy(self.h)

@@ -112,6 +112,7 @@ class Device:
         ld_out = ld_out or dim
         xin = self.padded(x, ld_in)
         out = self.buf(np.full((g.n_rows, ld_out), np.nan, np.float32))
+        g.reserve(dim)
         if row_nonzero is None:
             _ck(self.lib, self.lib.gcnhip_graphsum(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim), "gcnhip_graphsum")
         else:
@@ -144,6 +145,7 @@ class Device:
             bits = np.concatenate([bits, np.zeros((-bits.size) % 4 + 4, np.uint8)]).view(np.uint32)
             bb = self.buf(bits)
         rd = relu_dropout or {}
+        g.reserve(dim)
         ep = self.buf(np.array([rd.get("epoch", 0)], np.uint32))
         km = self.buf(np.ascontiguousarray(rd["keep_mask"], np.uint8)) if rd.get("keep_mask") is not None else None
         _ck(self.lib, self.lib.gcnhip_graphsum_bf16(self.ctx, g.h, tb.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr if bb else None,
@@ -158,6 +160,7 @@ class Device:
         ld = ld or dim
         xin = self.padded(x, ld)
         out = self.buf(np.full((g.n_rows, ld), np.nan, np.float32))
+        g.reserve(dim)
         ep = self.buf(np.array([epoch], np.uint32))
         km = self.buf(np.ascontiguousarray(keep_mask, np.uint8)) if keep_mask is not None else None
         _ck(self.lib, self.lib.gcnhip_graphsum_relu_dropout(self.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim, int(training), p,
@@ -355,6 +358,11 @@ class Graph:
         rg = np.ascontiguousarray(row_group, np.int32) if row_group is not None else None
         _ck(self.dev.lib, self.dev.lib.gcnhip_graph_set_schedule(self.dev.ctx, self.h, mode, rg.ctypes.data if rg is not None else None,
                                                                   n_groups), "gcnhip_graph_set_schedule")
+
+    def reserve(self, dim):
+        """segment scratch for aggregations up to `dim` columns (256 are reserved when the object is built)"""
+        if dim > 256:
+            _ck(self.dev.lib, self.dev.lib.gcnhip_graph_reserve_width(self.dev.ctx, self.h, int(dim)), "gcnhip_graph_reserve_width")
 
     def coef(self):
         pc = C.c_void_p()

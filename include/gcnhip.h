@@ -92,6 +92,12 @@ int gcnhip_graph_create_grouped(gcnhip_ctx *ctx, gcnhip_graph **g, const int *h_
  *           group-major; measured on an R-MAT graph with a 1 GiB table: 6.9 -> 5.3 ms at d = 128
  * The host (HipGCN) times the candidates once per dataset and keeps the fastest. */
 int gcnhip_graph_set_schedule(gcnhip_ctx *ctx, gcnhip_graph *g, int mode, const int *h_row_group, int n_groups);
+/* Widest aggregation (columns) this object will be asked for.  Rows cut into segments need a scratch row per
+ * segment; it is sized for 256 columns when the object is built and grown HERE (synchronises the context) —
+ * never inside gcnhip_graphsum*, which return -1 for a wider call.  So a launch allocates nothing, may be
+ * captured into a hipGraph at any time, and treats the object as read-only apart from that scratch: two streams
+ * may share one object only if their aggregations never overlap in time (HipGCN gives each lane its own). */
+int gcnhip_graph_reserve_width(gcnhip_ctx *ctx, gcnhip_graph *g, int max_dim);
 int gcnhip_graph_destroy(gcnhip_ctx *ctx, gcnhip_graph *g);
 /* device pointers of the prepared arrays (tests, diagnostics) */
 int gcnhip_graph_arrays(const gcnhip_graph *g, const int **d_indptr, const int **d_indices,

@@ -88,6 +88,9 @@ int gcnhost_model_set_weights(gcnhost_model *m, const float *w1, const float *w2
  * 15 GraphSum at the hidden width): accumulated seconds and number of intervals */
 int gcnhost_model_timer(gcnhost_model *m, int id, double *seconds, long *count);
 int gcnhost_model_timers_reset(gcnhost_model *m);
+/* switch the per-op timers on/off after construction (synchronises).  While on, run_epochs runs eagerly instead
+ * of replaying its captured hipGraph: time the headline with them off, collect the breakdown in a separate pass */
+int gcnhost_model_set_timers(gcnhost_model *m, int on);
 
 /* the text loader (src/common/parser.cpp) — fills caller-visible arrays owned by the returned handle */
 typedef struct gcnhost_dataset gcnhost_dataset;
@@ -101,6 +104,9 @@ int gcnhost_dataset_free(gcnhost_dataset *d);
 /* one-rank RCCL round trip on `device` (communicator init, in-place all-gather, all-reduce,
  * destroy): checks that the RCCL this process loaded works before a multi-GPU job relies on it */
 int gcnhost_rccl_selftest(int device);
+/* the same with `world` ranks, one process per rank, all given the id rank 0 got from gcnhost_nccl_unique_id:
+ * in-place all-gather of distinct blocks, all-reduce, split communicator, alternating lanes — values checked */
+int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *nccl_id);
 
 /* host-only helpers, callable without a GPU (CPU tests) */
 int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start /* [world+1] */, int *rows_max);
@@ -110,6 +116,12 @@ int gcnhost_local_graph(const int *g_indptr, const int *g_indices, int n_rows, i
                         int *indptr, int *indices, int *col_deg, int *n_local, int *n_cols, int64_t *nnz_local);
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws);
 int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t skip_draws);
+/* Graph500 R-MAT graph (a,b,c = .57,.19,.19) of 2^scale nodes and edge_factor * 2^scale sampled pairs, symmetrised,
+ * duplicates and self pairs dropped, in the layout the reference's loader produces (src/common/parser.cpp:20-46:
+ * CSR with the self loop first, neighbours ascending).  BASELINE configs[4] = scale 22, edge_factor 16.  The arrays
+ * are malloc'ed here; release them with gcnhost_free_array.  Deterministic in (scale, edge_factor, seed). */
+int gcnhost_rmat_graph(int scale, int edge_factor, uint64_t seed, int **indptr, int **indices, int64_t *nnz);
+void gcnhost_free_array(void *p);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -155,6 +155,33 @@ void or_graphsum(const int *indptr, const int *indices, int n_rows,
         }
 }
 
+/* The same loop body as or_graphsum (src/seq/module.cpp:88-99) for a chosen subset of source rows:
+ * out[k,:] = row rows[k] of the full result.  For graphs too large to evaluate whole on one core
+ * (R-MAT 2^21+ nodes).  The reference multiplies the two row lengths as `int` (module.cpp:91-93); the
+ * product overflows (undefined behaviour) once it reaches 2^31, so a caller comparing against an
+ * implementation with a 64-bit product must choose rows whose products all stay below 2^31 —
+ * returns the number of selected rows that violate this (their output is still written). */
+int or_graphsum_rows(const int *indptr, const int *indices, const int *rows, int n_sel,
+                     const float *in, float *out, int dim) {
+    int overflowing = 0;
+    for (long i = 0; i < (long)n_sel * dim; i++) out[i] = 0;
+    for (int k = 0; k < n_sel; k++) {
+        const int src = rows[k];
+        int bad = 0;
+        for (int e = indptr[src]; e < indptr[src + 1]; e++) {
+            const int dst = indices[e];
+            const long wide = (long)(indptr[src + 1] - indptr[src]) * (long)(indptr[dst + 1] - indptr[dst]);
+            if (wide >= 2147483648L) bad = 1;
+            const float coef = (float)(1.0 / (double)sqrtf((float)(
+                (indptr[src + 1] - indptr[src]) * (indptr[dst + 1] - indptr[dst]))));
+            for (int j = 0; j < dim; j++)
+                out[(long)k * dim + j] += coef * in[(long)dst * dim + j];
+        }
+        overflowing += bad;
+    }
+    return overflowing;
+}
+
 /* -------------------------------------------------------- CrossEntropyLoss */
 /* src/seq/module.cpp:124-161 */
 void or_xent_fwd(float *logits, float *grad, const int *truth,

@@ -51,6 +51,10 @@ void or_spmm_bwd(const int *indptr, const int *indices, int n_rows,
 /* GraphSum forward and backward are the same operator        module.cpp:83-119 */
 void or_graphsum(const int *indptr, const int *indices, int n_rows,
                  const float *in, float *out, int dim);
+/* the same operator for a subset of source rows (out[k,:] = row rows[k]); returns how many of the
+ * selected rows contain an edge whose `int` degree product (module.cpp:91-93) would overflow */
+int or_graphsum_rows(const int *indptr, const int *indices, const int *rows, int n_sel,
+                     const float *in, float *out, int dim);
 /* CrossEntropyLoss::forward; grad may be NULL (eval)         module.cpp:124-161
  * logits are shifted in place exactly as the reference does. */
 void or_xent_fwd(float *logits, float *grad, const int *truth,

@@ -134,6 +134,14 @@ class Oracle:
         self.lib.or_graphsum(indptr.ctypes, indices.ctypes, n_rows, x.ctypes, out.ctypes, dim)
         return out.reshape(n_rows, dim)
 
+    def graphsum_rows(self, indptr, indices, rows, x, dim):
+        """rows `rows` of graphsum(indptr, indices, x) -> (out [len(rows), dim], n rows with an overflowing int degree product)"""
+        indptr, indices, rows, x = _i(indptr), _i(indices), _i(rows), _f(x)
+        out = np.empty(rows.size * dim, np.float32)
+        self.lib.or_graphsum_rows.restype = C.c_int
+        bad = self.lib.or_graphsum_rows(indptr.ctypes, indices.ctypes, rows.ctypes, int(rows.size), x.ctypes, out.ctypes, dim)
+        return out.reshape(rows.size, dim), int(bad)
+
     def xent_fwd(self, logits, truth, num_classes, training=True):
         """returns (loss, shifted_logits, grad or None)"""
         logits = _f(logits).copy()

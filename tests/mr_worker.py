@@ -5,7 +5,9 @@ rendezvous on 127.0.0.1).  Modes:
          rank's block (checked against the single-process CPU oracle);
   gpu  — every rank drives the HIP path on GPU 0 through HipGCNModel with the
          host-staged transport (D2H -> gloo -> H2D), i.e. everything of the
-         N > 1 path except RCCL itself; rank 0 writes its trace to a file.
+         N > 1 path except RCCL itself; rank 0 writes its trace to a file;
+  rccl — needs one GPU per rank: rank r on GPU r, RCCL over xGMI (the product's transport):
+         gcnhost_rccl_selftest_world first, then the same model run as `gpu`.
 """
 import os
 import sys
@@ -71,11 +73,24 @@ def main():
         if rank == 0:
             np.save(out, np.array([1.0]))
     else:
-        ag, ar = make_callbacks(dist, world)
+        ag, ar, nccl_id, device = None, None, None, 0
+        if mode == "rccl":
+            device = int(os.environ.get("LOCAL_RANK", rank))
+            box = [model.nccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            nccl_id = box[0]
+            from cuda_gcn_amd import _lib
+            rc = _lib.gcnhost().gcnhost_rccl_selftest_world(device, rank, world, nccl_id)
+            assert rc == 0, (rc, _lib.gcnhost().gcnhost_last_error())
+            box = [model.nccl_unique_id() if rank == 0 else None]      # a fresh id for the model's communicator
+            dist.broadcast_object_list(box, src=0)
+            nccl_id = box[0]
+        else:
+            ag, ar = make_callbacks(dist, world)
         epochs = int(sys.argv[4])
         flags = int(sys.argv[5])
         dropout = float(sys.argv[6])
-        m = model.HipGCNModel(ds, seed=4, device=0, flags=flags, rank=rank, world=world, host_allgather=ag, host_allreduce=ar,
+        m = model.HipGCNModel(ds, seed=4, device=device, flags=flags, rank=rank, world=world, nccl_id=nccl_id, host_allgather=ag, host_allreduce=ar,
                               hidden_dim=int(os.environ.get("MR_HIDDEN", "16")), dropout=dropout, epochs=epochs)
         info = m.info()
         assert info["world"] == world and info["rank"] == rank

@@ -101,3 +101,33 @@ def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, fla
     # dropout decisions identical => the same zero pattern in H1 of the last eval... eval has no dropout;
     # the trace equality above at dropout 0.5 is the partition-invariance check of the RNG
     m.close()
+
+
+def _gpu_count():
+    from cuda_gcn_amd import _lib
+    import ctypes as C
+    n = C.c_int()
+    return n.value if _lib.gcnhip().gcnhip_device_count(C.byref(n)) == 0 else 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run_async,flags", [(1, 0), (0, 32)])
+def test_two_ranks_rccl_match_single_gpu(run_async, flags):
+    """the product's transport: one GPU per rank, RCCL over xGMI (in-place ncclAllGather, the fused all-reduce, the
+    validation lane's split communicator).  Needs two GPUs; the one-GPU box of this pool skips it."""
+    if _gpu_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL with two ranks); this box has fewer")
+    from cuda_gcn_amd import datagen
+    from cuda_gcn_amd.model import HipGCNModel
+    epochs, hidden, name = 12, 128, "reddit-mini"
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "mr.npz")
+        launch(2, ["rccl", name, out, epochs, flags, 0.5], extra_env={"MR_ASYNC": str(run_async), "MR_HIDDEN": str(hidden)})
+        got = np.load(out)
+    ds = datagen.make_dataset(name)
+    m = HipGCNModel(ds, seed=4, hidden_dim=hidden, dropout=0.5, epochs=epochs)
+    want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
+    wtest = m.eval(3)
+    m.close()
+    assert np.abs(got["trace"] - want).max() <= 2e-4, np.abs(got["trace"] - want).max()
+    assert np.abs(got["test"] - np.array(wtest, np.float32)).max() <= 2e-5

@@ -37,9 +37,7 @@ def main():
     if name.startswith("rmat-") and len(sys.argv) > 3 and sys.argv[3] == "graphsum":
         # graph only (the feature matrix of an R-MAT stress graph is synthetic anyway)
         scale = int(name.split("-")[1])
-        lo, hi = datagen._rmat_edges(np.random.default_rng(datagen.DEFAULT_SEED), scale, 16)
-        gp, gi = datagen.csr_with_self_loops(lo, hi, 1 << scale)
-        del lo, hi
+        gp, gi = datagen.rmat_graph(scale)
         N = 1 << scale
         deg = np.diff(gp)
         print(f"rmat scale {scale}: N={N} nnzA={gi.size} max_deg={deg.max()} built in {time.time() - t0:.1f}s", flush=True)
