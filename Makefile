@@ -45,8 +45,25 @@ $(BINDIR)/gcn-hip: $(PKG)/host/main.cpp $(HOBJ) $(LIBDIR)/libgcnhip.so
 oracle:
 	$(MAKE) -s -C oracle
 
+# CPU sanitizer build of the host logic and the oracle (the GPU box cannot run ASan; the reference has no
+# sanitizer target at all, /root/reference/Makefile:6-7).  `make asan-test` runs the CPU tests of the parser,
+# partition, RNG replay, R-MAT generator, C-ABI tables and the oracle pin against the instrumented libraries.
+ASANDIR  = build/asan
+SANFLAGS = -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
+asan: $(LIBDIR)/libgcnhip.so
+	@mkdir -p $(ASANDIR)
+	$(CXX) $(filter-out -O2,$(CXXFLAGS)) $(SANFLAGS) -shared $(HSRC) -L$(LIBDIR) -lgcnhip -L/opt/rocm/lib -lrccl -lamdhip64 \
+	    -Wl,-rpath,'$(abspath $(LIBDIR))' -Wl,-rpath,/opt/rocm/lib -o $(ASANDIR)/libgcnhost.so
+	cp $(LIBDIR)/libgcnhip.so $(ASANDIR)/libgcnhip.so
+	$(CC) -std=gnu11 -Wall -Wno-unused-result $(SANFLAGS) -fPIC -shared oracle/gcn_oracle.c -o $(ASANDIR)/liboracle.so -lm
+asan-test: asan
+	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" \
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+	GCN_LIBDIR=$(abspath $(ASANDIR)) GCN_ORACLE_LIB=$(abspath $(ASANDIR))/liboracle.so \
+	python3 -m pytest tests/test_host_cpu.py tests/test_abi_cpu.py tests/test_oracle_pin.py tests/test_datagen_cpu.py -q -x -m "not gpu" -p no:cacheprovider
+
 clean:
 	rm -rf build $(LIBDIR) $(BINDIR)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all kernels host oracle clean
+.PHONY: all kernels host oracle clean asan asan-test

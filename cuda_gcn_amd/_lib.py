@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("GCN_LIBDIR") or os.path.join(HERE, "lib")     # GCN_LIBDIR: `make asan-test` points at build/asan
 
 _cache = {}
 
@@ -86,6 +86,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graph_arrays": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
     "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),
     "gcnhip_graphsum_rowmask": (I, [P, P, P, I, P, I, I, P]),
+    "gcnhip_graphsum_masked": (I, [P, P, P, I, P, I, I, P, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
     "gcnhip_feat_destroy": (I, [P, P]),
@@ -99,12 +100,16 @@ GCNHIP_SYMBOLS = {
     "gcnhip_matmul_bwd_fused": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F]),
     "gcnhip_pack_positive": (I, [P, P, I, I, I, P, I]),
     "gcnhip_f32_to_bf16": (I, [P, P, I, P, I, I64, I]),
-    "gcnhip_graphsum_bf16": (I, [P, P, P, I, P, I, I, P, I, I, F, U64, P, U64, P]),
+    "gcnhip_graphsum_bf16": (I, [P, P, P, I, P, I, I, P, P, I, I, F, U64, P, U64, P]),
     "gcnhip_matmul_bwd_da_bits": (I, [P, P, I, P, I, P, I, I, I, I, P, I, F]),
     "gcnhip_relu_fwd": (I, [P, P, P, I64, I]),
     "gcnhip_relu_bwd": (I, [P, P, P, I64]),
     "gcnhip_dropout_fwd": (I, [P, P, P, I64, F, U64, P, U64, P]),
     "gcnhip_dropout_bwd": (I, [P, P, P, I64, F]),
+    "gcnhip_relu_fwd_2d": (I, [P, P, I, I, I, P, I]),
+    "gcnhip_relu_bwd_2d": (I, [P, P, I, I, I, P]),
+    "gcnhip_dropout_fwd_2d": (I, [P, P, I, I, I, P, F, U64, P, U64, P]),
+    "gcnhip_dropout_bwd_2d": (I, [P, P, I, I, I, P, F]),
     "gcnhip_relu_dropout_bwd": (I, [P, P, I, P, I, I, I, F]),
     "gcnhip_xent_fwd": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P]),
     "gcnhip_accuracy": (I, [P, P, I, P, I, I, P]),

@@ -15,38 +15,42 @@ static inline int stream_grid(int64_t n_items, int per_block) {
 
 // ------------------------------------------------------------------ ReLU
 // src/seq/module.cpp:175-194, src/cuda/cuda_kernel.cu:204-219
-__global__ __launch_bounds__(256) void relu_fwd_kernel(float *x, uint8_t *mask, int64_t n, int training) {
+// Element i of the logical [rows x cols] matrix (the reference's flat index: masks and the dropout stream are
+// keyed by it) lives at (i / cols) * ld + i % cols.  The flat entry points pass cols == ld == 1.
+__device__ inline int64_t at(int64_t i, int cols, int ld) { const int64_t r = i / cols; return r * ld + (i - r * cols); }
+
+__global__ __launch_bounds__(256) void relu_fwd_kernel(float *x, uint8_t *mask, int64_t n, int training, int cols, int ld) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = x[i];
-        const bool keep = v > 0.f;
+        float *xp = x + at(i, cols, ld);
+        const bool keep = *xp > 0.f;
         if (training) mask[i] = keep ? 1 : 0;
-        if (!keep) x[i] = 0.f;
+        if (!keep) *xp = 0.f;
     }
 }
-__global__ __launch_bounds__(256) void relu_bwd_kernel(float *g, const uint8_t *mask, int64_t n) {
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float *g, const uint8_t *mask, int64_t n, int cols, int ld) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (!mask[i]) g[i] = 0.f;
+        if (!mask[i]) g[at(i, cols, ld)] = 0.f;
 }
 
 // --------------------------------------------------------------- Dropout
 // src/seq/module.cpp:207-233, src/cuda/cuda_kernel.cu:223-240
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(float *x, int32_t *mask, int64_t n, int thr, float scale,
                                                           uint64_t seed, const uint32_t *d_epoch, uint64_t off,
-                                                          const uint8_t *keep_in) {
+                                                          const uint8_t *keep_in, int cols, int ld) {
     const uint32_t epoch = d_epoch ? *d_epoch : 0u;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const bool keep = keep_in ? keep_in[i] != 0 : keep1(off + (uint64_t)i, epoch, seed, thr);
-        x[i] *= keep ? scale : 0.f;
+        x[at(i, cols, ld)] *= keep ? scale : 0.f;
         if (mask) mask[i] = keep ? 1 : 0;
     }
 }
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(float *g, const int32_t *mask, int64_t n, float scale) {
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(float *g, const int32_t *mask, int64_t n, float scale, int cols, int ld) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        g[i] *= mask[i] ? scale : 0.f;
+        g[at(i, cols, ld)] *= mask[i] ? scale : 0.f;
 }
 // fused ReLU+Dropout backward: the forward output h is > 0 exactly where both kept
 __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(float *g, int ldg, const float *h, int ldh,
@@ -172,35 +176,57 @@ __global__ void metrics_record_kernel(float *ring, int capacity, int slot, const
 
 extern "C" {
 
-int gcnhip_relu_fwd(gcnhip_ctx *c, float *x, uint8_t *mask, int64_t n, int training) {
-    if (!c || !x || (training && !mask)) return -1;
+int gcnhip_relu_fwd_2d(gcnhip_ctx *c, float *x, int ld, int rows, int cols, uint8_t *mask, int training) {
+    if (!c || !x || (training && !mask) || rows < 0 || cols < 0 || ld < cols) return -1;
+    const int64_t n = (int64_t)rows * cols;
     if (n <= 0) return 0;
-    relu_fwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(x, mask, n, training);
+    relu_fwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(x, mask, n, training, cols, ld);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }
-int gcnhip_relu_bwd(gcnhip_ctx *c, float *grad, const uint8_t *mask, int64_t n) {
-    if (!c || !grad || !mask) return -1;
+int gcnhip_relu_bwd_2d(gcnhip_ctx *c, float *grad, int ld, int rows, int cols, const uint8_t *mask) {
+    if (!c || !grad || !mask || rows < 0 || cols < 0 || ld < cols) return -1;
+    const int64_t n = (int64_t)rows * cols;
     if (n <= 0) return 0;
-    relu_bwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(grad, mask, n);
+    relu_bwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(grad, mask, n, cols, ld);
     GCNHIP_LAUNCH_CHECK();
     return 0;
+}
+int gcnhip_dropout_fwd_2d(gcnhip_ctx *c, float *x, int ld, int rows, int cols, int32_t *mask, float p,
+                          uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset, const uint8_t *keep_in) {
+    if (!c || !x || !(p >= 0.f && p < 1.f) || rows < 0 || cols < 0 || ld < cols) return -1;
+    const int64_t n = (int64_t)rows * cols;
+    if (n <= 0) return 0;
+    dropout_fwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(x, mask, n, dropout_threshold(p), 1 / (1 - p),
+                                                                    seed, d_epoch, elem_offset, keep_in, cols, ld);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_dropout_bwd_2d(gcnhip_ctx *c, float *grad, int ld, int rows, int cols, const int32_t *mask, float p) {
+    if (!c || !grad || rows < 0 || cols < 0 || ld < cols) return -1;
+    const int64_t n = (int64_t)rows * cols;
+    if (!mask || n <= 0) return 0;               // module.cpp:224: no mask, no-op
+    dropout_bwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(grad, mask, n, 1 / (1 - p), cols, ld);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+// the reference's flat form (one contiguous array of n elements): a single row
+int gcnhip_relu_fwd(gcnhip_ctx *c, float *x, uint8_t *mask, int64_t n, int training) {
+    if (n > 0x7fffffff) return -1;
+    return gcnhip_relu_fwd_2d(c, x, (int)n, 1, (int)n, mask, training);
+}
+int gcnhip_relu_bwd(gcnhip_ctx *c, float *grad, const uint8_t *mask, int64_t n) {
+    if (n > 0x7fffffff) return -1;
+    return gcnhip_relu_bwd_2d(c, grad, (int)n, 1, (int)n, mask);
 }
 int gcnhip_dropout_fwd(gcnhip_ctx *c, float *x, int32_t *mask, int64_t n, float p,
                        uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset, const uint8_t *keep_in) {
-    if (!c || !x || !(p >= 0.f && p < 1.f)) return -1;
-    if (n <= 0) return 0;
-    dropout_fwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(x, mask, n, dropout_threshold(p), 1 / (1 - p),
-                                                                    seed, d_epoch, elem_offset, keep_in);
-    GCNHIP_LAUNCH_CHECK();
-    return 0;
+    if (n > 0x7fffffff) return -1;
+    return gcnhip_dropout_fwd_2d(c, x, (int)n, 1, (int)n, mask, p, seed, d_epoch, elem_offset, keep_in);
 }
 int gcnhip_dropout_bwd(gcnhip_ctx *c, float *grad, const int32_t *mask, int64_t n, float p) {
-    if (!c || !grad) return -1;
-    if (!mask || n <= 0) return 0;               // module.cpp:224: no mask, no-op
-    dropout_bwd_kernel<<<stream_grid(n, 1024), 256, 0, c->stream>>>(grad, mask, n, 1 / (1 - p));
-    GCNHIP_LAUNCH_CHECK();
-    return 0;
+    if (n > 0x7fffffff) return -1;
+    return gcnhip_dropout_bwd_2d(c, grad, (int)n, 1, (int)n, mask, p);
 }
 int gcnhip_relu_dropout_bwd(gcnhip_ctx *c, float *grad, int ld_grad, const float *h, int ld_h,
                             int n_rows, int dim, float scale) {

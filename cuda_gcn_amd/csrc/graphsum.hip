@@ -42,7 +42,12 @@ struct GsArgs {
     const uint32_t *d_epoch;
     const uint8_t *keep_mask;
     const uint32_t *row_bits;   // optional: bit j == 0 -> row j of `in` is all zero and is not read
+    const uint32_t *out_bits;   // optional: bit r == 0 -> nobody reads row r of `out`: it is not computed (left untouched)
 };
+
+__device__ inline bool row_wanted(const GsArgs &a, int row) {
+    return !a.out_bits || ((a.out_bits[row >> 5] >> (row & 31)) & 1u);
+}
 
 __device__ inline float4 f4_fma(float c, float4 v, float4 a) {
     a.x += c * v.x; a.y += c * v.y; a.z += c * v.z; a.w += c * v.w;
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     } else {
         row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
     }
+    if (!row_wanted(a, row)) return;                       // wave-uniform
     const int g = lane / L, l = lane % L;
     const int col0 = (cslice * L + l) * 4;                  // first column of this lane's float4
     const bool active = col0 < a.dim;
@@ -184,6 +190,7 @@ __global__ __launch_bounds__(256) void graphsum_bf16_kernel(GsArgs a) {
     } else {
         row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
     }
+    if (!row_wanted(a, row)) return;                       // wave-uniform
     const int g = lane / L, l = lane % L;
     const int col0 = (cslice * L + l) * 8;
     const bool active = col0 < a.dim;
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256) void graphsum_scalar_kernel(GsArgs a) {
     } else {
         row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
     }
+    if (!row_wanted(a, row)) return;                       // wave-uniform
     const int g = lane / L, l = lane % L;
     for (int cbase = 0; cbase < a.dim; cbase += L * MAXC) {
         float acc[MAXC] = {0.f, 0.f, 0.f, 0.f};
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
     if (s >= n_split_rows) return;
     const int4 sr = split_rows[s];
     const int row = sr.x, first = sr.y, ns = sr.z;
+    if (!row_wanted(a, row)) return;
     for (int col = threadIdx.x; col < a.dim; col += blockDim.x) {
         float v = 0.f;
         for (int k = 0; k < ns; k++) v += a.partials[(size_t)(first + k) * a.part_ld + col];
@@ -380,7 +389,7 @@ static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
 static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in, float *out, int ld_out,
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
-                         const uint16_t *in_bf = nullptr) {
+                         const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr) {
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (in_bf && (ld_in % 8 != 0 || !aligned16(in_bf))) return -1;
     if (g->n_rows == 0) return 0;
@@ -396,6 +405,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.scale = 1 / (1 - p);                                  // module.cpp:212
     a.seed = seed; a.elem_offset = elem_offset; a.d_epoch = d_epoch; a.keep_mask = keep_mask;
     a.row_bits = row_bits;
+    a.out_bits = out_bits;
     const int nt = g->n_tasks ? g->n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
@@ -448,6 +458,11 @@ int gcnhip_graphsum_rowmask(gcnhip_ctx *c, const gcnhip_graph *g, const float *i
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr, in_row_bits);
 }
 
+int gcnhip_graphsum_masked(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
+                           float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits) {
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr, in_row_bits, nullptr, out_row_bits);
+}
+
 int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
                                  float *out, int ld_out, int dim, int training, float p,
                                  uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
@@ -467,12 +482,12 @@ int gcnhip_f32_to_bf16(gcnhip_ctx *c, const float *src, int ld_src, uint16_t *ds
 }
 
 int gcnhip_graphsum_bf16(gcnhip_ctx *c, const gcnhip_graph *g, const uint16_t *in_bf16, int ld_in,
-                         float *out, int ld_out, int dim, const uint32_t *in_row_bits,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits,
                          int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask) {
     if (relu_dropout && training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, nullptr, ld_in, out, ld_out, dim, relu_dropout ? 1 : 0, training, relu_dropout ? p : 0.f, seed, d_epoch,
-                         elem_offset, keep_mask, in_row_bits, in_bf16);
+                         elem_offset, keep_mask, in_row_bits, in_bf16, out_row_bits);
 }
 
 }  // extern "C"

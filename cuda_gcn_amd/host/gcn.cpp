@@ -1,6 +1,7 @@
 #include "gcn.h"
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <tuple>
 #include "hip_check.h"
@@ -40,7 +41,25 @@ bool labels_are_assortative(const GCNData &d, int N, int C) {
 }  // namespace
 
 HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : params(p), data(input_data), flags(opt.flags) {
+    // a constructor that throws runs no destructor: release whatever init() had built before the failure
+    try {
+        init(opt);
+    } catch (...) {
+        release();
+        throw;
+    }
+}
+
+void HipGCN::init(const HipGCNOptions &opt) {
     device_ = opt.device;
+    // argument checks first: nothing is allocated for a request that cannot be served
+    if (opt.world > 1 && !opt.comm && !opt.host_allgather && !(flags & HIPGCN_NULL_COMM) && !opt.nccl_id)
+        throw GcnHipFailure(-1, "world > 1 needs an RCCL unique id");
+    if (params.num_nodes < 1 || params.hidden_dim < 1 || params.output_dim < 1 || params.input_dim < 1)
+        throw GcnHipFailure(-1, "HipGCN: empty model dimensions");
+    if ((int)data->graph.indptr.size() != params.num_nodes + 1 || (int)data->split.size() != params.num_nodes ||
+        (int)data->label.size() != params.num_nodes || (int)data->feature_index.indptr.size() != params.num_nodes + 1)
+        throw GcnHipFailure(-1, "HipGCN: GCNData arrays do not match num_nodes");
     GCNHIP_CHECK(gcnhip_ctx_create(&env.ctx, opt.device, nullptr));
     timers.reset(new DeviceTimers(env.ctx));
     timers->enabled = (flags & HIPGCN_TIMERS) != 0;
@@ -123,6 +142,17 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         for (int s = 1; s <= 3; s++) split_count[s] = (int)cnt[s];
     }
 
+    // scored-split bit per LOCAL row: the last aggregation of a forward computes only the rows the loss and the
+    // accuracy read (CrossEntropyLoss::forward skips truth < 0, module.cpp:131-133; get_accuracy, gcn.cpp:86-88)
+    if (getenv("HIPGCN_ALL_ROWS")) flags |= HIPGCN_ALL_ROWS;
+    if (!(flags & HIPGCN_ALL_ROWS))
+        for (int s = 1; s <= 3; s++) {
+            std::vector<uint32_t> bits((size_t)n_local / 32 + 2, 0u);
+            for (int r = 0; r < n_local; r++)
+                if (data->split[r0 + r] == s) bits[r >> 5] |= 1u << (r & 31);
+            d_split_bits[s] = dev_upload(env.ctx, bits.data(), bits.size());
+        }
+
     // training-split bit per padded node position: dZ is zero elsewhere, GraphSum's backward skips those rows
     {
         const size_t n_pos = world > 1 ? (size_t)world * part.rows_max : (size_t)N;
@@ -138,7 +168,6 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
     for (auto &v : variables) v.reset(new HipVariable());
     const int rm = part.rows_max;
     if (flags & HIPGCN_MODULAR) {
-        if (H % 4 != 0) throw GcnHipFailure(-1, "modular mode needs hidden_dim % 4 == 0");
         variables[0]->alloc(env.ctx, 1, (int)(f1 - f0), false);
         input = variables[0].get();
         input_vals = input->data;
@@ -202,7 +231,7 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
         } catch (const GcnHipFailure &e) {
             // e.g. an RCCL without ncclCommSplit: every rank fails the same way and falls back to one lane
             fprintf(stderr, "gcn-hip: validation lane disabled (%s)\n", e.what());
-            lane.reset();
+            destroy_lane();
         }
     }
     AdamParams ap = AdamParams::get_default();
@@ -276,7 +305,7 @@ void HipGCN::build_modules() {
         modules.push_back(new HipReLU(&env, H1));
         modules.push_back(new HipDropout(&env, H1, p, KEY_HIDDEN_DROPOUT, hid_off, (flags & HIPGCN_HOST_MASKS) ? &env.keep_hidden : &no_mask));
         modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C));
-        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; modules.push_back(gs); }
+        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_row_bits = &cur_out_bits; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, true));
     } else {
         const float scale = 1 / (1 - p);
@@ -294,7 +323,7 @@ void HipGCN::build_modules() {
         modules.push_back(sm);
         modules.push_back(gs);
         modules.push_back(mm);
-        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; modules.push_back(gs); }
+        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_row_bits = &cur_out_bits; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
     }
 }
@@ -356,35 +385,50 @@ void HipGCN::build_eval_lane() {
         L.modules.push_back(gs);
     }
     L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
-    L.modules.push_back(new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C));
+    { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_row_bits = &L.out_bits; L.modules.push_back(gs); }
     L.modules.push_back(new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false));
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_weights));
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_done));
     GCNHIP_CHECK(gcnhip_ctx_sync(L.env.ctx));
 }
 
-HipGCN::~HipGCN() {
-    if (env.ctx) gcnhip_ctx_sync(env.ctx);
-    if (lane) {
-        EvalLane &L = *lane;
+// whatever of the lane exists (it may be half built when build_eval_lane threw)
+void HipGCN::destroy_lane() {
+    if (!lane) return;
+    EvalLane &L = *lane;
+    if (L.env.ctx) {
         gcnhip_ctx_sync(L.env.ctx);
         for (auto m : L.modules) delete m;
+        L.modules.clear();
         L.H0.reset(); L.H1.reset(); L.Z0.reset(); L.Z.reset();
         if (L.graph) gcnhip_graph_destroy(L.env.ctx, L.graph);
         if (L.graph_l1) gcnhip_graph_destroy(L.env.ctx, L.graph_l1);
         gcnhip_free(L.env.ctx, L.d_result); gcnhip_free(L.env.ctx, L.d_result_i); gcnhip_free(L.env.ctx, L.env.d_epoch);
-        gcnhip_event_destroy(L.ev_weights); gcnhip_event_destroy(L.ev_done);
+        if (L.ev_weights) gcnhip_event_destroy(L.ev_weights);
+        if (L.ev_done) gcnhip_event_destroy(L.ev_done);
         L.timers.reset();
         L.comm.reset();
         gcnhip_ctx_destroy(L.env.ctx);
-        lane.reset();
     }
+    lane.reset();
+}
+
+HipGCN::~HipGCN() { release(); }
+
+void HipGCN::release() {
+    if (!env.ctx) return;
+    gcnhip_ctx_sync(env.ctx);
+    destroy_lane();
     for (auto m : modules) delete m;
-    // W1/W2 grads live in gradbuf
-    if (variables.size() == 7) { variables[2]->grad = nullptr; variables[5]->grad = nullptr; }
+    modules.clear();
+    // W1/W2 grads live in gradbuf (interior pointers: never freed through the variable)
+    if (variables.size() == 7 && gradbuf) {
+        if (variables[2]) variables[2]->grad = nullptr;
+        if (variables[5]) variables[5]->grad = nullptr;
+    }
     variables.clear();
     optimizer.reset();
-    if (epoch_graph) gcnhip_graph_exec_destroy(epoch_graph);
+    if (epoch_graph) { gcnhip_graph_exec_destroy(epoch_graph); epoch_graph = nullptr; }
     if (graph) gcnhip_graph_destroy(env.ctx, graph);
     if (feat) gcnhip_feat_destroy(env.ctx, feat);
     if (feat_full) gcnhip_feat_destroy(env.ctx, feat_full);
@@ -397,6 +441,7 @@ HipGCN::~HipGCN() {
     gcnhip_free(env.ctx, d_keep0);
     gcnhip_free(env.ctx, d_keep1);
     gcnhip_free(env.ctx, d_train_bits);
+    for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_split_bits[s]);
     gcnhip_free(env.ctx, d_pos_bits);
     timers.reset();
     owned_comm.reset();
@@ -430,6 +475,7 @@ void HipGCN::set_timers(bool on) {
 void HipGCN::set_truth(int s) {                 // gcn.cpp:78-81: here a pointer switch
     cur_truth = d_truth[s];
     cur_count = split_count[s];
+    cur_out_bits = d_split_bits[s];
 }
 
 // replay the reference's RNG consumption for one training epoch: nnzX draws for
@@ -496,6 +542,7 @@ void HipGCN::lane_begin(int s) {
     L.epoch_word = want;
     L.truth = d_truth[s];
     L.count = split_count[s];
+    L.out_bits = d_split_bits[s];
 }
 
 void HipGCN::lane_end(int s) {

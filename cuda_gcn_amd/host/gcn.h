@@ -41,6 +41,7 @@ enum HipGCNFlags {
     HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
     HIPGCN_GATHER_DH1 = 256,
     HIPGCN_BF16_TABLES = 2048,   // opt-in, beyond the reference: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate)
+    HIPGCN_ALL_ROWS = 4096,      // compute every row of the logits (default: only rows of the scored split, which is all the loss and accuracy read)
     HIPGCN_NULL_COMM = 1024,     // world > 1 without transport: collectives are no-ops (per-rank compute timing only)
     HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
@@ -131,6 +132,8 @@ private:
     int32_t *cur_truth = nullptr;
     uint32_t *d_train_bits = nullptr;                          // bit per (padded) node: in the training split
     const uint32_t *bwd_bits = nullptr;
+    uint32_t *d_split_bits[4] = {};                            // bit per LOCAL row: node is in split s (rows the loss reads)
+    const uint32_t *cur_out_bits = nullptr;                    // follows set_truth; NULL with HIPGCN_ALL_ROWS
     int split_count[4] = {};
     int cur_count = 0;
     float *d_ring = nullptr;
@@ -156,12 +159,16 @@ private:
         float *d_result = nullptr;
         int32_t *d_result_i = nullptr;
         int32_t *truth = nullptr;
+        const uint32_t *out_bits = nullptr;
         int count = 0;
         void *ev_weights = nullptr, *ev_done = nullptr;        // Adam(e) -> eval(e);  eval(e) -> Adam(e+1)
         bool pending = false;
         long epoch_word = -1;                                  // host shadow of *env.d_epoch (starts at 0xFFFFFFFF)
     };
     std::unique_ptr<EvalLane> lane;
+    void init(const HipGCNOptions &opt);
+    void release();                                            // frees everything that exists; safe on a half-built object
+    void destroy_lane();
     void build_eval_lane();
     void eval_on_lane(int current_split);
     void lane_begin(int current_split);

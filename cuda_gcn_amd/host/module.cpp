@@ -93,6 +93,7 @@ void HipGraphSum::forward(bool training) {
     // rank computed all of `in` itself (replicated first-layer product)
     gcnhip_graph *graph = this->graph;
     const int world = env->comm->size(), rank = env->comm->rank();
+    const uint32_t *out_bits = fwd_out_row_bits ? *fwd_out_row_bits : nullptr;
     const bool replicated = in->replicated && fwd_graph_replicated;
     if (replicated) graph = fwd_graph_replicated;
     if (env->bf16_tables) {
@@ -112,7 +113,7 @@ void HipGraphSum::forward(bool training) {
         }
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
         const bool fused = fused_relu_dropout >= 0.f;
-        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, out->data, out->ld, dim, nullptr, fused ? 1 : 0, training ? 1 : 0,
+        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, out->data, out->ld, dim, nullptr, out_bits, fused ? 1 : 0, training ? 1 : 0,
                                           fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
                                           training ? env->keep_hidden : nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
@@ -130,6 +131,8 @@ void HipGraphSum::forward(bool training) {
             GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
                                                       fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
                                                       training ? env->keep_hidden : nullptr));
+        else if (out_bits)
+            GCNHIP_CHECK(gcnhip_graphsum_masked(env->ctx, graph, src, in->ld, out->data, out->ld, dim, nullptr, out_bits));
         else
             GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
@@ -164,7 +167,7 @@ void HipGraphSum::backward() {
             }
         }
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, in->grad, in->ld, dim, row_bits, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, in->grad, in->ld, dim, row_bits, nullptr, 0, 0, 0.f, 0, nullptr, 0, nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_BW);
         return;
@@ -201,18 +204,18 @@ void HipCrossEntropyLoss::forward(bool training) {
 // --------------------------------------------------------------------- ReLU
 HipReLU::HipReLU(HipEnv *env, HipVariable *in) : env(env), in(in), mask(nullptr) {
     void *p;
-    GCNHIP_CHECK(gcnhip_malloc(env->ctx, &p, in->elems()));
+    GCNHIP_CHECK(gcnhip_malloc(env->ctx, &p, (size_t)in->rows * in->cols));
     mask = (uint8_t *)p;
 }
 HipReLU::~HipReLU() { gcnhip_free(env->ctx, mask); }
 void HipReLU::forward(bool training) {
     env->timers->start(TMR_RELU_FW);
-    GCNHIP_CHECK(gcnhip_relu_fwd(env->ctx, in->data, mask, (int64_t)in->elems(), training ? 1 : 0));
+    GCNHIP_CHECK(gcnhip_relu_fwd_2d(env->ctx, in->data, in->ld, in->rows, in->cols, mask, training ? 1 : 0));
     env->timers->stop(TMR_RELU_FW);
 }
 void HipReLU::backward() {
     env->timers->start(TMR_RELU_BW);
-    GCNHIP_CHECK(gcnhip_relu_bwd(env->ctx, in->grad, mask, (int64_t)in->elems()));
+    GCNHIP_CHECK(gcnhip_relu_bwd_2d(env->ctx, in->grad, in->ld, in->rows, in->cols, mask));
     env->timers->stop(TMR_RELU_BW);
 }
 
@@ -221,7 +224,7 @@ HipDropout::HipDropout(HipEnv *env, HipVariable *in, float p, uint64_t key_tweak
     : env(env), in(in), mask(nullptr), p(p), key_tweak(key_tweak), elem_offset(elem_offset), keep_in(keep_in) {
     if (in->grad) {                                 // module.cpp:199: a mask only when the input has a gradient
         void *q;
-        GCNHIP_CHECK(gcnhip_malloc(env->ctx, &q, in->elems() * sizeof(int32_t)));
+        GCNHIP_CHECK(gcnhip_malloc(env->ctx, &q, (size_t)in->rows * in->cols * sizeof(int32_t)));
         mask = (int32_t *)q;
     }
 }
@@ -229,14 +232,14 @@ HipDropout::~HipDropout() { if (mask) gcnhip_free(env->ctx, mask); }
 void HipDropout::forward(bool training) {
     if (!training) return;                          // module.cpp:208
     env->timers->start(TMR_DROPOUT_FW);
-    // modular mode works on ld == cols layouts only (asserted by the model builder)
-    GCNHIP_CHECK(gcnhip_dropout_fwd(env->ctx, in->data, mask, (int64_t)in->rows * in->cols, p, env->seed ^ key_tweak,
-                                    env->d_epoch, elem_offset, *keep_in));
+    // element (r, c) of the padded layout is the reference's flat element r*cols + c (RNG stream, masks)
+    GCNHIP_CHECK(gcnhip_dropout_fwd_2d(env->ctx, in->data, in->ld, in->rows, in->cols, mask, p, env->seed ^ key_tweak,
+                                       env->d_epoch, elem_offset, *keep_in));
     env->timers->stop(TMR_DROPOUT_FW);
 }
 void HipDropout::backward() {
     if (!mask) return;                              // module.cpp:224
     env->timers->start(TMR_DROPOUT_BW);
-    GCNHIP_CHECK(gcnhip_dropout_bwd(env->ctx, in->grad, mask, (int64_t)in->rows * in->cols, p));
+    GCNHIP_CHECK(gcnhip_dropout_bwd_2d(env->ctx, in->grad, in->ld, in->rows, in->cols, mask, p));
     env->timers->stop(TMR_DROPOUT_BW);
 }

@@ -89,6 +89,9 @@ public:
     bool out_grad_complete = false;
     // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
     const uint32_t *const *bwd_row_bits = nullptr;
+    // rows of `out` that the consumer reads in forward() (bit = 1); the others are not computed.  NULL: all rows.
+    // The last aggregation sets it: loss and accuracy read only rows of the scored split (module.cpp:131-133).
+    const uint32_t *const *fwd_out_row_bits = nullptr;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
     ~HipGraphSum() override;

@@ -126,6 +126,7 @@ bool Parser::parse() {
         std::cout << "Loaded binary cache." << std::endl;
         return true;
     }
+    *gcnData = GCNData();      // a rejected cache leaves nothing behind: the text parsers append
     // all three must open before anything is parsed (parser.cpp:48-50,111)
     for (const char *ext : {".graph", ".split", ".svmlight"}) {
         FILE *f = fopen((root + name + ext).c_str(), "rb");
@@ -149,12 +150,18 @@ bool wr(FILE *f, const std::vector<T> &v) {
     uint64_t n = v.size();
     return fwrite(&n, sizeof n, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
 }
+// `left` = bytes of the file not yet consumed: a length prefix larger than that is a truncated or
+// corrupt cache, rejected before anything is allocated
 template <class T>
-bool rd(FILE *f, std::vector<T> &v) {
+bool rd(FILE *f, std::vector<T> &v, uint64_t &left) {
     uint64_t n;
-    if (fread(&n, sizeof n, 1, f) != 1) return false;
+    if (left < sizeof n || fread(&n, sizeof n, 1, f) != 1) return false;
+    left -= sizeof n;
+    if (n > left / sizeof(T)) return false;
     v.resize(n);
-    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+    if (n && fread(v.data(), sizeof(T), n, f) != n) return false;
+    left -= n * sizeof(T);
+    return true;
 }
 }  // namespace
 
@@ -174,10 +181,37 @@ bool Parser::load_binary(const std::string &path, GCNParams *p, GCNData *d) {
     if (!f) return false;
     char magic[8];
     int dims[3];
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 && fread(dims, sizeof dims, 1, f) == 1 &&
-              rd(f, d->graph.indptr) && rd(f, d->graph.indices) && rd(f, d->feature_index.indptr) &&
-              rd(f, d->feature_index.indices) && rd(f, d->feature_value) && rd(f, d->split) && rd(f, d->label);
+    uint64_t left = 0;
+    if (fseek(f, 0, SEEK_END) == 0) { const long sz = ftell(f); if (sz > 0) left = (uint64_t)sz; }
+    rewind(f);
+    // read into a scratch object and validate it against the header: the caller's GCNData is touched only by a
+    // complete, self-consistent cache (a stale or cut-off file must leave it empty for the text parsers)
+    GCNData t;
+    bool ok = left >= 8 + sizeof dims && fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 &&
+              fread(dims, sizeof dims, 1, f) == 1;
+    if (ok) left -= 8 + sizeof dims;
+    ok = ok && rd(f, t.graph.indptr, left) && rd(f, t.graph.indices, left) && rd(f, t.feature_index.indptr, left) &&
+         rd(f, t.feature_index.indices, left) && rd(f, t.feature_value, left) && rd(f, t.split, left) && rd(f, t.label, left);
     fclose(f);
-    if (ok) { p->num_nodes = dims[0]; p->input_dim = dims[1]; p->output_dim = dims[2]; }
-    return ok;
+    if (!ok) return false;
+    const int64_t N = dims[0];
+    if (N < 0 || dims[1] < 0 || dims[2] < 0) return false;
+    if ((int64_t)t.graph.indptr.size() != N + 1 || (int64_t)t.feature_index.indptr.size() != N + 1 ||
+        (int64_t)t.split.size() != N || (int64_t)t.label.size() != N)
+        return false;
+    if (t.graph.indptr.front() != 0 || (size_t)t.graph.indptr.back() != t.graph.indices.size()) return false;
+    if (t.feature_index.indptr.front() != 0 || (size_t)t.feature_index.indptr.back() != t.feature_value.size()) return false;
+    // indices may be omitted for a dense X (every row = columns 0..input_dim-1)
+    if (t.feature_index.indices.size() != t.feature_value.size() &&
+        !(t.feature_index.indices.empty() && (int64_t)t.feature_value.size() == N * dims[1]))
+        return false;
+    for (int64_t i = 0; i < N; i++)
+        if (t.graph.indptr[i + 1] < t.graph.indptr[i] || t.feature_index.indptr[i + 1] < t.feature_index.indptr[i]) return false;
+    for (int j : t.graph.indices)
+        if (j < 0 || j >= N) return false;
+    for (int k : t.feature_index.indices)
+        if (k < 0 || k >= dims[1]) return false;
+    *d = std::move(t);
+    p->num_nodes = dims[0]; p->input_dim = dims[1]; p->output_dim = dims[2];
+    return true;
 }

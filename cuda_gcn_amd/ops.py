@@ -105,6 +105,25 @@ class Device:
         return Feat(self, indptr, indices, values, n_cols)
 
     # ---- ops (numpy in, numpy out)
+    def _bits(self, flags):
+        bits = np.packbits(np.asarray(flags, bool), bitorder="little")
+        return self.buf(np.concatenate([bits, np.zeros((-bits.size) % 4 + 4, np.uint8)]).view(np.uint32))
+
+    def graphsum_masked(self, g: "Graph", x, ld_in=None, ld_out=None, row_nonzero=None, out_rows=None, fill=np.nan):
+        """gcnhip_graphsum_masked: rows of x flagged zero are not read, rows of the result not in out_rows are
+        not computed (they keep `fill`)"""
+        x = np.asarray(x, np.float32)
+        dim = x.shape[1]
+        ld_in, ld_out = ld_in or dim, ld_out or dim
+        xin = self.padded(x, ld_in)
+        out = self.buf(np.full((g.n_rows, ld_out), fill, np.float32))
+        g.reserve(dim)
+        ib = self._bits(row_nonzero) if row_nonzero is not None else None
+        ob = self._bits(out_rows) if out_rows is not None else None
+        _ck(self.lib, self.lib.gcnhip_graphsum_masked(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim,
+                                                       ib.ptr if ib else None, ob.ptr if ob else None), "gcnhip_graphsum_masked")
+        return out.download()[:, :dim]
+
     def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None, row_nonzero=None):
         x = np.asarray(x, np.float32)
         dim = x.shape[1]
@@ -132,7 +151,7 @@ class Device:
         _ck(self.lib, self.lib.gcnhip_f32_to_bf16(self.ctx, xb.ptr, dim, dst.ptr, ld_dst, rows, dim), "gcnhip_f32_to_bf16")
         return dst.download()
 
-    def graphsum_bf16(self, g: "Graph", table_u16, dim, ld_out=None, row_nonzero=None, relu_dropout=None):
+    def graphsum_bf16(self, g: "Graph", table_u16, dim, ld_out=None, row_nonzero=None, relu_dropout=None, out_rows=None):
         """GraphSum over a bf16 table (uint16 [n_cols, ld]); relu_dropout = dict(training, p, seed, epoch, elem_offset, keep_mask)"""
         t = np.ascontiguousarray(table_u16, np.uint16)
         ld_in = t.shape[1]
@@ -148,7 +167,9 @@ class Device:
         g.reserve(dim)
         ep = self.buf(np.array([rd.get("epoch", 0)], np.uint32))
         km = self.buf(np.ascontiguousarray(rd["keep_mask"], np.uint8)) if rd.get("keep_mask") is not None else None
+        ob = self._bits(out_rows) if out_rows is not None else None
         _ck(self.lib, self.lib.gcnhip_graphsum_bf16(self.ctx, g.h, tb.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr if bb else None,
+                                                     ob.ptr if ob else None,
                                                      1 if relu_dropout is not None else 0, int(rd.get("training", 0)), float(rd.get("p", 0.0)),
                                                      int(rd.get("seed", 0)), ep.ptr, int(rd.get("elem_offset", 0)), km.ptr if km else None),
             "gcnhip_graphsum_bf16")

@@ -117,6 +117,13 @@ int gcnhip_graphsum(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int
  * identical results. */
 int gcnhip_graphsum_rowmask(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int ld_in,
                             float *out, int ld_out, int dim, const uint32_t *in_row_bits);
+/* ... and when only some rows of `out` are ever read: bit r of out_row_bits (n_rows bits) == 0 means row r is
+ * not computed and its memory is left untouched.  The last aggregation of a forward is the case: the loss and the
+ * accuracy read only rows whose node is in the scored split (CrossEntropyLoss::forward, module.cpp:131-133;
+ * GCN::get_accuracy, gcn.cpp:86-88), i.e. 66 % of Reddit's rows in a training forward and 10 % in a validation
+ * forward.  Every computed row is bit-identical to gcnhip_graphsum's.  Either mask may be NULL. */
+int gcnhip_graphsum_masked(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int ld_in,
+                           float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits);
 /* Fused epilogue used by the first layer: GraphSum, then ReLU
  * (module.cpp:175-185), then Dropout (module.cpp:207-221) on the same rows.
  * training == 0: ReLU only.  The dropout decision for element (r, c) is
@@ -166,11 +173,11 @@ int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, co
  * GraphSum reading that table: coef, the running sum and `out` are f32, so the ONLY difference to
  * gcnhip_graphsum* is the rounding of the gathered values — on a table that holds bf16-representable numbers
  * the two agree bit for bit.  A row of d values is 2d bytes: half the cache lines per edge.
- * in_row_bits (optional) as in gcnhip_graphsum_rowmask; relu_dropout != 0 selects the fused epilogue of
+ * in_row_bits / out_row_bits (optional) as in gcnhip_graphsum_masked; relu_dropout != 0 selects the fused epilogue of
  * gcnhip_graphsum_relu_dropout with the arguments that follow. */
 int gcnhip_f32_to_bf16(gcnhip_ctx *ctx, const float *src, int ld_src, uint16_t *dst, int ld_dst, int64_t rows, int dim);
 int gcnhip_graphsum_bf16(gcnhip_ctx *ctx, const gcnhip_graph *g, const uint16_t *in_bf16, int ld_in,
-                         float *out, int ld_out, int dim, const uint32_t *in_row_bits,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits,
                          int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask);
 
@@ -203,6 +210,10 @@ int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *ctx, const float *b, int ldb, const fl
  * mask: one byte per element, written only when training (module.cpp:180). */
 int gcnhip_relu_fwd(gcnhip_ctx *ctx, float *x, uint8_t *mask, int64_t n, int training);
 int gcnhip_relu_bwd(gcnhip_ctx *ctx, float *grad, const uint8_t *mask, int64_t n);
+/* the same on a [rows x cols] matrix with leading dimension ld (the model's padded layouts, e.g. 40 columns at
+ * ld 48): element (r, c) is the reference's flat element r*cols + c — masks stay dense [rows*cols] */
+int gcnhip_relu_fwd_2d(gcnhip_ctx *ctx, float *x, int ld, int rows, int cols, uint8_t *mask, int training);
+int gcnhip_relu_bwd_2d(gcnhip_ctx *ctx, float *grad, int ld, int rows, int cols, const uint8_t *mask);
 
 /* ---- Dropout (CUDADropout: cuda_module.cu:201-227; cuda_kernel.cu:223-240;
  *      CPU: src/seq/module.cpp:207-233) -----------------------------------------
@@ -222,6 +233,11 @@ int gcnhip_dropout_fwd(gcnhip_ctx *ctx, float *x, int32_t *mask, int64_t n, floa
                        uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
                        const uint8_t *keep_in);
 int gcnhip_dropout_bwd(gcnhip_ctx *ctx, float *grad, const int32_t *mask, int64_t n, float p);
+/* [rows x cols] with leading dimension ld; the decision for (r, c) is keep(elem_offset + r*cols + c) or
+ * keep_in[r*cols + c]; mask is dense [rows*cols] */
+int gcnhip_dropout_fwd_2d(gcnhip_ctx *ctx, float *x, int ld, int rows, int cols, int32_t *mask, float p,
+                          uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset, const uint8_t *keep_in);
+int gcnhip_dropout_bwd_2d(gcnhip_ctx *ctx, float *grad, int ld, int rows, int cols, const int32_t *mask, float p);
 /* backward of the fused ReLU+Dropout: grad[i] = h[i] > 0 ? scale * grad[i] : 0 */
 int gcnhip_relu_dropout_bwd(gcnhip_ctx *ctx, float *grad, int ld_grad, const float *h, int ld_h,
                             int n_rows, int dim, float scale);

@@ -41,6 +41,8 @@ enum {
     GCNHOST_GATHER_DH1 = 256,     /* multi-GPU backward: all-gather dH1 instead of dZ0 + mask bits */
     GCNHOST_NO_ROW_GROUPS = 512,  /* keep the plain descending-degree row schedule (no load-time timing of alternatives) */
     GCNHOST_BF16_TABLES = 2048,   /* opt-in, beyond the reference: the aggregation gathers bfloat16 copies of H0, Z0, dZ, dH1 (f32 sums) */
+    GCNHOST_ALL_ROWS = 4096,      /* compute every row of the logits (default: the last aggregation computes only the rows of the
+                                     scored split — all that loss and accuracy read; env HIPGCN_ALL_ROWS=1 does the same) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 

@@ -1,5 +1,6 @@
 """ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when present,
-for the reference's own objects (oracle/_ref/libref.so, build container only).
+for the reference's own objects (oracle/_ref/libref.so: built in the build container from the
+reference's sources where they lie; the built library travels to the GPU box with the snapshot).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
 bench.py's cpu_baseline leg — never by the product package.
@@ -52,7 +53,7 @@ class Oracle:
     """numpy front end of gcn_oracle.h"""
 
     def __init__(self, path: str | None = None):
-        path = path or os.path.join(HERE, "liboracle.so")
+        path = path or os.environ.get("GCN_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")   # GCN_ORACLE_LIB: the sanitizer build
         if not os.path.exists(path):
             build()
         self.lib = L = C.CDLL(path)
@@ -269,7 +270,7 @@ class OracleModel:
 
 class Ref:
     """numpy front end of oracle/_ref/libref.so (the reference's own objects).
-    Exists in the build container only."""
+    Built in the build container only; present wherever the built file travelled (tests skip without it)."""
 
     PATH = os.path.join(HERE, "_ref", "libref.so")
 

@@ -3,11 +3,14 @@
  *
  * TEST INFRASTRUCTURE ONLY.  This file is ours; it is compiled together with
  * the reference's sources *where they lie* under /root/reference (see
- * oracle/Makefile, target `ref`) into oracle/_ref/libref.so, which exists
- * only in the build container (the reference never travels to the GPU box
- * and no reference source is copied into this repo).  It is used to
- *   (1) pin oracle/gcn_oracle.c bit-for-bit against the reference, and
- *   (2) generate the fixtures committed under tests/golden/.
+ * oracle/Makefile, target `ref`) into oracle/_ref/libref.so.  It can only be BUILT
+ * in the build container (the reference's sources never travel and none is
+ * copied into this repo); the built library is git-ignored but does travel
+ * to the GPU box with the repo snapshot, like our own .so files.  It is used to
+ *   (1) pin oracle/gcn_oracle.c bit-for-bit against the reference,
+ *   (2) generate the fixtures committed under tests/golden/, and
+ *   (3) be the timed CPU baseline of bench.py (cpu_baseline.kind "reference")
+ * and by nothing else: tests/ and bench.py's cpu_baseline leg are its only loaders.
  *
  * No reference source is modified: time(NULL) in src/seq/rand.cpp:7 is
  * redirected at link time (-Wl,--wrap=time) to __wrap_time below, and the

@@ -21,7 +21,7 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def ref():
-    """the reference's own objects (oracle/_ref/libref.so); build container only"""
+    """the reference's own objects (oracle/_ref/libref.so): built in the build container, used wherever the built file is present"""
     from oracle.pyoracle import Ref, build
     if not Ref.available() and os.path.isdir("/root/reference/src"):
         build()

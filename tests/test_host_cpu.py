@@ -139,3 +139,39 @@ def test_graphsage_converter_on_a_small_fixture():
     X = ds["f_val"].reshape(5, 5)
     tr = X[[0, 3, 4]]
     assert np.allclose(tr.mean(axis=0), 0, atol=1e-6) and np.allclose(tr.std(axis=0), 1, atol=1e-5)
+
+
+def test_truncated_or_inconsistent_gcnbin_is_rejected_and_text_is_parsed(tmp_path):
+    """a cache whose magic matches but whose arrays are cut off, oversized or inconsistent with the header must
+    not leave a half-filled GCNData behind: the loader falls back to the text files and gives their arrays"""
+    import struct
+    from cuda_gcn_amd import model
+    ds = datagen.make_dataset("tiny-syn")
+    root = str(tmp_path)
+    datagen.write_text(ds, root, "t")
+    want = model.load_dataset(root, "t")
+    good = os.path.join(root, "good.gcnbin")
+    datagen.write_gcnbin(ds, good)
+    blob = open(good, "rb").read()
+    bad = {
+        "cut": blob[:len(blob) // 2],
+        "huge_len": blob[:20] + struct.pack("<Q", 1 << 60) + blob[28:],
+        "short_split": None,
+        "bad_column": None,
+    }
+    d2 = dict(ds); d2["split"] = ds["split"][:-3]
+    datagen.write_gcnbin(d2, os.path.join(root, "tmp.gcnbin")); bad["short_split"] = open(os.path.join(root, "tmp.gcnbin"), "rb").read()
+    d3 = dict(ds); gi = ds["g_indices"].copy(); gi[5] = ds["num_nodes"] + 7; d3["g_indices"] = gi
+    datagen.write_gcnbin(d3, os.path.join(root, "tmp.gcnbin")); bad["bad_column"] = open(os.path.join(root, "tmp.gcnbin"), "rb").read()
+    os.remove(os.path.join(root, "tmp.gcnbin"))
+    for tag, data in bad.items():
+        with open(os.path.join(root, "t.gcnbin"), "wb") as f:
+            f.write(data)
+        got = model.load_dataset(root, "t")
+        for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
+            assert np.array_equal(got[k], want[k]), (tag, k)
+        assert got["num_nodes"] == want["num_nodes"]
+    with open(os.path.join(root, "t.gcnbin"), "wb") as f:       # and the intact cache is accepted
+        f.write(blob)
+    got = model.load_dataset(root, "t")
+    assert np.array_equal(got["g_indices"], ds["g_indices"]) and np.array_equal(got["f_val"], ds["f_val"])

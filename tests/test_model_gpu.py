@@ -65,15 +65,16 @@ def test_trace_dropout0_vs_oracle(oracle, name, hidden, mode):
     m.close(); om.close()
 
 
-@pytest.mark.parametrize("name", ["tiny-syn", "cora-syn"])
+@pytest.mark.parametrize("name,hidden", [("tiny-syn", 16), ("cora-syn", 16),
+                                         ("tiny-syn", 40), ("tiny-syn", 6)])   # 40 -> ld 48, 6 -> ld 8: padded rows (ld != cols)
 @pytest.mark.parametrize("mode", ["fused", "modular"])
-def test_trace_dropout_host_masks_vs_oracle(oracle, name, mode):
+def test_trace_dropout_host_masks_vs_oracle(oracle, name, hidden, mode):
     """dropout 0.5 with the reference's own RNG decisions replayed on the host"""
     from cuda_gcn_amd.model import HipGCNModel, MODULAR, HOST_MASKS
     ds = datagen.make_dataset(name)
     epochs = 60 if name == "tiny-syn" else 30
-    want, _, om = oracle_trace(oracle, ds, 3, epochs, hidden_dim=16, dropout=0.5)
-    m = HipGCNModel(ds, seed=3, flags=HOST_MASKS | (MODULAR if mode == "modular" else 0), hidden_dim=16, dropout=0.5, epochs=epochs)
+    want, _, om = oracle_trace(oracle, ds, 3, epochs, hidden_dim=hidden, dropout=0.5)
+    m = HipGCNModel(ds, seed=3, flags=HOST_MASKS | (MODULAR if mode == "modular" else 0), hidden_dim=hidden, dropout=0.5, epochs=epochs)
     got = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
     check_trace(got, want, ds)
     m.close(); om.close()
@@ -94,13 +95,16 @@ def test_trace_vs_reference_golden(name, seed, dropout):
     m.close()
 
 
-def test_first_epoch_tensors_vs_oracle(oracle):
-    """every intermediate of one training epoch (H0, H1, Z0, Z and their gradients)"""
-    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+@pytest.mark.parametrize("all_rows", [True, False])
+def test_first_epoch_tensors_vs_oracle(oracle, all_rows):
+    """every intermediate of one training epoch (H0, H1, Z0, Z and their gradients).  By default the last
+    aggregation computes only the rows of the scored split (all that the loss reads, module.cpp:131-133):
+    then Z is compared on those rows; with ALL_ROWS on every row."""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS, ALL_ROWS
     ds = datagen.make_dataset("cora-syn")
     N, H, C = ds["num_nodes"], 16, ds["output_dim"]
     om = oracle.model(ds, seed_time=9, hidden_dim=H, dropout=0.5)
-    m = HipGCNModel(ds, seed=9, flags=HOST_MASKS, hidden_dim=H, dropout=0.5)
+    m = HipGCNModel(ds, seed=9, flags=HOST_MASKS | (ALL_ROWS if all_rows else 0), hidden_dim=H, dropout=0.5)
     assert np.array_equal(m.var(2).reshape(-1), om.var(2))          # same Glorot init as gcn-seq
     assert np.array_equal(m.var(5).reshape(-1), om.var(5))
     a, b = m.train_epoch(), om.train_epoch()
@@ -112,6 +116,9 @@ def test_first_epoch_tensors_vs_oracle(oracle):
             want = want - 0          # oracle's Z is max-shifted in place; fused path leaves Z unshifted
             got = m.var(k)
             got = got - got.max(axis=1, keepdims=True) * (ds["split"] == 1)[:, None]
+            if not all_rows:
+                assert np.all(got[ds["split"] != 1] == 0)      # never computed: still the allocation's zeros
+                got, want = got[ds["split"] == 1], want[ds["split"] == 1]
         else:
             got = m.var(k)
         assert np.allclose(got, want, rtol=2e-5, atol=2e-6), k
@@ -247,6 +254,24 @@ def test_eval_lane_is_bit_identical():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,hidden", [("cora-syn", 16), ("reddit-mini", 128)])
+def test_scored_rows_only_is_bit_identical_to_all_rows(name, hidden):
+    """skipping the rows of the logits that no split reads changes no reported number and no weight"""
+    from cuda_gcn_amd.model import HipGCNModel, ALL_ROWS
+    ds = datagen.make_dataset(name)
+    a = HipGCNModel(ds, seed=8, flags=ALL_ROWS, hidden_dim=hidden, dropout=0.5, epochs=12)
+    b = HipGCNModel(ds, seed=8, hidden_dim=hidden, dropout=0.5, epochs=12)
+    ta, tb = a.run_epochs(10), b.run_epochs(10)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert a.train_epoch() == b.train_epoch()
+    for s in (2, 3, 1):
+        assert a.eval(s) == b.eval(s)
+    assert np.array_equal(a.var(2), b.var(2)) and np.array_equal(a.var(5), b.var(5))
+    za, zb = a.var(6), b.var(6)                              # after eval(1): rows of the training split
+    assert np.array_equal(za[ds["split"] == 1], zb[ds["split"] == 1])
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""
@@ -329,7 +354,9 @@ def test_full_size_reddit_two_epochs_vs_oracle(oracle):
     z, zo = m.var(6), om.var(6).reshape(-1, ds["output_dim"])
     lab = ds["split"] == 2                                   # the oracle max-shifts the rows it scored, in place
     z = z - np.where(lab[:, None], z.max(axis=1, keepdims=True), 0)
-    assert np.allclose(z, zo, rtol=1e-4, atol=5e-6)
+    # only the scored rows of Z are computed (nobody reads the others); all rows of the aggregation at full
+    # size are covered by test_graphsum_reddit_size_properties and the masked-vs-unmasked op test
+    assert np.allclose(z[lab], zo[lab], rtol=1e-4, atol=5e-6)
     for e in range(2):
         got = m.train_epoch() + m.eval(2)
         want = om.train_epoch() + om.eval(2)

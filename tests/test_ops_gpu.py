@@ -103,6 +103,31 @@ def hub_graph(n=3000, hub_deg=2500, seed=3):
 
 
 # --------------------------------------------------------------------- GraphSum
+@pytest.mark.parametrize("gname", ["cora-syn", "hub"])
+@pytest.mark.parametrize("dim,ld", [(41, 48), (7, 8), (128, 128), (5, 5)])
+def test_graphsum_output_row_mask(dev, gname, dim, ld):
+    """gcnhip_graphsum_masked: computed rows are bit-identical to the unmasked call, rows nobody reads are left
+    untouched (hub graph: a split row that is masked out, and one that is kept, go through the finalize kernel)"""
+    gp, gi = hub_graph() if gname == "hub" else (lambda d: (d["g_indptr"], d["g_indices"]))(datagen.make_dataset(gname))
+    n = gp.size - 1
+    g = dev.graph(gp, gi)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    full = dev.graphsum(g, x, ld_in=ld, ld_out=ld)
+    for trial in range(2):
+        want_rows = rng.random(n) < (0.66 if trial == 0 else 0.1)
+        want_rows[0] = trial == 0                      # row 0 is the hub
+        got = dev.graphsum_masked(g, x, ld_in=ld, ld_out=ld, out_rows=want_rows, fill=123.0)
+        assert np.array_equal(got[want_rows], full[want_rows])
+        assert np.all(got[~want_rows] == 123.0)
+        zero_rows = rng.random(n) < 0.5                # with an input-row mask as well
+        xm = x * zero_rows[:, None]
+        both = dev.graphsum_masked(g, xm, ld_in=ld, ld_out=ld, row_nonzero=zero_rows, out_rows=want_rows, fill=-7.0)
+        ref = dev.graphsum(g, xm, ld_in=ld, ld_out=ld, row_nonzero=zero_rows)
+        assert np.array_equal(both[want_rows], ref[want_rows]) and np.all(both[~want_rows] == -7.0)
+    g.free()
+
+
 def test_edge_coef_bit_exact(dev):
     ds = datagen.make_dataset("cora-syn")
     gp, gi = ds["g_indptr"], ds["g_indices"]

@@ -3,7 +3,7 @@
 (1) against the committed fixtures in tests/golden/ — produced by the
     reference's own objects (tests/golden/make_golden.py);
 (2) against oracle/_ref/libref.so itself on fresh seeded inputs, when the
-    reference tree is present (build container only).
+    built library is present (it can be built in the build container only).
 CPU only; everything here is exact equality (==), no tolerance.
 """
 import os

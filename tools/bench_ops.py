@@ -84,7 +84,7 @@ def main():
         t = dev.buf(np.zeros((N, ld), np.uint16))
         o = dev.buf((N, (dim + 3) // 4 * 4))
         ms_c = timeit(dev, lambda: _ck(lib, lib.gcnhip_f32_to_bf16(dev.ctx, x.ptr, dim, t.ptr, ld, N, dim), "cv"))
-        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum_bf16(dev.ctx, g.h, t.ptr, ld, o.ptr, (dim + 3) // 4 * 4, dim, None, 0, 0, 0.0, 0, None, 0, None), "gsb"))
+        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum_bf16(dev.ctx, g.h, t.ptr, ld, o.ptr, (dim + 3) // 4 * 4, dim, None, None, 0, 0, 0.0, 0, None, 0, None), "gsb"))
         res[f"graphsum_bf16_d{dim}_ld{ld}"] = dict(ms=ms, convert_ms=ms_c)
         print(f"graphsum bf16 table d={dim} ld={ld}: {ms:.3f} ms (+ f32->bf16 convert {ms_c:.3f} ms)", flush=True)
     only_gs = len(sys.argv) > 3 and sys.argv[3] == 'graphsum'
