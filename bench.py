@@ -252,7 +252,8 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)    # control plane; data plane is RCCL in libgcnhost
 
     from cuda_gcn_amd import datagen
-    from cuda_gcn_amd.model import (HipGCNModel, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, NO_ROW_GROUPS, nccl_unique_id)
+    from cuda_gcn_amd.model import (HipGCNModel, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, NO_ROW_GROUPS, NO_AGG_FIRST_EVAL,
+                                    ALL_ROWS, nccl_unique_id)
 
     def barrier():
         if world > 1:
@@ -399,7 +400,10 @@ def main():
                                    f"{ds['input_dim']}->{args.hidden}->{ds['output_dim']}, dropout 0.5, Adam; "
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
-                       "train_nodes": n_lab, "aggregation_schedule": schedule},
+                       "train_nodes": n_lab, "aggregation_schedule": schedule,
+                       "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
+                                       "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",
+                       "logit_rows": "all" if os.environ.get("HIPGCN_ALL_ROWS") else "rows of the scored split only"},
             "bursts": {"epochs_per_s": [round(b, 2) for b in burst_eps], "median": statistics.median(burst_eps), "min": min(burst_eps),
                        "max": max(burst_eps), "steps_each": args.steps},
             "roofline": roof,
@@ -419,6 +423,15 @@ def main():
         out["value_no_row_groups"] = args.steps / d2
         m2.close()
         log(f"no row groups: {args.steps / d2:.2f} epochs/s")
+    if extras and not args.no_row_groups:
+        # ... and with every forward in the reference's own operation order and every row of the logits computed
+        # (no A^.X built once for the evaluation forwards, no skipping of rows the loss never reads)
+        m3, _ = build(base_flags | NO_AGG_FIRST_EVAL | ALL_ROWS)
+        m3.run_epochs(args.warmup, want_trace=False)
+        d3, _tr = timed_region(m3, args.steps)
+        out["value_reference_op_order_all_rows"] = args.steps / d3
+        m3.close()
+        log(f"reference op order, all rows: {args.steps / d3:.2f} epochs/s")
     if extras:
         try:
             out["roofline"]["hbm_regime"] = hbm_regime_leg(args.hbm_scale, args.hidden if args.hidden > 64 else 128, device)

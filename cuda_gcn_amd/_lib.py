@@ -87,13 +87,18 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graphsum": (I, [P, P, P, I, P, I, I]),
     "gcnhip_graphsum_rowmask": (I, [P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_masked": (I, [P, P, P, I, P, I, I, P, P]),
+    "gcnhip_graph_add_rowset": (I, [P, P, P, C.POINTER(P)]),
+    "gcnhip_rowset_size": (I, [P, C.POINTER(I)]),
+    "gcnhip_graphsum_rowset": (I, [P, P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
+    "gcnhip_feat_create_aggregated": (I, [P, C.POINTER(P), P, P]),
     "gcnhip_feat_destroy": (I, [P, P]),
     "gcnhip_feat_is_dense": (I, [P]),
     "gcnhip_feat_values": (P, [P]),
     "gcnhip_feat_nnz": (I64, [P]),
     "gcnhip_spmm_fwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
+    "gcnhip_spmm_fwd_relu": (I, [P, P, P, P, I, P, I, I]),
     "gcnhip_spmm_bwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
     "gcnhip_matmul_fwd": (I, [P, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I]),

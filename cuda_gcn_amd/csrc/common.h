@@ -32,6 +32,17 @@ struct gcnhip_ctx {
 };
 constexpr int RED_SLOTS = 4096;
 
+// a registered subset of the rows of an adjacency object: its own compacted task list, in the order of the
+// object's current row schedule (rebuilt whenever that changes).  Segment slots are the full schedule's.
+struct gcnhip_rowset {
+    std::vector<uint32_t> bits;   // host copy: bit r = row r is in the subset
+    int n_tasks;
+    int4 *tasks;
+    int n_split_rows;
+    int4 *split_rows;
+    int bounds[4][9];
+};
+
 struct gcnhip_graph {
     int n_rows, n_cols, nnz;
     int *indptr;        // [n_rows+1]
@@ -49,6 +60,8 @@ struct gcnhip_graph {
     int bounds[4][9];
     int *tmp_col_deg;   // only during construction
     std::vector<int> *h_indptr;   // host copy of the row pointers (the schedule can be rebuilt)
+    std::vector<int4> *h_tasks, *h_srows;   // host copies of the full schedule (row subsets are cut from them)
+    std::vector<gcnhip_rowset *> *rowsets;   // owned
 };
 
 struct gcnhip_feat {

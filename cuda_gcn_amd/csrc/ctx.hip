@@ -164,6 +164,49 @@ static int split_length(int64_t nnz) {
     return s;
 }
 
+// equal-work task ranges for 1/2/4/8 XCD groups, each starting on a multiple of 4 tasks (one workgroup)
+static void xcd_bounds(const std::vector<int4> &tasks, int bounds[4][9]) {
+    const int n_units = (int)tasks.size();
+    std::vector<int64_t> prefix((size_t)n_units + 1);   // work before task t: edges + a per-task constant
+    prefix[0] = 0;
+    for (int t = 0; t < n_units; t++) prefix[t + 1] = prefix[t] + (tasks[t].z - tasks[t].y) + 8;
+    for (int lg = 0; lg < 4; lg++) {
+        const int G = 1 << lg;
+        bounds[lg][0] = 0;
+        for (int k = 1; k < G; k++) {
+            const int64_t target = prefix[n_units] * k / G;
+            int t = (int)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+            t = (t + 3) / 4 * 4;
+            if (t > n_units) t = n_units;
+            if (t < bounds[lg][k - 1]) t = bounds[lg][k - 1];
+            bounds[lg][k] = t;
+        }
+        for (int k = G; k <= 8; k++) bounds[lg][k] = n_units;
+    }
+}
+
+// the tasks of the full schedule whose row is in the subset, same order, same segment slots
+static int build_rowset(gcnhip_rowset *rs, const std::vector<int4> &tasks, const std::vector<int4> &srows) {
+    if (rs->tasks) { GCNHIP_TRY(hipFree(rs->tasks)); rs->tasks = nullptr; }
+    if (rs->split_rows) { GCNHIP_TRY(hipFree(rs->split_rows)); rs->split_rows = nullptr; }
+    auto in = [&](int r) { return (rs->bits[r >> 5] >> (r & 31)) & 1u; };
+    std::vector<int4> t2, s2;
+    for (const int4 &t : tasks) if (in(t.x)) t2.push_back(t);
+    for (const int4 &sr : srows) if (in(sr.x)) s2.push_back(sr);
+    rs->n_tasks = (int)t2.size();
+    rs->n_split_rows = (int)s2.size();
+    if (!t2.empty()) {
+        GCNHIP_TRY(hipMalloc((void **)&rs->tasks, t2.size() * sizeof(int4)));
+        GCNHIP_TRY(hipMemcpy(rs->tasks, t2.data(), t2.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    if (!s2.empty()) {
+        GCNHIP_TRY(hipMalloc((void **)&rs->split_rows, s2.size() * sizeof(int4)));
+        GCNHIP_TRY(hipMemcpy(rs->split_rows, s2.data(), s2.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    xcd_bounds(t2, rs->bounds);
+    return 0;
+}
+
 // (Re)build the row schedule: tasks ordered by (key[row] ascending, degree descending); key == nullptr: degree only.
 static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
     const int n_rows = g->n_rows;
@@ -196,9 +239,6 @@ static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
     g->n_split_rows = (int)srows.size();
     g->n_slots = n_slots;
     const int n_units = g->n_tasks;
-    std::vector<int64_t> prefix((size_t)n_units + 1);   // work before task t: edges + a per-task constant
-    prefix[0] = 0;
-    for (int t = 0; t < n_units; t++) prefix[t + 1] = prefix[t] + (tasks[t].z - tasks[t].y) + 8;
     if (n_units) {
         GCNHIP_TRY(hipMalloc((void **)&g->tasks, tasks.size() * sizeof(int4)));
         GCNHIP_TRY(hipMemcpy(g->tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -212,20 +252,16 @@ static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
     if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); g->partials = nullptr; }
     if (g->part_ld < 256) g->part_ld = 256;
     if (n_slots) GCNHIP_TRY(hipMalloc((void **)&g->partials, (size_t)n_slots * g->part_ld * sizeof(float)));
-    // equal-work task ranges for 1/2/4/8 XCD groups, each starting on a multiple of 4 tasks (one workgroup)
-    for (int lg = 0; lg < 4; lg++) {
-        const int G = 1 << lg;
-        g->bounds[lg][0] = 0;
-        for (int k = 1; k < G; k++) {
-            const int64_t target = prefix[n_units] * k / G;
-            int t = (int)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
-            t = (t + 3) / 4 * 4;
-            if (t > n_units) t = n_units;
-            if (t < g->bounds[lg][k - 1]) t = g->bounds[lg][k - 1];
-            g->bounds[lg][k] = t;
+    xcd_bounds(tasks, g->bounds);
+    if (!g->h_tasks) g->h_tasks = new std::vector<int4>();
+    if (!g->h_srows) g->h_srows = new std::vector<int4>();
+    *g->h_tasks = tasks;
+    *g->h_srows = srows;
+    if (g->rowsets)
+        for (gcnhip_rowset *rs : *g->rowsets) {
+            const int rc = build_rowset(rs, tasks, srows);
+            if (rc != 0) return rc;
         }
-        for (int k = G; k <= 8; k++) g->bounds[lg][k] = n_units;
-    }
     return 0;
 }
 
@@ -310,6 +346,16 @@ int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
     if (g->coef) hipFree(g->coef);
     if (g->tmp_col_deg) hipFree(g->tmp_col_deg);
     delete g->h_indptr;
+    delete g->h_tasks;
+    delete g->h_srows;
+    if (g->rowsets) {
+        for (gcnhip_rowset *rs : *g->rowsets) {
+            if (rs->tasks) hipFree(rs->tasks);
+            if (rs->split_rows) hipFree(rs->split_rows);
+            delete rs;
+        }
+        delete g->rowsets;
+    }
     if (g->tasks) hipFree(g->tasks);
     if (g->split_rows) hipFree(g->split_rows);
     if (g->partials) hipFree(g->partials);
@@ -334,6 +380,31 @@ int gcnhip_graph_set_schedule(gcnhip_ctx *c, gcnhip_graph *g, int mode, const in
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ip[a + 1] - ip[a] > ip[b + 1] - ip[b]; });
     for (int k = 0; k < n; k++) key[order[k]] = k % n_groups;
     return build_schedule(g, key.data());
+}
+
+int gcnhip_graph_add_rowset(gcnhip_ctx *c, gcnhip_graph *g, const uint32_t *h_row_bits, gcnhip_rowset **out) {
+    if (!c || !g || !h_row_bits || !out || !g->h_tasks) return -1;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    gcnhip_rowset *rs = new gcnhip_rowset();
+    rs->n_tasks = rs->n_split_rows = 0;
+    rs->tasks = rs->split_rows = nullptr;
+    rs->bits.assign(h_row_bits, h_row_bits + (size_t)g->n_rows / 32 + 1);
+    const int rc = build_rowset(rs, *g->h_tasks, *g->h_srows);
+    if (rc != 0) {
+        if (rs->tasks) hipFree(rs->tasks);
+        if (rs->split_rows) hipFree(rs->split_rows);
+        delete rs;
+        return rc;
+    }
+    if (!g->rowsets) g->rowsets = new std::vector<gcnhip_rowset *>();
+    g->rowsets->push_back(rs);
+    *out = rs;
+    return 0;
+}
+int gcnhip_rowset_size(const gcnhip_rowset *rs, int *n_rows_tasks) {
+    if (!rs || !n_rows_tasks) return -1;
+    *n_rows_tasks = rs->n_tasks;
+    return 0;
 }
 
 int gcnhip_graph_reserve_width(gcnhip_ctx *c, gcnhip_graph *g, int max_dim) {
@@ -433,6 +504,47 @@ static int feat_create_impl(gcnhip_ctx *c, gcnhip_feat *f, const int *h_indptr, 
             GCNHIP_TRY(hipMemcpy(f->csc_pos, pos.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
         }
     }
+    return 0;
+}
+
+// A^.X for a dense X, computed once: the feature object of an evaluation forward that aggregates first.
+static int feat_aggregate_impl(gcnhip_ctx *c, gcnhip_feat *f, gcnhip_graph *g, const gcnhip_feat *x) {
+    GCNHIP_TRY(hipSetDevice(c->device));
+    const int F = x->n_cols, n = g->n_rows;
+    f->n_rows = n; f->n_cols = F; f->nnz = (int64_t)n * F; f->dense = true;
+    std::vector<int> ip((size_t)n + 1);
+    for (int r = 0; r <= n; r++) ip[r] = (int)((int64_t)r * F);
+    GCNHIP_TRY(hipMalloc((void **)&f->indptr, (size_t)(n + 1) * sizeof(int)));
+    GCNHIP_TRY(hipMemcpy(f->indptr, ip.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice));
+    GCNHIP_TRY(hipMalloc((void **)&f->values, (size_t)std::max<int64_t>(f->nnz, 4) * sizeof(float)));
+    GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (size_t)(f->nnz / 32 + 32) * sizeof(uint32_t)));
+    int rc = gcnhip_graph_reserve_width(c, g, F);
+    if (rc != 0) return rc;
+    const float *src = x->values_pad ? x->values_pad : x->values;
+    const int ld_src = x->values_pad ? x->ld_pad : F;
+    if (x->values_pad) {                          // keep the padded, 16-byte aligned layout the MFMA tiles read
+        f->ld_pad = x->ld_pad;
+        GCNHIP_TRY(hipMalloc((void **)&f->values_pad, (size_t)n * f->ld_pad * sizeof(float)));
+        GCNHIP_TRY(hipMemsetAsync(f->values_pad, 0, (size_t)n * f->ld_pad * sizeof(float), c->stream));
+        rc = gcnhip_graphsum(c, g, src, ld_src, f->values_pad, f->ld_pad, F);
+        if (rc != 0) return rc;
+        GCNHIP_TRY(hipMemcpy2DAsync(f->values, (size_t)F * sizeof(float), f->values_pad, (size_t)f->ld_pad * sizeof(float),
+                                    (size_t)F * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        rc = gcnhip_graphsum(c, g, src, ld_src, f->values, F, F);
+        if (rc != 0) return rc;
+    }
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gcnhip_feat_create_aggregated(gcnhip_ctx *c, gcnhip_feat **out, gcnhip_graph *g, const gcnhip_feat *x) {
+    if (!c || !out || !g || !x || !x->dense || x->n_rows != g->n_cols) return -1;
+    gcnhip_feat *f = new gcnhip_feat();
+    memset(f, 0, sizeof *f);
+    const int rc = feat_aggregate_impl(c, f, g, x);
+    if (rc != 0) { gcnhip_feat_destroy(c, f); return rc; }
+    *out = f;
     return 0;
 }
 

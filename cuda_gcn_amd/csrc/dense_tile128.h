@@ -45,6 +45,7 @@ struct Tile128Args {
     const uint32_t *bits;             // NULL: no dropout
     float scale;
     int rows_per_split;               // bwd only
+    int relu;                         // fwd only: store max(x, 0)
 };
 
 template <int V>
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = row_base + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-                if (row < a.m) a.out[(size_t)row * a.ldo + col] = acc[i][j][r];
+                if (row < a.m) a.out[(size_t)row * a.ldo + col] = (a.relu && !(acc[i][j][r] > 0.f)) ? 0.f : acc[i][j][r];
             }
         }
 }

@@ -261,14 +261,14 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 }
 
 template <int L>
-static void launch_bf16(GsArgs a, const gcnhip_graph *g, hipStream_t s) {
+static void launch_bf16(GsArgs a, const int (*xb)[9], hipStream_t s) {
     const int ychunks = ceil_div(a.dim, L * 8);
     const bool sliced = ychunks > 1 && 8 % ychunks == 0;
     a.n_slices = sliced ? ychunks : 1;
     const int G = 8 / a.n_slices;
     const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
     int max_blocks = 1;
-    for (int k = 0; k <= 8; k++) a.bounds[k] = g->bounds[lg][k];
+    for (int k = 0; k <= 8; k++) a.bounds[k] = xb[lg][k];
     for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
     graphsum_bf16_kernel<L><<<dim3(max_blocks * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
 }
@@ -370,14 +370,14 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
 }
 
 template <int L>
-static void launch_vec(GsArgs a, const gcnhip_graph *g, hipStream_t s) {
+static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     const int ychunks = ceil_div(a.dim, L * 4);
     const bool sliced = ychunks > 1 && 8 % ychunks == 0;   // XCD-sliced columns (1-D grid)
     a.n_slices = sliced ? ychunks : 1;
     const int G = 8 / a.n_slices;                          // XCD groups that share the task list
     const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
     int max_blocks = 1;
-    for (int k = 0; k <= 8; k++) a.bounds[k] = g->bounds[lg][k];
+    for (int k = 0; k <= 8; k++) a.bounds[k] = xb[lg][k];
     for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
     graphsum_vec_kernel<L><<<dim3(max_blocks * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
 }
@@ -389,16 +389,21 @@ static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
 static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in, float *out, int ld_out,
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
-                         const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr) {
+                         const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr,
+                         const gcnhip_rowset *rs = nullptr) {
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (in_bf && (ld_in % 8 != 0 || !aligned16(in_bf))) return -1;
-    if (g->n_rows == 0) return 0;
+    if (g->n_rows == 0 || (rs && rs->n_tasks == 0)) return 0;
     // the segment scratch of split rows is sized when the object is built (256 columns) or by
     // gcnhip_graph_reserve_width; a launch never allocates, synchronises or touches the object
     if (g->n_slots && g->part_ld < (dim + 7) / 8 * 8) return -1;
     GsArgs a;
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
-    a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows;
+    // a registered row subset brings its own compacted task list (same order, same segment slots)
+    a.tasks = rs ? rs->tasks : g->tasks; a.n_tasks = rs ? rs->n_tasks : g->n_tasks; a.n_rows = g->n_rows;
+    const int (*xb)[9] = rs ? rs->bounds : g->bounds;
+    const int4 *split_rows = rs ? rs->split_rows : g->split_rows;
+    const int n_split_rows = rs ? rs->n_split_rows : g->n_split_rows;
     a.in = in; a.in_bf = in_bf; a.out = out; a.partials = g->partials;
     a.ld_in = ld_in; a.ld_out = ld_out; a.part_ld = g->part_ld; a.dim = dim;
     a.fuse = fuse; a.training = training; a.thr = dropout_threshold(p);
@@ -406,29 +411,29 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.seed = seed; a.elem_offset = elem_offset; a.d_epoch = d_epoch; a.keep_mask = keep_mask;
     a.row_bits = row_bits;
     a.out_bits = out_bits;
-    const int nt = g->n_tasks ? g->n_tasks : g->n_rows;
+    const int nt = a.n_tasks ? a.n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
     a.n_slices = 1;
     if (in_bf) {
         const int d8 = (dim + 7) / 8;                       // 16-byte pieces per row
-        if (d8 <= 1) launch_bf16<1>(a, g, c->stream);
-        else if (d8 <= 2) launch_bf16<2>(a, g, c->stream);
-        else if (d8 <= 4) launch_bf16<4>(a, g, c->stream);
-        else launch_bf16<8>(a, g, c->stream);               // 64-column (one line) slices, one per XCD group when 8 % slices == 0
+        if (d8 <= 1) launch_bf16<1>(a, xb, c->stream);
+        else if (d8 <= 2) launch_bf16<2>(a, xb, c->stream);
+        else if (d8 <= 4) launch_bf16<4>(a, xb, c->stream);
+        else launch_bf16<8>(a, xb, c->stream);               // 64-column (one line) slices, one per XCD group when 8 % slices == 0
     } else if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
         // rows of whole 128-byte lines: one 32-float column slice per XCD group (measured at
         // Reddit scale, d = 128: 1.42 ms unsliced -> 1.26 ms; L2 hit rate of the gather rises
         // because each XCD's L2 holds a quarter of the table)
-        launch_vec<8>(a, g, c->stream);
+        launch_vec<8>(a, xb, c->stream);
     } else if (vec) {
-        if (d4 <= 1) launch_vec<1>(a, g, c->stream);
-        else if (d4 <= 2) launch_vec<2>(a, g, c->stream);
-        else if (d4 <= 4) launch_vec<4>(a, g, c->stream);
-        else if (d4 <= 8) launch_vec<8>(a, g, c->stream);
-        else if (d4 <= 16) launch_vec<16>(a, g, c->stream);
-        else if (d4 <= 32) launch_vec<32>(a, g, c->stream);
-        else launch_vec<64>(a, g, c->stream);
+        if (d4 <= 1) launch_vec<1>(a, xb, c->stream);
+        else if (d4 <= 2) launch_vec<2>(a, xb, c->stream);
+        else if (d4 <= 4) launch_vec<4>(a, xb, c->stream);
+        else if (d4 <= 8) launch_vec<8>(a, xb, c->stream);
+        else if (d4 <= 16) launch_vec<16>(a, xb, c->stream);
+        else if (d4 <= 32) launch_vec<32>(a, xb, c->stream);
+        else launch_vec<64>(a, xb, c->stream);
     } else {
         if (dim <= 1) launch_scalar<1>(a, nt, c->stream);
         else if (dim <= 2) launch_scalar<2>(a, nt, c->stream);
@@ -439,8 +444,8 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         else launch_scalar<64>(a, nt, c->stream);
     }
     GCNHIP_LAUNCH_CHECK();
-    if (g->n_split_rows) {
-        graphsum_finalize_kernel<<<g->n_split_rows, 256, 0, c->stream>>>(a, g->split_rows, g->n_split_rows);
+    if (n_split_rows) {
+        graphsum_finalize_kernel<<<n_split_rows, 256, 0, c->stream>>>(a, split_rows, n_split_rows);
         GCNHIP_LAUNCH_CHECK();
     }
     return 0;
@@ -463,6 +468,12 @@ int gcnhip_graphsum_masked(gcnhip_ctx *c, const gcnhip_graph *g, const float *in
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr, in_row_bits, nullptr, out_row_bits);
 }
 
+int gcnhip_graphsum_rowset(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_rowset *rows, const float *in, int ld_in,
+                           float *out, int ld_out, int dim, const uint32_t *in_row_bits) {
+    if (!rows) return -1;
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 0, 0, 0.f, 0, nullptr, 0, nullptr, in_row_bits, nullptr, nullptr, rows);
+}
+
 int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
                                  float *out, int ld_out, int dim, int training, float p,
                                  uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
@@ -482,12 +493,12 @@ int gcnhip_f32_to_bf16(gcnhip_ctx *c, const float *src, int ld_src, uint16_t *ds
 }
 
 int gcnhip_graphsum_bf16(gcnhip_ctx *c, const gcnhip_graph *g, const uint16_t *in_bf16, int ld_in,
-                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, const gcnhip_rowset *out_rows,
                          int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask) {
     if (relu_dropout && training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, nullptr, ld_in, out, ld_out, dim, relu_dropout ? 1 : 0, training, relu_dropout ? p : 0.f, seed, d_epoch,
-                         elem_offset, keep_mask, in_row_bits, in_bf16, out_row_bits);
+                         elem_offset, keep_mask, in_row_bits, in_bf16, nullptr, out_rows);
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ struct SpFwdArgs {
     float *out;
     int n_rows, ld_w, ld_out, p;
     DropSpec d;
+    int relu;                       // store max(x, 0) (module.cpp:175-185 folded into the producer)
 };
 
 template <int L, bool VEC>
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void spmm_csr_fwd_kernel(SpFwdArgs a) {
             float *o = a.out + (size_t)row * a.ld_out + col0;
 #pragma unroll
             for (int i = 0; i < V; i++)
-                if (col0 + i < a.p) o[i] = acc[i];
+                if (col0 + i < a.p) o[i] = (a.relu && !(acc[i] > 0.f)) ? 0.f : acc[i];
         }
     }
 }
@@ -169,6 +170,7 @@ struct DenseFwdArgs {
     int m, K, p;
     const uint32_t *bits;           // keep bits of the stored elements (dropbits_kernel), NULL: no dropout
     float scale;
+    int relu;
 };
 
 constexpr int DF_BM = 128, DF_BK = 32;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = row_base + wave * 32 + r * 16 + 4 * kq + i;
-                if (row < a.m) a.out[(size_t)row * a.ldo + col] = acc[r][t][i];
+                if (row < a.m) a.out[(size_t)row * a.ldo + col] = (a.relu && !(acc[r][t][i] > 0.f)) ? 0.f : acc[r][t][i];
             }
         }
 }
@@ -313,9 +315,9 @@ static void launch_dense_fwd(const DenseFwdArgs &a, int vx, dim3 grid, hipStream
 
 extern "C" {
 
-int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
-                    float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
-                    uint64_t nnz_offset, const uint8_t *keep_mask) {
+static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
+                         float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                         uint64_t nnz_offset, const uint8_t *keep_mask, int relu) {
     if (!c || !f || !vals || !w || !out || p <= 0 || ld_w < p || ld_out < p) return -1;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
     if (f->n_rows == 0) return 0;
@@ -326,7 +328,7 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         t.x = vals; t.ldx = f->n_cols; t.w = w; t.ldw = ld_w; t.out = out; t.ldo = ld_out;
         int vx = x_vec_width(f, vals);
         if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }   // aligned copy of the pristine X
-        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = 0;
+        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = 0; t.relu = relu;
         dim3 grid(ceil_div(f->n_rows, T_BM), ceil_div(p, T_BN));
         const bool fast = vx == 4 && t.ldx % 4 == 0 && (t.K + 31) / 32 * 32 <= t.ldx && ld_w % 4 == 0 && p % T_BN == 0 && aligned16(w);
         if (fast) dense_fwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);
@@ -340,7 +342,7 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
         DenseFwdArgs a;
         a.x = vals; a.ldx = f->n_cols; a.w = w; a.ldw = ld_w; a.out = out; a.ldo = ld_out;
-        a.m = f->n_rows; a.K = f->n_cols; a.p = p; a.bits = d.on ? f->keep_bits : nullptr; a.scale = d.scale;
+        a.m = f->n_rows; a.K = f->n_cols; a.p = p; a.bits = d.on ? f->keep_bits : nullptr; a.scale = d.scale; a.relu = relu;
         int vx = x_vec_width(f, vals);
         if (vals == f->values && f->values_pad) { a.x = f->values_pad; a.ldx = f->ld_pad; vx = 4; }
         const int nt_total = ceil_div(p, 16);
@@ -357,7 +359,7 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
     }
     SpFwdArgs a;
     a.indptr = f->indptr; a.indices = f->indices; a.vals = vals; a.w = w; a.out = out;
-    a.n_rows = f->n_rows; a.ld_w = ld_w; a.ld_out = ld_out; a.p = p; a.d = d;
+    a.n_rows = f->n_rows; a.ld_w = ld_w; a.ld_out = ld_out; a.p = p; a.d = d; a.relu = relu;
     const bool vec = ld_w % 4 == 0 && aligned16(w);
     const int units = vec ? (p + 3) / 4 : p;              // lanes needed for one row of W
     dim3 grid(ceil_div(f->n_rows, 4), 1);
@@ -371,6 +373,17 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
 #undef SPF
     GCNHIP_LAUNCH_CHECK();
     return 0;
+}
+
+int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
+                    float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
+                    uint64_t nnz_offset, const uint8_t *keep_mask) {
+    return spmm_fwd_impl(c, f, vals, w, ld_w, out, ld_out, p, p_drop, seed, d_epoch, nnz_offset, keep_mask, 0);
+}
+
+int gcnhip_spmm_fwd_relu(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
+                         float *out, int ld_out, int p) {
+    return spmm_fwd_impl(c, f, vals, w, ld_w, out, ld_out, p, 0.f, 0, nullptr, 0, nullptr, 1);
 }
 
 int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
@@ -394,7 +407,7 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
         int vx = x_vec_width(f, vals);
         if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }
-        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps;
+        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps; t.relu = 0;
         dim3 grid(S, kt, pt);
         const bool fast = vx == 4 && t.ldx % 4 == 0 && kt * 128 <= t.ldx && ld_dout % 4 == 0 && p % 128 == 0 && aligned16(dout);
         if (fast) dense_bwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);

@@ -142,16 +142,11 @@ void HipGCN::init(const HipGCNOptions &opt) {
         for (int s = 1; s <= 3; s++) split_count[s] = (int)cnt[s];
     }
 
-    // scored-split bit per LOCAL row: the last aggregation of a forward computes only the rows the loss and the
-    // accuracy read (CrossEntropyLoss::forward skips truth < 0, module.cpp:131-133; get_accuracy, gcn.cpp:86-88)
+    // The last aggregation of a forward computes only the rows the loss and the accuracy read
+    // (CrossEntropyLoss::forward skips truth < 0, module.cpp:131-133; get_accuracy, gcn.cpp:86-88):
+    // one registered row subset per split.
     if (getenv("HIPGCN_ALL_ROWS")) flags |= HIPGCN_ALL_ROWS;
-    if (!(flags & HIPGCN_ALL_ROWS))
-        for (int s = 1; s <= 3; s++) {
-            std::vector<uint32_t> bits((size_t)n_local / 32 + 2, 0u);
-            for (int r = 0; r < n_local; r++)
-                if (data->split[r0 + r] == s) bits[r >> 5] |= 1u << (r & 31);
-            d_split_bits[s] = dev_upload(env.ctx, bits.data(), bits.size());
-        }
+    if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(env.ctx, graph, split_rows);
 
     // training-split bit per padded node position: dZ is zero elsewhere, GraphSum's backward skips those rows
     {
@@ -225,6 +220,8 @@ void HipGCN::init(const HipGCNOptions &opt) {
     }
     if (!(flags & HIPGCN_NO_ROW_GROUPS)) tune_schedule();
     build_modules();
+    if (getenv("HIPGCN_NO_AGG_FIRST_EVAL")) flags |= HIPGCN_NO_AGG_FIRST_EVAL;
+    if (!(flags & (HIPGCN_NO_AGG_FIRST_EVAL | HIPGCN_MODULAR)) && gcnhip_feat_is_dense(feat) && n_local > 0) build_agg_first_eval();
     if (!(flags & HIPGCN_NO_EVAL_LANE) && ((flags & HIPGCN_EVAL_LANE) || world > 1)) {
         try {
             build_eval_lane();
@@ -250,6 +247,16 @@ void HipGCN::init(const HipGCNOptions &opt) {
 void HipGCN::apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g) {
     const int *labels = data->label.data() + part.start[env.comm->rank()];
     GCNHIP_CHECK(gcnhip_graph_set_schedule(ctx, g, sched_mode, sched_mode == 1 ? labels : nullptr, sched_groups));
+}
+
+void HipGCN::add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *out[4]) {
+    const int r0 = part.start[env.comm->rank()];
+    for (int s = 1; s <= 3; s++) {
+        std::vector<uint32_t> bits((size_t)n_local / 32 + 2, 0u);
+        for (int r = 0; r < n_local; r++)
+            if (data->split[r0 + r] == s) bits[r >> 5] |= 1u << (r & 31);
+        GCNHIP_CHECK(gcnhip_graph_add_rowset(ctx, g, bits.data(), &out[s]));
+    }
 }
 
 void HipGCN::tune_schedule() {
@@ -305,7 +312,7 @@ void HipGCN::build_modules() {
         modules.push_back(new HipReLU(&env, H1));
         modules.push_back(new HipDropout(&env, H1, p, KEY_HIDDEN_DROPOUT, hid_off, (flags & HIPGCN_HOST_MASKS) ? &env.keep_hidden : &no_mask));
         modules.push_back(new HipMatmul(&env, H1, W2, Z0, N, H, C));
-        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_row_bits = &cur_out_bits; modules.push_back(gs); }
+        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_rows = &cur_out_rows; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, true));
     } else {
         const float scale = 1 / (1 - p);
@@ -323,9 +330,48 @@ void HipGCN::build_modules() {
         modules.push_back(sm);
         modules.push_back(gs);
         modules.push_back(mm);
-        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_row_bits = &cur_out_bits; modules.push_back(gs); }
+        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_rows = &cur_out_rows; modules.push_back(gs); }
         modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
     }
+}
+
+// A^.X for this rank's rows (needs every column of the adjacency and the matching rows of X: with several GPUs
+// both are taken from the whole dataset once and released), then the evaluation module list that uses it.
+void HipGCN::build_agg_first_eval() {
+    const int world = env.comm->size(), rank = env.comm->rank();
+    const int N = params.num_nodes, F = params.input_dim, H = params.hidden_dim;
+    if (world == 1) {
+        GCNHIP_CHECK(gcnhip_feat_create_aggregated(env.ctx, &feat_agg, graph, feat));
+    } else {
+        const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
+        const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
+        const int r0 = part.start[rank];
+        gcnhip_graph *g_all = graph_l1;
+        gcnhip_feat *x_all = feat_full;
+        try {
+            if (!g_all) {
+                std::vector<int> lp(n_local + 1), deg(N);
+                for (int r = 0; r <= n_local; r++) lp[r] = gp[r0 + r] - gp[r0];
+                for (int j = 0; j < N; j++) deg[j] = gp[j + 1] - gp[j];
+                GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &g_all, lp.data(), gi.data() + gp[r0], n_local, N, deg.data()));
+            }
+            if (!x_all)
+                GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &x_all, fp.data(), fi.empty() ? nullptr : fi.data(), data->feature_value.data(), N, F));
+            GCNHIP_CHECK(gcnhip_feat_create_aggregated(env.ctx, &feat_agg, g_all, x_all));
+        } catch (...) {
+            if (g_all && g_all != graph_l1) gcnhip_graph_destroy(env.ctx, g_all);
+            if (x_all && x_all != feat_full) gcnhip_feat_destroy(env.ctx, x_all);
+            throw;
+        }
+        if (g_all != graph_l1) gcnhip_graph_destroy(env.ctx, g_all);
+        if (x_all != feat_full) gcnhip_feat_destroy(env.ctx, x_all);
+    }
+    agg_vals = gcnhip_feat_values(feat_agg);
+    // H1 = ReLU((A^.X).W1) written straight into variable 3; from there on the training modules' own forward(false)
+    auto *sm = new HipSparseMatmul(&env, &agg_vals, variables[2].get(), variables[3].get(), feat_agg, n_local, F, H, 0.f, 0);
+    sm->relu_out = true;
+    eval_modules.push_back(sm);
+    for (size_t i = 2; i < modules.size(); i++) eval_modules.push_back(modules[i]);
 }
 
 void HipGCN::build_eval_lane() {
@@ -357,10 +403,13 @@ void HipGCN::build_eval_lane() {
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, gp.data(), gi.data(), params.num_nodes, params.num_nodes, nullptr));
         GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph, std::max(params.hidden_dim, params.output_dim)));
     }
+    if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(L.env.ctx, L.graph, L.split_rows);
     apply_schedule(L.env.ctx, L.graph);                     // the schedule the training lane measured as fastest
     const int rm = part.rows_max;
     L.H0.reset(new HipVariable()); L.H1.reset(new HipVariable()); L.Z0.reset(new HipVariable()); L.Z.reset(new HipVariable());
-    if (replicate_l1) {
+    if (feat_agg) {
+        // aggregate-first: the lane's hidden layer is one GEMM on A^.X — no H0, no hidden-width aggregation, no exchange
+    } else if (replicate_l1) {
         std::vector<int> lp(N + 1), deg(params.num_nodes);
         const int r0 = part.start[rank];
         for (int r = 0; r <= N; r++) lp[r] = gp[r0 + r] - gp[r0];
@@ -377,7 +426,11 @@ void HipGCN::build_eval_lane() {
     L.Z->alloc(L.env.ctx, N, C, false);
     const uint64_t nnz_off = (uint64_t)data->feature_index.indptr[part.start[rank]];
     eval_vals = gcnhip_feat_values(feat);
-    {
+    if (feat_agg) {
+        auto *sm = new HipSparseMatmul(&L.env, &agg_vals, variables[2].get(), L.H1.get(), feat_agg, N, F, H, 0.f, 0);
+        sm->relu_out = true;
+        L.modules.push_back(sm);
+    } else {
         auto *sm = new HipSparseMatmul(&L.env, &eval_vals, variables[2].get(), L.H0.get(), feat, N, F, H, 0.f, nnz_off);
         auto *gs = new HipGraphSum(&L.env, L.H0.get(), L.H1.get(), L.graph, H, 0.f, 0);   // ReLU epilogue, no dropout in eval
         if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = L.graph_l1; }
@@ -385,7 +438,7 @@ void HipGCN::build_eval_lane() {
         L.modules.push_back(gs);
     }
     L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
-    { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_row_bits = &L.out_bits; L.modules.push_back(gs); }
+    { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_rows = &L.out_rows; L.modules.push_back(gs); }
     L.modules.push_back(new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false));
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_weights));
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_done));
@@ -419,6 +472,8 @@ void HipGCN::release() {
     if (!env.ctx) return;
     gcnhip_ctx_sync(env.ctx);
     destroy_lane();
+    if (!eval_modules.empty()) delete eval_modules[0];       // the rest are borrowed from `modules`
+    eval_modules.clear();
     for (auto m : modules) delete m;
     modules.clear();
     // W1/W2 grads live in gradbuf (interior pointers: never freed through the variable)
@@ -432,6 +487,7 @@ void HipGCN::release() {
     if (graph) gcnhip_graph_destroy(env.ctx, graph);
     if (feat) gcnhip_feat_destroy(env.ctx, feat);
     if (feat_full) gcnhip_feat_destroy(env.ctx, feat_full);
+    if (feat_agg) gcnhip_feat_destroy(env.ctx, feat_agg);
     if (graph_l1) gcnhip_graph_destroy(env.ctx, graph_l1);
     for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_truth[s]);
     gcnhip_free(env.ctx, gradbuf);
@@ -441,7 +497,6 @@ void HipGCN::release() {
     gcnhip_free(env.ctx, d_keep0);
     gcnhip_free(env.ctx, d_keep1);
     gcnhip_free(env.ctx, d_train_bits);
-    for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_split_bits[s]);
     gcnhip_free(env.ctx, d_pos_bits);
     timers.reset();
     owned_comm.reset();
@@ -475,7 +530,7 @@ void HipGCN::set_timers(bool on) {
 void HipGCN::set_truth(int s) {                 // gcn.cpp:78-81: here a pointer switch
     cur_truth = d_truth[s];
     cur_count = split_count[s];
-    cur_out_bits = d_split_bits[s];
+    cur_out_rows = split_rows[s];
 }
 
 // replay the reference's RNG consumption for one training epoch: nnzX draws for
@@ -542,7 +597,7 @@ void HipGCN::lane_begin(int s) {
     L.epoch_word = want;
     L.truth = d_truth[s];
     L.count = split_count[s];
-    L.out_bits = d_split_bits[s];
+    L.out_rows = L.split_rows[s];
 }
 
 void HipGCN::lane_end(int s) {
@@ -585,7 +640,7 @@ void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
     if (flags & HIPGCN_MODULAR)
         GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
     set_truth(s);
-    for (auto m : modules) m->forward(false);
+    for (auto m : eval_modules.empty() ? modules : eval_modules) m->forward(false);
     if (env.comm->size() > 1) {
         timers->start(TMR_COMM);
         env.comm->allreduce_sum(d_result, 4);

@@ -42,6 +42,7 @@ enum HipGCNFlags {
     HIPGCN_GATHER_DH1 = 256,
     HIPGCN_BF16_TABLES = 2048,   // opt-in, beyond the reference: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate)
     HIPGCN_ALL_ROWS = 4096,      // compute every row of the logits (default: only rows of the scored split, which is all the loss and accuracy read)
+    HIPGCN_NO_AGG_FIRST_EVAL = 8192, // evaluation forwards keep the reference's order A^.(X.W1) instead of (A^.X).W1 with A^.X built once
     HIPGCN_NULL_COMM = 1024,     // world > 1 without transport: collectives are no-ops (per-rank compute timing only)
     HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
@@ -114,6 +115,12 @@ private:
     // of N x F x h per forward instead of an all-gather of N x h floats over xGMI
     gcnhip_feat *feat_full = nullptr;
     gcnhip_graph *graph_l1 = nullptr;                          // this rank's rows, GLOBAL column ids
+    // Aggregate-first evaluation (dense X, fused mode): A^.X of this rank's rows, built once.  An evaluation forward is
+    // then ReLU((A^.X).W1) — one GEMM, no hidden-width aggregation and no exchange before the hidden layer.
+    gcnhip_feat *feat_agg = nullptr;
+    const float *agg_vals = nullptr;
+    std::vector<Module *> eval_modules;                        // [0] owned (the GEMM on A^.X); the rest are modules[2..]
+    void build_agg_first_eval();
     const float *full_vals = nullptr;
     bool replicate_l1 = false;
     bool rebuild_dh1 = false;                                  // multi-GPU backward: gather dZ0 + mask bits, rebuild dH1 everywhere
@@ -132,8 +139,8 @@ private:
     int32_t *cur_truth = nullptr;
     uint32_t *d_train_bits = nullptr;                          // bit per (padded) node: in the training split
     const uint32_t *bwd_bits = nullptr;
-    uint32_t *d_split_bits[4] = {};                            // bit per LOCAL row: node is in split s (rows the loss reads)
-    const uint32_t *cur_out_bits = nullptr;                    // follows set_truth; NULL with HIPGCN_ALL_ROWS
+    gcnhip_rowset *split_rows[4] = {};                         // rows of `graph` whose node is in split s (all the loss reads); owned by graph
+    gcnhip_rowset *cur_out_rows = nullptr;                     // follows set_truth; NULL with HIPGCN_ALL_ROWS
     int split_count[4] = {};
     int cur_count = 0;
     float *d_ring = nullptr;
@@ -159,7 +166,8 @@ private:
         float *d_result = nullptr;
         int32_t *d_result_i = nullptr;
         int32_t *truth = nullptr;
-        const uint32_t *out_bits = nullptr;
+        gcnhip_rowset *split_rows[4] = {};                     // the lane has its own adjacency object
+        gcnhip_rowset *out_rows = nullptr;
         int count = 0;
         void *ev_weights = nullptr, *ev_done = nullptr;        // Adam(e) -> eval(e);  eval(e) -> Adam(e+1)
         bool pending = false;
@@ -182,6 +190,7 @@ private:
     bool labels_assortative = false;
     void tune_schedule();
     void apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g);
+    void add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *out[4]);
     void build_modules();
     void set_truth(int current_split);
     void host_masks_for_epoch();

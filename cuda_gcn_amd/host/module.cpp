@@ -43,7 +43,10 @@ void HipSparseMatmul::forward(bool training) {
     last_training = training;
     env->timers->start(TMR_SPMATMUL_FW);
     const float pd = training ? fused_dropout : 0.f;
-    if (sp_full)        // every row of the product, with global element indices for the dropout stream
+    if (relu_out) {
+        if (training) throw GcnHipFailure(-1, "HipSparseMatmul: the ReLU epilogue is an evaluation-only form");
+        GCNHIP_CHECK(gcnhip_spmm_fwd_relu(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p));
+    } else if (sp_full)        // every row of the product, with global element indices for the dropout stream
         GCNHIP_CHECK(gcnhip_spmm_fwd(env->ctx, sp_full, *vals_full, b->data, b->ld, c->full, c->ld, p, pd,
                                      env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, 0,
                                      pd > 0.f ? env->keep_input : nullptr));
@@ -93,7 +96,7 @@ void HipGraphSum::forward(bool training) {
     // rank computed all of `in` itself (replicated first-layer product)
     gcnhip_graph *graph = this->graph;
     const int world = env->comm->size(), rank = env->comm->rank();
-    const uint32_t *out_bits = fwd_out_row_bits ? *fwd_out_row_bits : nullptr;
+    const gcnhip_rowset *out_rows = fwd_out_rows ? *fwd_out_rows : nullptr;
     const bool replicated = in->replicated && fwd_graph_replicated;
     if (replicated) graph = fwd_graph_replicated;
     if (env->bf16_tables) {
@@ -113,7 +116,7 @@ void HipGraphSum::forward(bool training) {
         }
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
         const bool fused = fused_relu_dropout >= 0.f;
-        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, out->data, out->ld, dim, nullptr, out_bits, fused ? 1 : 0, training ? 1 : 0,
+        GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, out->data, out->ld, dim, nullptr, out_rows, fused ? 1 : 0, training ? 1 : 0,
                                           fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
                                           training ? env->keep_hidden : nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
@@ -131,8 +134,8 @@ void HipGraphSum::forward(bool training) {
             GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
                                                       fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
                                                       training ? env->keep_hidden : nullptr));
-        else if (out_bits)
-            GCNHIP_CHECK(gcnhip_graphsum_masked(env->ctx, graph, src, in->ld, out->data, out->ld, dim, nullptr, out_bits));
+        else if (out_rows)
+            GCNHIP_CHECK(gcnhip_graphsum_rowset(env->ctx, graph, out_rows, src, in->ld, out->data, out->ld, dim, nullptr));
         else
             GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);

@@ -67,6 +67,7 @@ public:
     // replicated forward (multi-GPU): X of ALL rows, so c->full is computed here and never gathered
     gcnhip_feat *sp_full = nullptr;
     const float *const *vals_full = nullptr;
+    bool relu_out = false;          // evaluation on A^.X: ReLU when the product is stored (forward(false) only)
     HipSparseMatmul(HipEnv *env, const float *const *vals, HipVariable *b, HipVariable *c, gcnhip_feat *sp,
                     int m, int n, int p, float fused_dropout, uint64_t nnz_offset);
     void forward(bool) override;
@@ -91,7 +92,7 @@ public:
     const uint32_t *const *bwd_row_bits = nullptr;
     // rows of `out` that the consumer reads in forward() (bit = 1); the others are not computed.  NULL: all rows.
     // The last aggregation sets it: loss and accuracy read only rows of the scored split (module.cpp:131-133).
-    const uint32_t *const *fwd_out_row_bits = nullptr;
+    gcnhip_rowset *const *fwd_out_rows = nullptr;              // a subset registered on `graph` (gcnhip_graph_add_rowset)
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
     ~HipGraphSum() override;

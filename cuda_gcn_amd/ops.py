@@ -124,6 +124,19 @@ class Device:
                                                        ib.ptr if ib else None, ob.ptr if ob else None), "gcnhip_graphsum_masked")
         return out.download()[:, :dim]
 
+    def graphsum_rowset(self, g: "Graph", rows_handle, x, ld_in=None, ld_out=None, row_nonzero=None, fill=np.nan):
+        """gcnhip_graphsum_rowset: only the rows of a subset registered with Graph.add_rowset are computed"""
+        x = np.asarray(x, np.float32)
+        dim = x.shape[1]
+        ld_in, ld_out = ld_in or dim, ld_out or dim
+        xin = self.padded(x, ld_in)
+        out = self.buf(np.full((g.n_rows, ld_out), fill, np.float32))
+        g.reserve(dim)
+        ib = self._bits(row_nonzero) if row_nonzero is not None else None
+        _ck(self.lib, self.lib.gcnhip_graphsum_rowset(self.ctx, g.h, rows_handle, xin.ptr, ld_in, out.ptr, ld_out, dim,
+                                                       ib.ptr if ib else None), "gcnhip_graphsum_rowset")
+        return out.download()[:, :dim]
+
     def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None, row_nonzero=None):
         x = np.asarray(x, np.float32)
         dim = x.shape[1]
@@ -151,13 +164,14 @@ class Device:
         _ck(self.lib, self.lib.gcnhip_f32_to_bf16(self.ctx, xb.ptr, dim, dst.ptr, ld_dst, rows, dim), "gcnhip_f32_to_bf16")
         return dst.download()
 
-    def graphsum_bf16(self, g: "Graph", table_u16, dim, ld_out=None, row_nonzero=None, relu_dropout=None, out_rows=None):
-        """GraphSum over a bf16 table (uint16 [n_cols, ld]); relu_dropout = dict(training, p, seed, epoch, elem_offset, keep_mask)"""
+    def graphsum_bf16(self, g: "Graph", table_u16, dim, ld_out=None, row_nonzero=None, relu_dropout=None, out_rows=None, fill=np.nan):
+        """GraphSum over a bf16 table (uint16 [n_cols, ld]); relu_dropout = dict(training, p, seed, epoch, elem_offset, keep_mask);
+        out_rows: a handle from Graph.add_rowset (only those rows are computed, the others keep `fill`)"""
         t = np.ascontiguousarray(table_u16, np.uint16)
         ld_in = t.shape[1]
         ld_out = ld_out or dim
         tb = self.buf(t)
-        out = self.buf(np.full((g.n_rows, ld_out), np.nan, np.float32))
+        out = self.buf(np.full((g.n_rows, ld_out), fill, np.float32))
         bb = None
         if row_nonzero is not None:
             bits = np.packbits(np.asarray(row_nonzero, bool), bitorder="little")
@@ -167,9 +181,8 @@ class Device:
         g.reserve(dim)
         ep = self.buf(np.array([rd.get("epoch", 0)], np.uint32))
         km = self.buf(np.ascontiguousarray(rd["keep_mask"], np.uint8)) if rd.get("keep_mask") is not None else None
-        ob = self._bits(out_rows) if out_rows is not None else None
         _ck(self.lib, self.lib.gcnhip_graphsum_bf16(self.ctx, g.h, tb.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr if bb else None,
-                                                     ob.ptr if ob else None,
+                                                     out_rows,
                                                      1 if relu_dropout is not None else 0, int(rd.get("training", 0)), float(rd.get("p", 0.0)),
                                                      int(rd.get("seed", 0)), ep.ptr, int(rd.get("elem_offset", 0)), km.ptr if km else None),
             "gcnhip_graphsum_bf16")
@@ -201,6 +214,16 @@ class Device:
         vptr = vb.ptr if vb else f.values_ptr
         _ck(self.lib, self.lib.gcnhip_spmm_fwd(self.ctx, f.h, vptr, wb.ptr, ld_w, out.ptr, ld_out, p, p_drop, seed, ep.ptr,
                                                 nnz_offset, km.ptr if km else None), "gcnhip_spmm_fwd")
+        return out.download()[:, :p]
+
+    def spmm_fwd_relu(self, f: "Feat", w, ld_w=None, ld_out=None):
+        """ReLU(X . w) through gcnhip_spmm_fwd_relu (the evaluation form on an aggregated feature object)"""
+        w = np.asarray(w, np.float32)
+        p = w.shape[1]
+        ld_w, ld_out = ld_w or p, ld_out or p
+        wb = self.padded(w, ld_w)
+        out = self.buf(np.full((f.n_rows, ld_out), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_spmm_fwd_relu(self.ctx, f.h, f.values_ptr, wb.ptr, ld_w, out.ptr, ld_out, p), "gcnhip_spmm_fwd_relu")
         return out.download()[:, :p]
 
     def spmm_bwd(self, f: "Feat", dout, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, keep_mask=None, vals=None, ld_dout=None, ld_dw=None):
@@ -380,6 +403,14 @@ class Graph:
         _ck(self.dev.lib, self.dev.lib.gcnhip_graph_set_schedule(self.dev.ctx, self.h, mode, rg.ctypes.data if rg is not None else None,
                                                                   n_groups), "gcnhip_graph_set_schedule")
 
+    def add_rowset(self, wanted):
+        """register a subset of the rows (boolean per row); returns the handle gcnhip_graphsum_rowset takes"""
+        bits = np.packbits(np.asarray(wanted, bool), bitorder="little")
+        bits = np.concatenate([bits, np.zeros((-bits.size) % 4 + 8, np.uint8)]).view(np.uint32)
+        h = C.c_void_p()
+        _ck(self.dev.lib, self.dev.lib.gcnhip_graph_add_rowset(self.dev.ctx, self.h, bits.ctypes.data, C.byref(h)), "gcnhip_graph_add_rowset")
+        return h
+
     def reserve(self, dim):
         """segment scratch for aggregations up to `dim` columns (256 are reserved when the object is built)"""
         if dim > 256:
@@ -400,6 +431,24 @@ class Graph:
 
 
 class Feat:
+    @classmethod
+    def aggregated(cls, dev: Device, g: "Graph", x: "Feat"):
+        """the feature object of A^.X (gcnhip_feat_create_aggregated)"""
+        self = cls.__new__(cls)
+        self.dev = dev
+        self.n_rows, self.n_cols = g.n_rows, x.n_cols
+        h = C.c_void_p()
+        _ck(dev.lib, dev.lib.gcnhip_feat_create_aggregated(dev.ctx, C.byref(h), g.h, x.h), "gcnhip_feat_create_aggregated")
+        self.h = h
+        self.values_ptr = dev.lib.gcnhip_feat_values(h)
+        self.dense = True
+        return self
+
+    def values(self):
+        out = np.empty((self.n_rows, self.n_cols), np.float32)
+        _ck(self.dev.lib, self.dev.lib.gcnhip_d2h(self.dev.ctx, out.ctypes.data, self.values_ptr, out.nbytes), "d2h")
+        return out
+
     def __init__(self, dev: Device, indptr, indices, values, n_cols):
         self.dev = dev
         indptr = np.ascontiguousarray(indptr, np.int32)

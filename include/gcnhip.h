@@ -43,7 +43,8 @@ extern "C" {
 #endif
 
 typedef struct gcnhip_ctx gcnhip_ctx;       /* device + stream + scratch */
-typedef struct gcnhip_graph gcnhip_graph;   /* prepared adjacency (CUDASparseIndex of the graph) */
+typedef struct gcnhip_graph gcnhip_graph;
+typedef struct gcnhip_rowset gcnhip_rowset;   /* a registered subset of an adjacency object's rows */   /* prepared adjacency (CUDASparseIndex of the graph) */
 typedef struct gcnhip_feat gcnhip_feat;     /* prepared feature matrix (CUDASparseIndex of X + its values) */
 
 /* ---- context / runtime (replaces the implicit null stream + CUDA_CHECK) ---- */
@@ -124,6 +125,15 @@ int gcnhip_graphsum_rowmask(gcnhip_ctx *ctx, const gcnhip_graph *g, const float 
  * forward.  Every computed row is bit-identical to gcnhip_graphsum's.  Either mask may be NULL. */
 int gcnhip_graphsum_masked(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int ld_in,
                            float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits);
+/* The same for a subset that is known in advance (the three splits of a dataset): gcnhip_graph_add_rowset cuts a
+ * compacted task list for the rows with bit r set in h_row_bits (host, n_rows bits) out of the object's row schedule
+ * — no wave is launched for a row outside it (the device mask above launches every wave and retires the unwanted ones:
+ * at 10 % wanted rows that is 4x slower than the compacted list).  The subset belongs to the object: it follows
+ * gcnhip_graph_set_schedule and is freed by gcnhip_graph_destroy.  Results as gcnhip_graphsum_masked. */
+int gcnhip_graph_add_rowset(gcnhip_ctx *ctx, gcnhip_graph *g, const uint32_t *h_row_bits, gcnhip_rowset **rows);
+int gcnhip_rowset_size(const gcnhip_rowset *rows, int *n_tasks);
+int gcnhip_graphsum_rowset(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_rowset *rows, const float *in, int ld_in,
+                           float *out, int ld_out, int dim, const uint32_t *in_row_bits);
 /* Fused epilogue used by the first layer: GraphSum, then ReLU
  * (module.cpp:175-185), then Dropout (module.cpp:207-221) on the same rows.
  * training == 0: ReLU only.  The dropout decision for element (r, c) is
@@ -143,6 +153,13 @@ int gcnhip_graphsum_relu_dropout(gcnhip_ctx *ctx, const gcnhip_graph *g, const f
  * scatter of cuda_kernel.cu:112-122. */
 int gcnhip_feat_create(gcnhip_ctx *ctx, gcnhip_feat **f, const int *h_indptr, const int *h_indices,
                        const float *h_values, int n_rows, int n_cols);
+/* Aggregate-first evaluation.  Without dropout the first layer is linear in X: ReLU(A^.(X.W1)) = ReLU((A^.X).W1)
+ * (src/seq/gcn.cpp:23-41 with Dropout skipped, module.cpp:208), and A^.X does not change from epoch to epoch.
+ * This builds the feature object of A^.X once (dense X only; x has g->n_cols rows — every column of g); an
+ * evaluation forward then runs gcnhip_spmm_fwd_relu on it and needs NO hidden-width aggregation (and, with
+ * several GPUs, no exchange before the hidden layer).  Same result up to the rounding of a reassociated f32 sum.
+ * Training cannot use it: its X~ changes with every epoch's dropout decisions. */
+int gcnhip_feat_create_aggregated(gcnhip_ctx *ctx, gcnhip_feat **f, gcnhip_graph *g, const gcnhip_feat *x);
 int gcnhip_feat_destroy(gcnhip_ctx *ctx, gcnhip_feat *f);
 int gcnhip_feat_is_dense(const gcnhip_feat *f);
 float *gcnhip_feat_values(gcnhip_feat *f);              /* device pointer, nnz floats (pristine X) */
@@ -163,6 +180,9 @@ int64_t gcnhip_feat_nnz(const gcnhip_feat *f);
 int gcnhip_spmm_fwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
                     float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
                     uint64_t nnz_offset, const uint8_t *keep_mask);
+/* forward without dropout, ReLU (module.cpp:175-185, keep = x > 0) applied when the result is stored */
+int gcnhip_spmm_fwd_relu(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
+                         float *out, int ld_out, int p);
 int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
                     float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
                     uint64_t nnz_offset, const uint8_t *keep_mask);
@@ -173,11 +193,11 @@ int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, co
  * GraphSum reading that table: coef, the running sum and `out` are f32, so the ONLY difference to
  * gcnhip_graphsum* is the rounding of the gathered values — on a table that holds bf16-representable numbers
  * the two agree bit for bit.  A row of d values is 2d bytes: half the cache lines per edge.
- * in_row_bits / out_row_bits (optional) as in gcnhip_graphsum_masked; relu_dropout != 0 selects the fused epilogue of
+ * in_row_bits (optional) as in gcnhip_graphsum_rowmask, out_rows (optional) as in gcnhip_graphsum_rowset; relu_dropout != 0 selects the fused epilogue of
  * gcnhip_graphsum_relu_dropout with the arguments that follow. */
 int gcnhip_f32_to_bf16(gcnhip_ctx *ctx, const float *src, int ld_src, uint16_t *dst, int ld_dst, int64_t rows, int dim);
 int gcnhip_graphsum_bf16(gcnhip_ctx *ctx, const gcnhip_graph *g, const uint16_t *in_bf16, int ld_in,
-                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, const uint32_t *out_row_bits,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, const gcnhip_rowset *out_rows,
                          int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask);
 

@@ -43,6 +43,8 @@ enum {
     GCNHOST_BF16_TABLES = 2048,   /* opt-in, beyond the reference: the aggregation gathers bfloat16 copies of H0, Z0, dZ, dH1 (f32 sums) */
     GCNHOST_ALL_ROWS = 4096,      /* compute every row of the logits (default: the last aggregation computes only the rows of the
                                      scored split — all that loss and accuracy read; env HIPGCN_ALL_ROWS=1 does the same) */
+    GCNHOST_NO_AGG_FIRST_EVAL = 8192, /* evaluation forwards keep the reference's order A^.(X.W1); default for a dense X: (A^.X).W1 with
+                                         A^.X built once (no hidden-width aggregation in eval; env HIPGCN_NO_AGG_FIRST_EVAL=1 does the same) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 

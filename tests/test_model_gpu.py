@@ -272,6 +272,28 @@ def test_scored_rows_only_is_bit_identical_to_all_rows(name, hidden):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,hidden", [("reddit-mini", 128), ("rmat-10-32", 16)])
+def test_aggregate_first_eval_matches_reference_order(name, hidden):
+    """dense X: evaluation forwards run ReLU((A^.X).W1) with A^.X built once; the reference's order
+    ReLU(A^.(X.W1)) (NO_AGG_FIRST_EVAL) gives the same losses to rounding and the same training (training never
+    uses the aggregated features)"""
+    from cuda_gcn_amd.model import HipGCNModel, NO_AGG_FIRST_EVAL
+    ds = datagen.make_dataset(name)
+    a = HipGCNModel(ds, seed=8, flags=NO_AGG_FIRST_EVAL, hidden_dim=hidden, dropout=0.5, epochs=12)
+    b = HipGCNModel(ds, seed=8, hidden_dim=hidden, dropout=0.5, epochs=12)
+    ta, tb = a.run_epochs(10), b.run_epochs(10)
+    assert np.array_equal(ta[:, :2].view(np.uint32), tb[:, :2].view(np.uint32))       # training: bit-identical
+    assert np.abs(ta[:, 2] - tb[:, 2]).max() <= 2e-5                                   # validation loss
+    for s in (1, 2, 3):
+        n_s = int((ds["split"] == s).sum())
+        la, lb = a.eval(s), b.eval(s)
+        assert abs(la[0] - lb[0]) <= 2e-5 and abs(la[1] - lb[1]) <= 1.0 / n_s + 1e-7, (s, la, lb)
+    ha, hb = a.var(3), b.var(3)                                                        # H1 of the last evaluation
+    assert np.allclose(ha, hb, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(ha).max())))
+    assert np.array_equal(a.var(2), b.var(2))
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""

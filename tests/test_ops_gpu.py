@@ -125,7 +125,57 @@ def test_graphsum_output_row_mask(dev, gname, dim, ld):
         both = dev.graphsum_masked(g, xm, ld_in=ld, ld_out=ld, row_nonzero=zero_rows, out_rows=want_rows, fill=-7.0)
         ref = dev.graphsum(g, xm, ld_in=ld, ld_out=ld, row_nonzero=zero_rows)
         assert np.array_equal(both[want_rows], ref[want_rows]) and np.all(both[~want_rows] == -7.0)
+        # the prepared form of the same thing: a registered row subset with its own compacted task list,
+        # which follows the object's row schedule
+        rs = g.add_rowset(want_rows)
+        for sched in range(3):
+            if sched == 1:
+                g.set_schedule(1, (np.arange(n) % 5).astype(np.int32))
+            elif sched == 2:
+                g.set_schedule(2, None, 16)
+            got = dev.graphsum_rowset(g, rs, x, ld_in=ld, ld_out=ld, fill=55.0)
+            assert np.array_equal(got[want_rows], full[want_rows]) and np.all(got[~want_rows] == 55.0), sched
+            both = dev.graphsum_rowset(g, rs, xm, ld_in=ld, ld_out=ld, row_nonzero=zero_rows, fill=-7.0)
+            assert np.array_equal(both[want_rows], ref[want_rows]) and np.all(both[~want_rows] == -7.0)
+        if dim % 8 == 0 or dim == 41:
+            tab = dev.to_bf16(x, ld_dst=(dim + 7) // 8 * 8)
+            fb = dev.graphsum_bf16(g, tab, dim)
+            gb = dev.graphsum_bf16(g, tab, dim, out_rows=rs, fill=9.0)
+            assert np.array_equal(gb[want_rows], fb[want_rows]) and np.all(gb[~want_rows] == 9.0)
+        g.set_schedule(0)
+    empty = g.add_rowset(np.zeros(n, bool))              # nothing wanted: nothing launched, nothing written
+    assert np.all(dev.graphsum_rowset(g, empty, x, ld_in=ld, ld_out=ld, fill=1.5) == 1.5)
     g.free()
+
+
+@pytest.mark.parametrize("n,F,p", [(1000, 602, 128), (700, 64, 16), (513, 100, 41)])
+def test_aggregate_first_evaluation_form(dev, oracle, n, F, p):
+    """gcnhip_feat_create_aggregated + gcnhip_spmm_fwd_relu: ReLU((A^.X).W) against the reference's order
+    ReLU(A^.(X.W)) from the oracle (SparseMatmul, GraphSum, ReLU: module.cpp:47-61,83-101,175-185) — the same
+    real number per element, two f32 summation orders."""
+    from cuda_gcn_amd.ops import Feat
+    rng = np.random.default_rng(n + p)
+    lo, hi = datagen._sample_edges(rng, n, 6 * n)
+    gp, gi = datagen.csr_with_self_loops(lo, hi, n)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    w = (rng.standard_normal((F, p)) / np.sqrt(F)).astype(np.float32)
+    fp = (np.arange(n + 1, dtype=np.int64) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), n)
+    g = dev.graph(gp, gi)
+    fx = dev.feat(fp, fi, x.reshape(-1), F)
+    assert fx.dense
+    fa = Feat.aggregated(dev, g, fx)
+    ax = fa.values()
+    close_mag(ax, oracle.graphsum(gp, gi, x, F), oracle.graphsum(gp, gi, np.abs(x), F))     # A^.X itself
+    got = dev.spmm_fwd_relu(fa, w)
+    h0 = oracle.spmm_fwd(fp, fi, x.reshape(-1), w, p)
+    pre = oracle.graphsum(gp, gi, h0, p)
+    want = np.maximum(pre, 0)
+    mag = oracle.graphsum(gp, gi, oracle.spmm_fwd(fp, fi, np.abs(x).reshape(-1), np.abs(w), p), p)
+    assert np.all(got >= 0) and np.all(np.isfinite(got))
+    viol = np.abs(got.astype(np.float64) - want) - 16 * EPS * mag
+    assert viol.max() <= 0, viol.max()
+    fa.free(); fx.free(); g.free()
 
 
 def test_edge_coef_bit_exact(dev):
