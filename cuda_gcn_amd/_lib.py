@@ -107,6 +107,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_f32_to_bf16": (I, [P, P, I, P, I, I64, I]),
     "gcnhip_graphsum_bf16": (I, [P, P, P, I, P, I, I, P, P, I, I, F, U64, P, U64, P]),
     "gcnhip_matmul_bwd_da_bits": (I, [P, P, I, P, I, P, I, I, I, I, P, I, F]),
+    "gcnhip_gather_rows": (I, [P, P, I, P, I, P]),
     "gcnhip_relu_fwd": (I, [P, P, P, I64, I]),
     "gcnhip_relu_bwd": (I, [P, P, P, I64]),
     "gcnhip_dropout_fwd": (I, [P, P, P, I64, F, U64, P, U64, P]),
@@ -178,6 +179,12 @@ GCNHOST_SYMBOLS = {
     "gcnhost_rccl_selftest_world": (I, [I, I, I, C.c_char_p]),
     "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
     "gcnhost_local_graph": (I, [P, P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
+    "gcnhost_plan_create": (I, [PP, P, P, I, I, I, I]),
+    "gcnhost_plan_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double),
+                              C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)]),
+    "gcnhost_plan_arrays": (I, [P, PP, PP, PP, PP, PP, PP, PP, PP]),
+    "gcnhost_plan_free": (I, [P]),
+    "gcnhost_model_exchange": (I, [P, C.POINTER(I), C.POINTER(I64), C.POINTER(I64), C.POINTER(I), C.POINTER(C.c_double)]),
     "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
     "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),
     "gcnhost_rmat_graph": (I, [I, I, U64, PP, PP, C.POINTER(I64)]),

@@ -65,6 +65,24 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(float *g, int ldg
     }
 }
 
+// ------------------------------------------------------------ row packing
+// dst[i, 0:ld] = src[rows[i], 0:ld]: the send side of a halo exchange (rows a peer needs, packed contiguously).
+// Words are moved, not interpreted (f32 rows, bf16 rows and mask words alike).
+template <int V>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__restrict__ src, int ld, const int *__restrict__ rows,
+                                                          int64_t total /* n * ld / V */, uint32_t *__restrict__ dst) {
+    const int per_row = ld / V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row) * V;
+        const uint32_t *s = src + (int64_t)rows[r] * ld + c;
+        uint32_t *d = dst + r * ld + c;
+        if (V == 4) *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s);
+        else *d = *s;
+    }
+}
+
 // -------------------------------------------------------------- set_truth
 // src/seq/gcn.cpp:78-81, src/cuda/cuda_kernel.cu:283-288
 __global__ __launch_bounds__(256) void set_truth_kernel(int32_t *truth, const int32_t *split, const int32_t *label, int n, int s) {
@@ -240,6 +258,16 @@ int gcnhip_pack_positive(gcnhip_ctx *c, const float *h, int ld, int n_rows, int 
     if (!c || !h || !bits || ld < dim || dim <= 0 || words_per_row * 32 < dim) return -1;
     if (n_rows <= 0) return 0;
     pack_positive_kernel<<<ceil_div(n_rows, 4), 256, 0, c->stream>>>(h, ld, n_rows, dim, bits, words_per_row);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_gather_rows(gcnhip_ctx *c, const float *src, int ld_words, const int *d_rows, int n, float *dst) {
+    if (!c || !src || !dst || ld_words <= 0 || n < 0 || (n > 0 && !d_rows)) return -1;
+    if (n == 0) return 0;
+    const bool v4 = ld_words % 4 == 0 && aligned16(src) && aligned16(dst);
+    const int64_t total = (int64_t)n * ld_words / (v4 ? 4 : 1);
+    if (v4) gather_rows_kernel<4><<<stream_grid(total, 1024), 256, 0, c->stream>>>((const uint32_t *)src, ld_words, d_rows, total, (uint32_t *)dst);
+    else gather_rows_kernel<1><<<stream_grid(total, 1024), 256, 0, c->stream>>>((const uint32_t *)src, ld_words, d_rows, total, (uint32_t *)dst);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

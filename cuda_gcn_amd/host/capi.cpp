@@ -90,6 +90,16 @@ int gcnhost_model_run_epochs(gcnhost_model *m, int n, float *trace) { API_TRY({ 
 int gcnhost_model_run(gcnhost_model *m) { API_TRY({ m->gcn->run(); }) }
 int gcnhost_model_sync(gcnhost_model *m) { API_TRY({ m->gcn->sync(); }) }
 
+int gcnhost_model_exchange(gcnhost_model *m, int *halo, int64_t *recv_rows, int64_t *send_rows, int *table_rows, double *halo_share) {
+    API_TRY({
+        const ExchangePlan &x = m->gcn->exchange_plan();
+        if (halo) *halo = x.halo ? 1 : 0;
+        if (recv_rows) *recv_rows = x.world > 1 ? x.recv_total() : 0;
+        if (send_rows) *send_rows = x.world > 1 ? x.send_total() : 0;
+        if (table_rows) *table_rows = x.table_rows;
+        if (halo_share) *halo_share = x.halo_share;
+    })
+}
 int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges) {
     API_TRY({
         if (rank) *rank = m->gcn->rank();
@@ -244,6 +254,50 @@ int gcnhost_local_graph(const int *g_indptr, const int *g_indices, int n_rows, i
     if (col_deg) memcpy(col_deg, lg.col_deg.data(), lg.col_deg.size() * sizeof(int));
     return 0;
 }
+struct gcnhost_plan {
+    RowPartition part;
+    ExchangePlan plan;
+    LocalGraph graph;
+};
+int gcnhost_plan_create(gcnhost_plan **out, const int *g_indptr, const int *g_indices, int n_rows, int world, int rank, int mode) {
+    if (!out || !g_indptr || !g_indices || world < 1 || rank < 0 || rank >= world || mode < 0 || mode > 2) return -1;
+    API_TRY({
+        gcnhost_plan *p = new gcnhost_plan();
+        p->part = make_partition(g_indptr, n_rows, world);
+        p->plan = make_exchange_plan(g_indptr, g_indices, n_rows, p->part, rank, mode);
+        p->graph = build_table_graph(g_indptr, g_indices, n_rows, p->part, p->plan);
+        *out = p;
+    })
+}
+int gcnhost_plan_info(const gcnhost_plan *p, int *halo, int *n_local, int *table_rows, int *own_offset, int *rows_max,
+                      double *halo_share, int64_t *nnz_local, int64_t *n_recv, int64_t *n_send) {
+    if (!p) return -1;
+    if (halo) *halo = p->plan.halo ? 1 : 0;
+    if (n_local) *n_local = p->plan.n_local;
+    if (table_rows) *table_rows = p->plan.table_rows;
+    if (own_offset) *own_offset = p->plan.own_offset;
+    if (rows_max) *rows_max = p->plan.rows_max;
+    if (halo_share) *halo_share = p->plan.halo_share;
+    if (nnz_local) *nnz_local = (int64_t)p->graph.indices.size();
+    if (n_recv) *n_recv = (int64_t)p->plan.recv_rows.size();
+    if (n_send) *n_send = (int64_t)p->plan.send_rows.size();
+    return 0;
+}
+int gcnhost_plan_arrays(const gcnhost_plan *p, const int **recv_off, const int **recv_rows, const int **send_off, const int **send_rows,
+                        const int **table_global, const int **indptr, const int **indices, const int **col_deg) {
+    if (!p) return -1;
+    if (recv_off) *recv_off = p->plan.recv_off.data();
+    if (recv_rows) *recv_rows = p->plan.recv_rows.data();
+    if (send_off) *send_off = p->plan.send_off.data();
+    if (send_rows) *send_rows = p->plan.send_rows.data();
+    if (table_global) *table_global = p->plan.table_global.data();
+    if (indptr) *indptr = p->graph.indptr.data();
+    if (indices) *indices = p->graph.indices.data();
+    if (col_deg) *col_deg = p->graph.col_deg.data();
+    return 0;
+}
+int gcnhost_plan_free(gcnhost_plan *p) { delete p; return 0; }
+
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws) {
     HostRng rng;
     rng.seed_time((unsigned)seed);

@@ -25,6 +25,25 @@ int rccl_get_unique_id(char id[GCN_NCCL_ID_BYTES]) {
     return 0;
 }
 
+void exchange_buffers_create(gcnhip_ctx *ctx, const ExchangePlan &plan, int max_ld_words, ExchangeBuffers *out) {
+    out->ctx = ctx;
+    out->max_ld_words = (size_t)max_ld_words;
+    if (!plan.halo) return;
+    void *p;
+    const size_t n = plan.send_rows.size();
+    GCNHIP_CHECK(gcnhip_malloc(ctx, &p, (n ? n : 1) * sizeof(int)));
+    out->d_send_rows = (int *)p;
+    if (n) GCNHIP_CHECK(gcnhip_h2d(ctx, p, plan.send_rows.data(), n * sizeof(int)));
+    GCNHIP_CHECK(gcnhip_malloc(ctx, &p, (n ? n : 1) * (size_t)max_ld_words * sizeof(float)));
+    out->d_send_buf = (float *)p;
+}
+void exchange_buffers_destroy(ExchangeBuffers *b) {
+    if (!b || !b->ctx) return;
+    gcnhip_free(b->ctx, b->d_send_rows);
+    gcnhip_free(b->ctx, b->d_send_buf);
+    *b = ExchangeBuffers();
+}
+
 namespace {
 
 // Two communicators of one process (training lane + validation lane) must never have collectives in
@@ -81,6 +100,23 @@ struct RcclComm : Comm {
         NCCL_CHECK(ncclAllGather(base + block * r, base, block, ncclFloat, comm, (hipStream_t)gcnhip_ctx_stream(ctx)));
         leave();
     }
+    void exchange_rows(const ExchangePlan &plan, ExchangeBuffers &bufs, float *table, int ld) override {
+        if (!plan.halo) { allgather_rows(table, (size_t)plan.rows_max * ld); return; }
+        if ((size_t)ld > bufs.max_ld_words) throw GcnHipFailure(-1, "exchange_rows: row wider than the packing buffer");
+        // pack: one gather kernel for all peers (send_rows is grouped by destination)
+        GCNHIP_CHECK(gcnhip_gather_rows(ctx, table + (size_t)plan.own_offset * ld, ld, bufs.d_send_rows, (int)plan.send_rows.size(), bufs.d_send_buf));
+        enter();
+        hipStream_t st = (hipStream_t)gcnhip_ctx_stream(ctx);
+        NCCL_CHECK(ncclGroupStart());
+        for (int q = 0; q < w; q++) {
+            if (q == r) continue;
+            const size_t ns = (size_t)(plan.send_off[q + 1] - plan.send_off[q]) * ld, nr = (size_t)(plan.recv_off[q + 1] - plan.recv_off[q]) * ld;
+            if (ns) NCCL_CHECK(ncclSend(bufs.d_send_buf + (size_t)plan.send_off[q] * ld, ns, ncclFloat, q, comm, st));
+            if (nr) NCCL_CHECK(ncclRecv(table + ((size_t)plan.n_local + plan.recv_off[q]) * ld, nr, ncclFloat, q, comm, st));
+        }
+        NCCL_CHECK(ncclGroupEnd());
+        leave();
+    }
     void allreduce_sum(float *buf, size_t n) override {
         enter();
         NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, comm, (hipStream_t)gcnhip_ctx_stream(ctx)));
@@ -114,6 +150,23 @@ struct HostComm : Comm {
         GCNHIP_CHECK(gcnhip_d2h(ctx, stage.data() + block * r, base + block * r, block * sizeof(float)));
         ag(user, stage.data(), block);
         GCNHIP_CHECK(gcnhip_h2d(ctx, base, stage.data(), block * w * sizeof(float)));
+    }
+    // HALO through a host-staged all-gather of whole (padded) blocks: every rank's block reaches the host, the rows
+    // of the plan's peer segments are picked from it.  Same table as the point-to-point exchange, so the layout,
+    // the column remap and everything downstream of it are what the tests exercise.
+    void exchange_rows(const ExchangePlan &plan, ExchangeBuffers &, float *table, int ld) override {
+        if (!plan.halo) { allgather_rows(table, (size_t)plan.rows_max * ld); return; }
+        const size_t block = (size_t)plan.rows_max * ld;
+        stage.assign(block * w, 0.f);
+        if (plan.n_local)
+            GCNHIP_CHECK(gcnhip_d2h(ctx, stage.data() + block * r, table + (size_t)plan.own_offset * ld, (size_t)plan.n_local * ld * sizeof(float)));
+        ag(user, stage.data(), block);
+        std::vector<float> halo(plan.recv_rows.size() * (size_t)ld);
+        for (int q = 0; q < w; q++)
+            for (int k = plan.recv_off[q]; k < plan.recv_off[q + 1]; k++)
+                memcpy(&halo[(size_t)k * ld], &stage[block * q + (size_t)plan.recv_rows[k] * ld], (size_t)ld * sizeof(float));
+        if (!halo.empty())
+            GCNHIP_CHECK(gcnhip_h2d(ctx, table + (size_t)plan.n_local * ld, halo.data(), halo.size() * sizeof(float)));
     }
     void allreduce_sum(float *buf, size_t n) override {
         stage.resize(n);

@@ -8,12 +8,28 @@
 #pragma once
 #include <cstddef>
 #include "gcnhip.h"
+#include "partition.h"
+
+// device-side companions of an ExchangePlan for ONE context / stream (each lane has its own, so the lanes'
+// exchanges never share a send buffer): the send lists and a packing buffer.  Empty for ALLGATHER plans.
+struct ExchangeBuffers {
+    gcnhip_ctx *ctx = nullptr;
+    int *d_send_rows = nullptr;
+    float *d_send_buf = nullptr;      // [send_total x max_ld_words]
+    size_t max_ld_words = 0;
+};
+void exchange_buffers_create(gcnhip_ctx *ctx, const ExchangePlan &plan, int max_ld_words, ExchangeBuffers *out);
+void exchange_buffers_destroy(ExchangeBuffers *b);
 
 struct Comm {
     virtual ~Comm() {}
     virtual int rank() const = 0;
     virtual int size() const = 0;
     virtual void allgather_rows(float *base, size_t block_elems) = 0;
+    // Complete a gathered table [plan.table_rows x ld_words 4-byte words] whose own block (plan.own_offset ..
+    // + n_local) this rank has just written: ALLGATHER plans -> allgather_rows; HALO plans -> pack the rows each
+    // peer needs, exchange point to point, receive straight into the peer segments.  Bytes are moved, not interpreted.
+    virtual void exchange_rows(const ExchangePlan &plan, ExchangeBuffers &bufs, float *table, int ld_words) = 0;
     virtual void allreduce_sum(float *buf, size_t n) = 0;
     virtual void allreduce_sum_host(double *vals, int n) = 0;   // init-time scalars (synchronises)
     // a second communicator over the same ranks whose collectives run on another context's stream
@@ -26,6 +42,7 @@ struct SelfComm : Comm {
     int rank() const override { return 0; }
     int size() const override { return 1; }
     void allgather_rows(float *, size_t) override {}
+    void exchange_rows(const ExchangePlan &, ExchangeBuffers &, float *, int) override {}
     void allreduce_sum(float *, size_t) override {}
     void allreduce_sum_host(double *, int) override {}
     Comm *clone_for(gcnhip_ctx *) override { return new SelfComm(); }
@@ -40,6 +57,7 @@ struct NullComm : Comm {
     int rank() const override { return r; }
     int size() const override { return w; }
     void allgather_rows(float *, size_t) override {}
+    void exchange_rows(const ExchangePlan &, ExchangeBuffers &, float *, int) override {}
     void allreduce_sum(float *, size_t) override {}
     void allreduce_sum_host(double *, int) override {}
     Comm *clone_for(gcnhip_ctx *) override { return new NullComm(r, w); }

@@ -93,8 +93,15 @@ void HipGCN::init(const HipGCNOptions &opt) {
     n_local = r1 - r0;
     nnzA_local = (long)gp[r1] - gp[r0];
     labels_assortative = !(flags & HIPGCN_NO_ROW_GROUPS) && labels_are_assortative(*data, N, C);
+    {
+        int mode = (flags & HIPGCN_EXCHANGE_HALO) ? 2 : ((flags & HIPGCN_EXCHANGE_ALLGATHER) ? 1 : 0);
+        if (const char *e = getenv("HIPGCN_EXCHANGE")) mode = !strcmp(e, "halo") ? 2 : (!strcmp(e, "allgather") ? 1 : mode);
+        xplan = make_exchange_plan(gp.data(), gi.data(), N, part, rank, mode);
+        env.plan = &xplan;
+        env.xbuf = &xbuf;
+    }
     if (world > 1) {
-        const LocalGraph lg = build_local_graph(gp.data(), gi.data(), N, part, rank);
+        const LocalGraph lg = build_table_graph(gp.data(), gi.data(), N, part, xplan);
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
         GCNHIP_CHECK(gcnhip_graph_reserve_width(env.ctx, graph, std::max(params.hidden_dim, params.output_dim)));
     } else {
@@ -112,7 +119,8 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // Replicating X.W1 trades a 119 MB all-gather per forward for 0.4 ms of extra GEMM on every rank.  With 2-4
     // GPUs each rank receives over 1-3 xGMI links (~60 GB/s each) and the GEMM is cheaper; with 8 GPUs seven
     // links feed the gather (~0.3 ms) while the replicated GEMMs would be 45 % of the per-rank compute.
-    replicate_l1 = world > 1 && (world <= 4 || (flags & HIPGCN_REPLICATE_L1)) && !(flags & (HIPGCN_NO_REPLICATE_L1 | HIPGCN_MODULAR));
+    // (ALLGATHER plans only: a HALO plan moves few rows, and its table is not in global row order)
+    replicate_l1 = world > 1 && !xplan.halo && (world <= 4 || (flags & HIPGCN_REPLICATE_L1)) && !(flags & (HIPGCN_NO_REPLICATE_L1 | HIPGCN_MODULAR));
     if (replicate_l1) {
         GCNHIP_CHECK(gcnhip_feat_create(env.ctx, &feat_full, fp.data(), fi.empty() ? nullptr : fi.data(),
                                         data->feature_value.data(), N, F));
@@ -148,12 +156,14 @@ void HipGCN::init(const HipGCNOptions &opt) {
     if (getenv("HIPGCN_ALL_ROWS")) flags |= HIPGCN_ALL_ROWS;
     if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(env.ctx, graph, split_rows);
 
-    // training-split bit per padded node position: dZ is zero elsewhere, GraphSum's backward skips those rows
+    // training-split bit per table row (= node, on one GPU): dZ is zero elsewhere, GraphSum's backward skips those rows
     {
-        const size_t n_pos = world > 1 ? (size_t)world * part.rows_max : (size_t)N;
+        const size_t n_pos = world > 1 ? (size_t)xplan.table_rows : (size_t)N;
         std::vector<uint32_t> bits(n_pos / 32 + 2, 0u);
-        for (int j = 0; j < N; j++)
-            if (data->split[j] == 1) { const size_t pj = world > 1 ? (size_t)part.padded(j) : (size_t)j; bits[pj >> 5] |= 1u << (pj & 31); }
+        for (size_t t = 0; t < n_pos; t++) {
+            const int j = world > 1 ? xplan.table_global[t] : (int)t;
+            if (j >= 0 && data->split[j] == 1) bits[t >> 5] |= 1u << (t & 31);
+        }
         d_train_bits = dev_upload(env.ctx, bits.data(), bits.size());
         bwd_bits = d_train_bits;
     }
@@ -161,7 +171,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // ---- variables (numbering of gcn.cpp:21-54)
     variables.resize(7);
     for (auto &v : variables) v.reset(new HipVariable());
-    const int rm = part.rows_max;
+    const ExchangePlan *xp = world > 1 ? &xplan : nullptr;
     if (flags & HIPGCN_MODULAR) {
         variables[0]->alloc(env.ctx, 1, (int)(f1 - f0), false);
         input = variables[0].get();
@@ -170,11 +180,16 @@ void HipGCN::init(const HipGCNOptions &opt) {
         input_vals = gcnhip_feat_values(feat);
     }
     if (replicate_l1) variables[1]->alloc_replicated(env.ctx, N, n_local, r0, H, true);   // H0: every row computed here
-    else variables[1]->alloc(env.ctx, n_local, H, true, true, false, world, rank, rm);    // H0: data gathered
-    variables[3]->alloc(env.ctx, n_local, H, true, false, true, world, rank, rm);    // H1: grad gathered
+    else variables[1]->alloc(env.ctx, n_local, H, true, true, false, xp);    // H0: data gathered
+    variables[3]->alloc(env.ctx, n_local, H, true, false, true, xp);    // H1: grad gathered
     rebuild_dh1 = world > 1 && !(flags & (HIPGCN_GATHER_DH1 | HIPGCN_MODULAR));
-    variables[4]->alloc(env.ctx, n_local, C, true, true, rebuild_dh1, world, rank, rm);   // Z0: data gathered (+ grad when dH1 is rebuilt)
-    variables[6]->alloc(env.ctx, n_local, C, true, false, true, world, rank, rm);    // Z : grad gathered
+    variables[4]->alloc(env.ctx, n_local, C, true, true, rebuild_dh1, xp);   // Z0: data gathered (+ grad when dH1 is rebuilt)
+    variables[6]->alloc(env.ctx, n_local, C, true, false, true, xp);    // Z : grad gathered
+    if (world > 1) {
+        // widest row (in 4-byte words) an exchange will carry: f32 rows of H / C, mask words, bf16 rows
+        const int ldH = variables[1]->ld, ldC = variables[4]->ld;
+        exchange_buffers_create(env.ctx, xplan, std::max(std::max(ldH, ldC), (H + 63) / 64 * 64), &xbuf);
+    }
     output = variables[6].get();
     HipVariable *W1 = variables[2].get(), *W2 = variables[5].get();
     W1->alloc(env.ctx, F, H, false);
@@ -321,11 +336,11 @@ void HipGCN::build_modules() {
         auto *mm = new HipMatmul(&env, H1, W2, Z0, N, H, C, scale);
         if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = graph_l1; }
         if (rebuild_dh1) {
-            const int world = env.comm->size(), wpr = (H + 31) / 32;
-            d_pos_bits = dev_upload(env.ctx, std::vector<uint32_t>((size_t)world * part.rows_max * wpr, 0u).data(),
-                                    (size_t)world * part.rows_max * wpr);
-            gs->pos_bits_full = d_pos_bits; gs->wpr = wpr; gs->rows_max = part.rows_max; gs->out_grad_complete = true;
-            mm->pos_bits_full = d_pos_bits; mm->wpr = wpr; mm->all_rows = world * part.rows_max;
+            const int wpr = (H + 31) / 32;
+            d_pos_bits = dev_upload(env.ctx, std::vector<uint32_t>((size_t)xplan.table_rows * wpr, 0u).data(),
+                                    (size_t)xplan.table_rows * wpr);
+            gs->pos_bits_full = d_pos_bits; gs->wpr = wpr; gs->out_grad_complete = true;
+            mm->pos_bits_full = d_pos_bits; mm->wpr = wpr; mm->all_rows = xplan.table_rows;
         }
         modules.push_back(sm);
         modules.push_back(gs);
@@ -385,6 +400,9 @@ void HipGCN::build_eval_lane() {
     L.env.timers = L.timers.get();
     L.comm.reset(env.comm->clone_for(L.env.ctx));
     L.env.comm = L.comm.get();
+    L.env.plan = &xplan;
+    L.env.xbuf = &L.xbuf;
+    if (world > 1) exchange_buffers_create(L.env.ctx, xplan, xbuf.max_ld_words, &L.xbuf);
     L.env.seed = env.seed;
     L.env.bf16_tables = env.bf16_tables;
     void *q;
@@ -396,7 +414,7 @@ void HipGCN::build_eval_lane() {
     // same adjacency, own scratch for split rows
     const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
     if (world > 1) {
-        const LocalGraph lg = build_local_graph(gp.data(), gi.data(), params.num_nodes, part, rank);
+        const LocalGraph lg = build_table_graph(gp.data(), gi.data(), params.num_nodes, part, xplan);
         GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
         GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph, std::max(params.hidden_dim, params.output_dim)));
     } else {
@@ -405,7 +423,7 @@ void HipGCN::build_eval_lane() {
     }
     if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(L.env.ctx, L.graph, L.split_rows);
     apply_schedule(L.env.ctx, L.graph);                     // the schedule the training lane measured as fastest
-    const int rm = part.rows_max;
+    const ExchangePlan *xp = world > 1 ? &xplan : nullptr;
     L.H0.reset(new HipVariable()); L.H1.reset(new HipVariable()); L.Z0.reset(new HipVariable()); L.Z.reset(new HipVariable());
     if (feat_agg) {
         // aggregate-first: the lane's hidden layer is one GEMM on A^.X — no H0, no hidden-width aggregation, no exchange
@@ -419,10 +437,10 @@ void HipGCN::build_eval_lane() {
         apply_schedule(L.env.ctx, L.graph_l1);
         L.H0->alloc_replicated(L.env.ctx, params.num_nodes, N, r0, H, false);
     } else {
-        L.H0->alloc(L.env.ctx, N, H, false, true, false, world, rank, rm);
+        L.H0->alloc(L.env.ctx, N, H, false, true, false, xp);
     }
     L.H1->alloc(L.env.ctx, N, H, false);
-    L.Z0->alloc(L.env.ctx, N, C, false, true, false, world, rank, rm);
+    L.Z0->alloc(L.env.ctx, N, C, false, true, false, xp);
     L.Z->alloc(L.env.ctx, N, C, false);
     const uint64_t nnz_off = (uint64_t)data->feature_index.indptr[part.start[rank]];
     eval_vals = gcnhip_feat_values(feat);
@@ -460,6 +478,7 @@ void HipGCN::destroy_lane() {
         if (L.ev_weights) gcnhip_event_destroy(L.ev_weights);
         if (L.ev_done) gcnhip_event_destroy(L.ev_done);
         L.timers.reset();
+        exchange_buffers_destroy(&L.xbuf);
         L.comm.reset();
         gcnhip_ctx_destroy(L.env.ctx);
     }
@@ -499,6 +518,7 @@ void HipGCN::release() {
     gcnhip_free(env.ctx, d_train_bits);
     gcnhip_free(env.ctx, d_pos_bits);
     timers.reset();
+    exchange_buffers_destroy(&xbuf);
     owned_comm.reset();
     gcnhip_ctx_destroy(env.ctx);
     env.ctx = nullptr;

@@ -43,6 +43,8 @@ enum HipGCNFlags {
     HIPGCN_BF16_TABLES = 2048,   // opt-in, beyond the reference: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate)
     HIPGCN_ALL_ROWS = 4096,      // compute every row of the logits (default: only rows of the scored split, which is all the loss and accuracy read)
     HIPGCN_NO_AGG_FIRST_EVAL = 8192, // evaluation forwards keep the reference's order A^.(X.W1) instead of (A^.X).W1 with A^.X built once
+    HIPGCN_EXCHANGE_ALLGATHER = 16384, // multi-GPU: always all-gather whole row blocks before an aggregation
+    HIPGCN_EXCHANGE_HALO = 32768,      // ... or always exchange only the rows some local edge points at (default: decided per graph)
     HIPGCN_NULL_COMM = 1024,     // world > 1 without transport: collectives are no-ops (per-rank compute timing only)
     HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
@@ -85,6 +87,7 @@ public:
     int local_rows() const { return n_local; }
     int row_start() const { return part.start[env.comm->rank()]; }
     const RowPartition &partition() const { return part; }
+    const ExchangePlan &exchange_plan() const { return xplan; }
     // variable k as in gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z); rows x cols floats, this rank's rows
     void get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols);
     void set_weights(const float *w1, const float *w2);       // [F x h], [h x C] row-major
@@ -102,6 +105,8 @@ private:
     std::unique_ptr<Comm> owned_comm;
     std::unique_ptr<DeviceTimers> timers;
     RowPartition part;
+    ExchangePlan xplan;                                        // layout of gathered tables, send/receive lists
+    ExchangeBuffers xbuf;
     int n_local = 0;
     long nnzA_local = 0;
     int flags = 0;
@@ -157,6 +162,7 @@ private:
     // communicator / activation buffers lets one lane compute while the other communicates.
     struct EvalLane {
         HipEnv env;
+        ExchangeBuffers xbuf;
         std::unique_ptr<Comm> comm;
         std::unique_ptr<DeviceTimers> timers;
         gcnhip_graph *graph = nullptr;                         // own split-row scratch

@@ -20,7 +20,7 @@ void HipMatmul::backward() {
                                        nullptr, a->ld, b->grad, b->ld, m, n, p));
         env->timers->stop(TMR_MATMUL_BW);
         env->timers->start(TMR_COMM);
-        env->comm->allgather_rows(c->full_grad, c->full_elems / env->comm->size());
+        env->comm->exchange_rows(*env->plan, *env->xbuf, c->full_grad, c->ld);
         env->timers->stop(TMR_COMM);
         env->timers->start(TMR_MATMUL_BW);
         GCNHIP_CHECK(gcnhip_matmul_bwd_da_bits(env->ctx, b->data, b->ld, c->full_grad, c->ld, a->full_grad, a->ld,
@@ -95,7 +95,7 @@ void HipGraphSum::forward(bool training) {
     // rows of `in` named by this rank's columns live on other ranks: gather them first — unless every
     // rank computed all of `in` itself (replicated first-layer product)
     gcnhip_graph *graph = this->graph;
-    const int world = env->comm->size(), rank = env->comm->rank();
+    const int world = env->comm->size();
     const gcnhip_rowset *out_rows = fwd_out_rows ? *fwd_out_rows : nullptr;
     const bool replicated = in->replicated && fwd_graph_replicated;
     if (replicated) graph = fwd_graph_replicated;
@@ -106,11 +106,11 @@ void HipGraphSum::forward(bool training) {
         if (replicated) {
             GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, in->full, in->ld, tab, ld_bf, (int64_t)full_rows(in, false), dim));
         } else {
-            const size_t block_rows = world > 1 ? full_rows(in, false) / world : 0;
-            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, in->data, in->ld, tab + (size_t)rank * block_rows * ld_bf, ld_bf, in->rows, dim));
+            const size_t own = world > 1 ? (size_t)env->plan->own_offset : 0;
+            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, in->data, in->ld, tab + own * ld_bf, ld_bf, in->rows, dim));
             if (world > 1) {
                 env->timers->start(TMR_COMM);
-                env->comm->allgather_rows(reinterpret_cast<float *>(tab), block_rows * ld_bf / 2);   // bytes are moved, not interpreted
+                env->comm->exchange_rows(*env->plan, *env->xbuf, reinterpret_cast<float *>(tab), ld_bf / 2);   // bytes are moved, not interpreted
                 env->timers->stop(TMR_COMM);
             }
         }
@@ -124,7 +124,7 @@ void HipGraphSum::forward(bool training) {
     } else {
         if (!replicated && world > 1) {
             env->timers->start(TMR_COMM);
-            env->comm->allgather_rows(in->full, in->full_elems / world);
+            env->comm->exchange_rows(*env->plan, *env->xbuf, in->full, in->ld);
             env->timers->stop(TMR_COMM);
         }
         const float *src = in->full ? in->full : in->data;
@@ -142,10 +142,10 @@ void HipGraphSum::forward(bool training) {
         env->timers->stop(TMR_GRAPHSUM_FW);
     }
     if (pos_bits_full && training) {
-        uint32_t *mine = pos_bits_full + (size_t)rank * rows_max * wpr;
+        uint32_t *mine = pos_bits_full + (size_t)env->plan->own_offset * wpr;
         GCNHIP_CHECK(gcnhip_pack_positive(env->ctx, out->data, out->ld, out->rows, dim, mine, wpr));
         env->timers->start(TMR_COMM);
-        env->comm->allgather_rows(reinterpret_cast<float *>(pos_bits_full), (size_t)rows_max * wpr);   // bytes are moved, not interpreted
+        env->comm->exchange_rows(*env->plan, *env->xbuf, reinterpret_cast<float *>(pos_bits_full), wpr);   // bytes are moved, not interpreted
         env->timers->stop(TMR_COMM);
     }
 }
@@ -153,7 +153,7 @@ void HipGraphSum::forward(bool training) {
 void HipGraphSum::backward() {
     // same operator on the gradients (symmetric adjacency, module.cpp:103-119); out->grad is gathered,
     // unless every rank has already rebuilt all of it
-    const int world = env->comm->size(), rank = env->comm->rank();
+    const int world = env->comm->size();
     const uint32_t *row_bits = bwd_row_bits ? *bwd_row_bits : nullptr;
     if (env->bf16_tables) {
         uint16_t *tab = table();
@@ -161,11 +161,11 @@ void HipGraphSum::backward() {
         if (world > 1 && out_grad_complete) {
             GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, out->full_grad, out->ld, tab, ld_bf, (int64_t)full_rows(out, true), dim));
         } else {
-            const size_t block_rows = world > 1 ? full_rows(out, true) / world : 0;
-            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, out->grad, out->ld, tab + (size_t)rank * block_rows * ld_bf, ld_bf, out->rows, dim));
+            const size_t own = world > 1 ? (size_t)env->plan->own_offset : 0;
+            GCNHIP_CHECK(gcnhip_f32_to_bf16(env->ctx, out->grad, out->ld, tab + own * ld_bf, ld_bf, out->rows, dim));
             if (world > 1) {
                 env->timers->start(TMR_COMM);
-                env->comm->allgather_rows(reinterpret_cast<float *>(tab), block_rows * ld_bf / 2);
+                env->comm->exchange_rows(*env->plan, *env->xbuf, reinterpret_cast<float *>(tab), ld_bf / 2);
                 env->timers->stop(TMR_COMM);
             }
         }
@@ -177,7 +177,7 @@ void HipGraphSum::backward() {
     }
     if (world > 1 && !out_grad_complete) {
         env->timers->start(TMR_COMM);
-        env->comm->allgather_rows(out->full_grad, out->full_elems / world);
+        env->comm->exchange_rows(*env->plan, *env->xbuf, out->full_grad, out->ld);
         env->timers->stop(TMR_COMM);
     }
     const float *src = out->full_grad ? out->full_grad : out->grad;

@@ -21,6 +21,8 @@
 struct HipEnv {
     gcnhip_ctx *ctx = nullptr;
     Comm *comm = nullptr;
+    const ExchangePlan *plan = nullptr;      // layout of gathered tables + how remote rows arrive (partition.h)
+    ExchangeBuffers *xbuf = nullptr;         // this context's packing buffers for HALO plans
     DeviceTimers *timers = nullptr;
     uint64_t seed = 0;
     uint32_t *d_epoch = nullptr;
@@ -86,7 +88,7 @@ public:
     // multi-GPU, first layer: after a training forward publish bit = (out > 0) of this rank's rows to every rank;
     // in exchange backward() finds out->full_grad already complete (rebuilt locally) and gathers nothing
     uint32_t *pos_bits_full = nullptr;
-    int wpr = 0, rows_max = 0;
+    int wpr = 0;
     bool out_grad_complete = false;
     // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
     const uint32_t *const *bwd_row_bits = nullptr;

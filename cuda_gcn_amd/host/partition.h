@@ -66,3 +66,113 @@ inline LocalGraph build_local_graph(const int *gp, const int *gi, int n_rows, co
     for (long e = 0; e < nnz; e++) lg.indices[e] = pad[gi[gp[r0] + e]];
     return lg;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// What a rank holds of a matrix that an aggregation gathers from ("table"), and how the missing rows arrive.
+//   ALLGATHER: world blocks of rows_max rows (the padded layout above); every rank receives every block with one
+//              in-place ncclAllGather.  Right when a rank's columns cover (nearly) the whole graph — reddit-syn:
+//              even whole-community row blocks need 91-100 % of the remote rows.
+//   HALO     : [this rank's rows | the rows it needs from peer 0 | from peer 1 | ...] — only rows some local edge
+//              points at.  Each rank packs, per peer, the rows that peer needs (send lists) and the pieces move
+//              point to point (grouped ncclSend/ncclRecv straight into the table segments).  R-MAT ids carry the
+//              generator's quadrant locality: at 8 ranks a row block needs a third of the remote rows.
+// Every rank derives the plan of ALL ranks from the whole adjacency (which each holds), so the mode decision and
+// the send lists agree everywhere without communication.
+struct ExchangePlan {
+    int world = 1, rank = 0;
+    bool halo = false;
+    int n_local = 0;
+    int rows_max = 0;               // ALLGATHER block size
+    int table_rows = 0;             // rows of a gathered table on this rank
+    int own_offset = 0;             // table row of this rank's first row
+    // HALO: segment of peer q = table rows [n_local + recv_off[q], n_local + recv_off[q+1]); recv_rows = the
+    // peer-local row ids in that segment (ascending); send_rows[send_off[q] .. send_off[q+1]) = local rows peer q needs
+    std::vector<int> recv_off, recv_rows, send_off, send_rows;
+    std::vector<int> table_global;  // global node id of every table row (-1: padding)
+    double halo_share = 1.0;        // max over ranks of (needed remote rows / remote rows): what the mode was decided on
+    long recv_total() const { return halo ? (long)recv_rows.size() : (long)(world - 1) * rows_max; }
+    long send_total() const { return halo ? (long)send_rows.size() : (long)n_local; }
+};
+
+// mode: 0 = decide (HALO when every rank needs at most `halo_below` of the remote rows), 1 = ALLGATHER, 2 = HALO
+inline ExchangePlan make_exchange_plan(const int *gp, const int *gi, int n_rows, const RowPartition &part, int rank,
+                                       int mode = 0, double halo_below = 0.75) {
+    ExchangePlan x;
+    const int P = part.world;
+    x.world = P; x.rank = rank;
+    x.n_local = part.rows(rank);
+    x.rows_max = part.rows_max;
+    // need[p] = sorted global ids owned by others that rows of p point at.  One pass over the edges per rank block.
+    std::vector<std::vector<int>> need(P);
+    std::vector<uint8_t> mark((size_t)n_rows);
+    double worst = 0.0;
+    for (int p = 0; p < P && P > 1; p++) {
+        std::fill(mark.begin(), mark.end(), 0);
+        const int a = part.start[p], b = part.start[p + 1];
+        for (long e = gp[a]; e < gp[b]; e++) mark[gi[e]] = 1;
+        long cnt = 0;
+        for (int j = 0; j < n_rows; j++)
+            if (mark[j] && (j < a || j >= b)) { cnt++; if (p == rank) need[p].push_back(j); else if (j >= part.start[rank] && j < part.start[rank + 1]) need[p].push_back(j); }
+        const long remote = (long)n_rows - (b - a);
+        if (remote > 0) worst = std::max(worst, (double)cnt / (double)remote);
+    }
+    x.halo_share = P > 1 ? worst : 0.0;
+    x.halo = P > 1 && (mode == 2 || (mode == 0 && worst <= halo_below));
+    if (!x.halo) {
+        x.table_rows = P * part.rows_max;
+        x.own_offset = rank * part.rows_max;
+        x.table_global.assign((size_t)x.table_rows, -1);
+        for (int q = 0; q < P; q++)
+            for (int j = part.start[q]; j < part.start[q + 1]; j++) x.table_global[(size_t)q * part.rows_max + (j - part.start[q])] = j;
+        return x;
+    }
+    // this rank's table: own rows, then per peer the needed rows in ascending id order
+    x.own_offset = 0;
+    x.recv_off.assign(P + 1, 0);
+    x.send_off.assign(P + 1, 0);
+    const int r0 = part.start[rank];
+    x.table_global.resize((size_t)x.n_local);
+    for (int r = 0; r < x.n_local; r++) x.table_global[r] = r0 + r;
+    {
+        const std::vector<int> &mine = need[rank];       // ascending ids => grouped by owner in rank order
+        size_t k = 0;
+        for (int q = 0; q < P; q++) {
+            x.recv_off[q] = (int)x.recv_rows.size();
+            while (k < mine.size() && mine[k] < part.start[q + 1]) {
+                if (q != rank) { x.recv_rows.push_back(mine[k] - part.start[q]); x.table_global.push_back(mine[k]); }
+                k++;
+            }
+        }
+        x.recv_off[P] = (int)x.recv_rows.size();
+    }
+    for (int q = 0; q < P; q++) {
+        x.send_off[q] = (int)x.send_rows.size();
+        if (q != rank)
+            for (int j : need[q]) x.send_rows.push_back(j - r0);   // need[q] (q != rank) holds only ids this rank owns
+    }
+    x.send_off[P] = (int)x.send_rows.size();
+    x.table_rows = x.n_local + (int)x.recv_rows.size();
+    return x;
+}
+
+// This rank's row block with columns rewritten to table rows of `plan` (either mode) + the degree of every table row
+inline LocalGraph build_table_graph(const int *gp, const int *gi, int n_rows, const RowPartition &part, const ExchangePlan &plan) {
+    LocalGraph lg;
+    const int rank = plan.rank, r0 = part.start[rank], r1 = part.start[rank + 1];
+    lg.n_rows = r1 - r0;
+    lg.n_cols = plan.table_rows;
+    lg.indptr.resize(lg.n_rows + 1);
+    for (int r = 0; r <= lg.n_rows; r++) lg.indptr[r] = gp[r0 + r] - gp[r0];
+    std::vector<int> pos((size_t)n_rows, -1);
+    lg.col_deg.assign((size_t)std::max(lg.n_cols, 1), 1);
+    for (int t = 0; t < plan.table_rows; t++) {
+        const int j = plan.table_global[t];
+        if (j < 0) continue;
+        pos[j] = t;
+        lg.col_deg[t] = gp[j + 1] - gp[j];
+    }
+    const long nnz = (long)gp[r1] - gp[r0];
+    lg.indices.resize((size_t)nnz);
+    for (long e = 0; e < nnz; e++) lg.indices[e] = pos[gi[gp[r0] + e]];   // never -1: the plan covers every column of the block
+    return lg;
+}

@@ -20,21 +20,21 @@ HipVariable::~HipVariable() {
     else if (grad) gcnhip_free(ctx, grad);
 }
 
-void HipVariable::alloc(gcnhip_ctx *c, int r, int cl, bool rg, bool gather_data, bool gather_grad,
-                        int world, int rank, int gather_rows_max) {
+void HipVariable::alloc(gcnhip_ctx *c, int r, int cl, bool rg, bool gather_data, bool gather_grad, const ExchangePlan *plan) {
+    const int world = plan ? plan->world : 1;
     ctx = c; rows = r; cols = cl; requires_grad = rg;
     // 16-byte aligned rows; wider rows are padded to 64 bytes so a gathered row never straddles a
     // third 128-byte line (GraphSum at 41 classes: ld 48 is 8 % faster than ld 44)
     ld = cl <= 32 ? (cl + 3) / 4 * 4 : (cl + 15) / 16 * 16;
     const size_t local = (size_t)(rows > 0 ? rows : 1) * ld;
-    const size_t block = (size_t)gather_rows_max * ld;
-    full_elems = block * world;
+    const size_t own = plan ? (size_t)plan->own_offset * ld : 0;
+    full_elems = plan ? (size_t)plan->table_rows * ld : 0;
     void *p = nullptr;
     if (gather_data && world > 1) {
         GCNHIP_CHECK(gcnhip_malloc(ctx, &p, full_elems * sizeof(float)));
         GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, full_elems * sizeof(float)));
         full = (float *)p;
-        data = full + block * rank;
+        data = full + own;
     } else {
         GCNHIP_CHECK(gcnhip_malloc(ctx, &p, local * sizeof(float)));
         GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, local * sizeof(float)));
@@ -45,7 +45,7 @@ void HipVariable::alloc(gcnhip_ctx *c, int r, int cl, bool rg, bool gather_data,
             GCNHIP_CHECK(gcnhip_malloc(ctx, &p, full_elems * sizeof(float)));
             GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, full_elems * sizeof(float)));
             full_grad = (float *)p;
-            grad = full_grad + block * rank;
+            grad = full_grad + own;
         } else {
             GCNHIP_CHECK(gcnhip_malloc(ctx, &p, local * sizeof(float)));
             GCNHIP_CHECK(gcnhip_memset_async(ctx, p, 0, local * sizeof(float)));

@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <vector>
 #include "gcnhip.h"
+#include "partition.h"
 #include "rand.h"
 
 struct Variable {
@@ -15,8 +16,8 @@ struct Variable {
 // A row-major [rows x cols] f32 matrix on the GPU with leading dimension ld
 // (multiple of 4 floats: every row 16-byte aligned for the vector kernels).
 // For variables that GraphSum gathers from other ranks, `full` is the base of
-// the [world * rows_max x ld] gather buffer and data/grad point at this
-// rank's block inside it (so the all-gather is in place).
+// the gathered table ([plan.table_rows x ld], partition.h) and data/grad point
+// at this rank's block inside it (so the exchange completes it in place).
 struct HipVariable {
     gcnhip_ctx *ctx = nullptr;
     float *data = nullptr, *grad = nullptr;          // this rank's rows
@@ -29,9 +30,10 @@ struct HipVariable {
     HipVariable(const HipVariable &) = delete;
     HipVariable &operator=(const HipVariable &) = delete;
     ~HipVariable();
-    // gather_rows_max > 0: allocate world * gather_rows_max rows and place this rank's block at rank * gather_rows_max
+    // gather_*: data / grad is a gathered table of plan->table_rows rows with this rank's block at plan->own_offset
+    // (only when the plan spans more than one rank)
     void alloc(gcnhip_ctx *ctx, int rows, int cols, bool requires_grad, bool gather_data = false,
-               bool gather_grad = false, int world = 1, int rank = 0, int gather_rows_max = 0);
+               bool gather_grad = false, const ExchangePlan *plan = nullptr);
     // replicated input of a GraphSum: every rank computes all `total_rows` rows itself (no all-gather);
     // data points at this rank's rows inside the full matrix
     void alloc_replicated(gcnhip_ctx *ctx, int total_rows, int local_rows, int row_start, int cols, bool requires_grad);

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192
+MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
 TIMER_NAMES = ["train", "test", "matmul_fw", "matmul_bw", "spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw",
                "loss_fw", "relu_fw", "relu_bw", "dropout_fw", "dropout_bw", "adam", "comm", "graphsum_wide"]
 
@@ -97,6 +97,13 @@ class HipGCNModel:
         e = C.c_int64()
         _ck(self.lib, self.lib.gcnhost_model_info(self.h, C.byref(r), C.byref(w), C.byref(s), C.byref(n), C.byref(e)), "info")
         return dict(rank=r.value, world=w.value, row_start=s.value, local_rows=n.value, local_edges=e.value)
+
+    def exchange(self):
+        h, t = C.c_int(), C.c_int()
+        r, sn = C.c_int64(), C.c_int64()
+        sh = C.c_double()
+        _ck(self.lib, self.lib.gcnhost_model_exchange(self.h, C.byref(h), C.byref(r), C.byref(sn), C.byref(t), C.byref(sh)), "exchange")
+        return dict(mode="halo" if h.value else "allgather", recv_rows=r.value, send_rows=sn.value, table_rows=t.value, halo_share=sh.value)
 
     def var(self, k, grad=False):
         r, c = C.c_int(), C.c_int()
@@ -201,6 +208,32 @@ def local_graph(g_indptr, g_indices, world, rank):
     lib.gcnhost_local_graph(gp.ctypes.data, gi.ctypes.data, gp.size - 1, world, rank, ip.ctypes.data, ix.ctypes.data,
                             cd.ctypes.data, None, None, None)
     return ip, ix, cd, nc.value
+
+
+def exchange_plan(g_indptr, g_indices, world, rank, mode=0):
+    """the host-side plan of `rank` (host/partition.h) as a dict of numpy arrays — host only"""
+    lib = _lib.gcnhost()
+    gp, gi = _i32(g_indptr), _i32(g_indices)
+    h = C.c_void_p()
+    if lib.gcnhost_plan_create(C.byref(h), gp.ctypes.data, gi.ctypes.data, gp.size - 1, world, rank, mode) != 0:
+        raise GcnHostError("plan_create failed")
+    halo, nl, tr, oo, rm = (C.c_int() for _ in range(5))
+    sh = C.c_double()
+    nnz, nr, ns = C.c_int64(), C.c_int64(), C.c_int64()
+    lib.gcnhost_plan_info(h, C.byref(halo), C.byref(nl), C.byref(tr), C.byref(oo), C.byref(rm), C.byref(sh), C.byref(nnz), C.byref(nr), C.byref(ns))
+    ptr = [C.c_void_p() for _ in range(8)]
+    lib.gcnhost_plan_arrays(h, *[C.byref(q) for q in ptr])
+
+    def arr(q, n):
+        return np.frombuffer((C.c_int * n).from_address(q.value), dtype=np.int32).copy() if n and q.value else np.zeros(0, np.int32)
+    is_halo = bool(halo.value)
+    out = dict(halo=is_halo, n_local=nl.value, table_rows=tr.value, own_offset=oo.value, rows_max=rm.value, halo_share=sh.value,
+               recv_off=arr(ptr[0], world + 1 if is_halo else 0), recv_rows=arr(ptr[1], nr.value),
+               send_off=arr(ptr[2], world + 1 if is_halo else 0), send_rows=arr(ptr[3], ns.value),
+               table_global=arr(ptr[4], tr.value), indptr=arr(ptr[5], nl.value + 1), indices=arr(ptr[6], nnz.value),
+               col_deg=arr(ptr[7], max(tr.value, 1)))
+    lib.gcnhost_plan_free(h)
+    return out
 
 
 def glorot(size, in_size, out_size, seed, skip_draws=0):

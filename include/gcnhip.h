@@ -226,6 +226,10 @@ int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *ctx, const float *b, int ldb, const fl
                               float *da, int ldda, int m, int n, int p,
                               const uint32_t *h_pos_bits, int words_per_row, float scale);
 
+/* Row packing for the halo exchange (new: the reference is single-GPU).  dst[i, 0:ld_words] = src[d_rows[i], 0:ld_words]
+ * for i < n; rows are arrays of 4-byte words that are moved, not interpreted (f32 rows, bf16 rows, mask words). */
+int gcnhip_gather_rows(gcnhip_ctx *ctx, const float *src, int ld_words, const int *d_rows, int n, float *dst);
+
 /* ---- ReLU (CUDAReLU: cuda_module.cu:164-186; cuda_kernel.cu:204-219) ---------
  * mask: one byte per element, written only when training (module.cpp:180). */
 int gcnhip_relu_fwd(gcnhip_ctx *ctx, float *x, uint8_t *mask, int64_t n, int training);

@@ -45,6 +45,9 @@ enum {
                                      scored split — all that loss and accuracy read; env HIPGCN_ALL_ROWS=1 does the same) */
     GCNHOST_NO_AGG_FIRST_EVAL = 8192, /* evaluation forwards keep the reference's order A^.(X.W1); default for a dense X: (A^.X).W1 with
                                          A^.X built once (no hidden-width aggregation in eval; env HIPGCN_NO_AGG_FIRST_EVAL=1 does the same) */
+    GCNHOST_EXCHANGE_ALLGATHER = 16384, /* multi-GPU: always all-gather whole row blocks before an aggregation */
+    GCNHOST_EXCHANGE_HALO = 32768,      /* ... or always exchange only the needed rows, peer to peer (default: decided per graph;
+                                           env HIPGCN_EXCHANGE=halo|allgather) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 
@@ -81,6 +84,9 @@ int gcnhost_model_run(gcnhost_model *m);                                       /
 int gcnhost_model_sync(gcnhost_model *m);
 
 /* introspection */
+/* multi-GPU: how this rank's gathered tables are completed (halo = 1: per-peer send lists; 0: whole-block all-gather),
+ * rows received / sent per exchange, rows of a table, and the share of remote rows the neediest rank reads */
+int gcnhost_model_exchange(gcnhost_model *m, int *halo, int64_t *recv_rows, int64_t *send_rows, int *table_rows, double *halo_share);
 int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges);
 /* the aggregation's row schedule this rank timed as fastest (gcnhip_graph_set_schedule modes; 0 when not tuned) */
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
@@ -118,6 +124,19 @@ int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start /* 
  * gcnhip_graph_create when world > 1).  Call once with NULL arrays for the sizes. */
 int gcnhost_local_graph(const int *g_indptr, const int *g_indices, int n_rows, int world, int rank,
                         int *indptr, int *indices, int *col_deg, int *n_local, int *n_cols, int64_t *nnz_local);
+/* How rank `rank` of `world` completes the tables an aggregation gathers from (host/partition.h): mode 0 decides
+ * per graph between an all-gather of whole row blocks and a halo exchange of only the rows some local edge points
+ * at (1 / 2 force one).  Gives the table layout, the per-peer send and receive lists and the rank's row block of the
+ * adjacency with its columns rewritten to table rows — what HipGCN hands to gcnhip_graph_create.  Host only. */
+typedef struct gcnhost_plan gcnhost_plan;
+int gcnhost_plan_create(gcnhost_plan **p, const int *g_indptr, const int *g_indices, int n_rows, int world, int rank, int mode);
+int gcnhost_plan_info(const gcnhost_plan *p, int *halo, int *n_local, int *table_rows, int *own_offset, int *rows_max,
+                      double *halo_share, int64_t *nnz_local, int64_t *n_recv, int64_t *n_send);
+/* recv_off/send_off: [world+1]; recv_rows: peer-local row ids per segment; send_rows: local row ids per destination;
+ * table_global: [table_rows] global node id (-1 = padding); indptr/indices/col_deg: the local adjacency */
+int gcnhost_plan_arrays(const gcnhost_plan *p, const int **recv_off, const int **recv_rows, const int **send_off, const int **send_rows,
+                        const int **table_global, const int **indptr, const int **indices, const int **col_deg);
+int gcnhost_plan_free(gcnhost_plan *p);
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws);
 int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t skip_draws);
 /* Graph500 R-MAT graph (a,b,c = .57,.19,.19) of 2^scale nodes and edge_factor * 2^scale sampled pairs, symmetrised,

@@ -175,3 +175,51 @@ def test_truncated_or_inconsistent_gcnbin_is_rejected_and_text_is_parsed(tmp_pat
         f.write(blob)
     got = model.load_dataset(root, "t")
     assert np.array_equal(got["g_indices"], ds["g_indices"]) and np.array_equal(got["f_val"], ds["f_val"])
+
+
+@pytest.mark.parametrize("name,world,mode", [("tiny-syn", 3, 2), ("cora-syn", 4, 2), ("rmat-12", 8, 0), ("rmat-12", 2, 0), ("cora-syn", 2, 1)])
+def test_exchange_plans_are_consistent_across_ranks(name, world, mode, oracle):
+    """every rank derives its plan from the whole adjacency: the plans must agree on the mode, rank q's send list for
+    p must be exactly what p expects from q, and aggregating through the table (own rows + received rows) must give
+    the rows the single-process oracle computes"""
+    from cuda_gcn_amd import model
+    if name.startswith("rmat"):
+        gp, gi = datagen.rmat_graph(int(name.split("-")[1]))
+    else:
+        ds = datagen.make_dataset(name)
+        gp, gi = ds["g_indptr"], ds["g_indices"]
+    N = gp.size - 1
+    start, _ = model.partition(gp, world)
+    plans = [model.exchange_plan(gp, gi, world, r, mode) for r in range(world)]
+    assert len({p["halo"] for p in plans}) == 1 and len({round(p["halo_share"], 12) for p in plans}) == 1
+    halo = plans[0]["halo"]
+    if name == "rmat-12" and world == 8:
+        assert halo and plans[0]["halo_share"] < 0.75            # R-MAT ids carry locality: the automatic choice is HALO
+    if mode == 1:
+        assert not halo
+    x = np.random.default_rng(1).standard_normal((N, 5)).astype(np.float32)
+    want = oracle.graphsum(gp, gi, x, 5)
+    deg = np.diff(gp).astype(np.int64)
+    for p_rank, p in enumerate(plans):
+        r0, r1 = int(start[p_rank]), int(start[p_rank + 1])
+        assert p["n_local"] == r1 - r0
+        tg = p["table_global"]
+        assert np.array_equal(tg[p["own_offset"]:p["own_offset"] + p["n_local"]], np.arange(r0, r1))
+        if halo:
+            for q in range(world):
+                seg = p["recv_rows"][p["recv_off"][q]:p["recv_off"][q + 1]]
+                sent = plans[q]["send_rows"][plans[q]["send_off"][p_rank]:plans[q]["send_off"][p_rank + 1]]
+                assert np.array_equal(seg, sent), (p_rank, q)
+                assert np.array_equal(tg[p["n_local"] + p["recv_off"][q]:p["n_local"] + p["recv_off"][q + 1]], seg + int(start[q]))
+            assert p["recv_off"][p_rank] == p["recv_off"][p_rank + 1]
+            assert p["table_rows"] == p["n_local"] + p["recv_rows"].size < N + 1
+        # the table a completed exchange leaves on this rank, then the aggregation in numpy
+        table = np.where(tg[:, None] >= 0, x[np.maximum(tg, 0)], np.nan).astype(np.float32)
+        ip, ix, cd = p["indptr"], p["indices"], p["col_deg"]
+        assert np.array_equal(tg[ix], gi[gp[r0]:gp[r1]])                      # columns decode to the same nodes
+        assert np.array_equal(cd[ix], deg[gi[gp[r0]:gp[r1]]])
+        src = np.repeat(np.arange(r1 - r0), np.diff(ip))
+        coef = (1.0 / np.sqrt((deg[r0:r1][src] * cd[ix].astype(np.int64)).astype(np.float32)).astype(np.float64)).astype(np.float32)
+        got = np.zeros((r1 - r0, 5), np.float64)
+        np.add.at(got, src, coef[:, None].astype(np.float64) * table[ix].astype(np.float64))
+        assert np.allclose(got, want[r0:r1], rtol=1e-5, atol=1e-5)

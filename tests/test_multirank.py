@@ -68,6 +68,11 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
     ("cora-syn", 2, 0.5, 1, 2048),      # BF16_TABLES: bf16 blocks are what the ranks all-gather
     ("reddit-mini", 2, 0.5, 0, 2048),
     ("reddit-mini", 2, 0.5, 1, 0),      # dense 602-column X, hidden 128, hub rows: the bench's shapes at 1/10 scale
+    # EXCHANGE_HALO (32768): tables hold own rows + the rows some local edge points at; per-peer send lists
+    ("cora-syn", 2, 0.5, 1, 32768), ("tiny-syn", 3, 0.5, 0, 32768), ("cora-syn", 3, 0.0, 1, 32768 | 256),
+    ("cora-syn", 2, 0.5, 0, 32768 | 2), ("cora-syn", 2, 0.5, 1, 32768 | 2048), ("reddit-mini", 2, 0.5, 1, 32768),
+    ("rmat-12-32", 3, 0.5, 1, 0),       # R-MAT: the automatic choice is the halo exchange
+    ("rmat-12-32", 3, 0.5, 0, 16384),   # ... and the same graph with the all-gather forced
 ])
 def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, flags):
     from cuda_gcn_amd import datagen
