@@ -304,6 +304,7 @@ def main():
 
     model, t_build = build(base_flags | (NO_ROW_GROUPS if args.no_row_groups else 0))
     info = model.info()
+    exchange = model.exchange() if world > 1 else None
     model.run_epochs(args.warmup, want_trace=False)
     dt, trace = timed_region(model, args.steps)      # <- the headline: default product path, per-op timers off
     burst_eps = [args.steps / dt]
@@ -401,6 +402,7 @@ def main():
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": schedule,
+                       "exchange": exchange,       # rank 0's view: all-gather of row blocks or halo lists, rows moved per exchange
                        "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
                                        "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",
                        "logit_rows": "all" if os.environ.get("HIPGCN_ALL_ROWS") else "rows of the scored split only"},

@@ -208,11 +208,10 @@ template <int VA, int VB>
 __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int worker = blockIdx.x * 4 + wave;
-    if (worker >= a.n_workers) return;
+    const int worker = blockIdx.x * 4 + wave;            // idle waves (past n_workers) still reach the barrier below
     const int colA = blockIdx.y * 16 * VA + VA * li;       // this lane's first A column
     const int colB = blockIdx.z * 16 * VB + VB * li;
-    const int r0 = worker * a.rows_per_worker;
+    const int r0 = min(a.m, worker * a.rows_per_worker);
     const int r1 = min(a.m, r0 + a.rows_per_worker);
     const uint32_t epoch = (a.drop && a.d_epoch) ? *a.d_epoch : 0u;
     f32x4 acc[VA][VB];
@@ -258,8 +257,35 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
             for (int u = 0; u < VB; u++)
                 acc[s][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[u], acc[s][u], 0, 0, 0);
     }
+    // The four waves of a workgroup are consecutive row ranges of the same output block: their partials are added
+    // here in wave order, ((w0 + w1) + w2) + w3, and ONE slab per workgroup goes to memory — four times the
+    // waves in flight for the same slab traffic (a worker with too few peers on its SIMD waits out every load).
+    __shared__ float red[3 * 64 * VA * VB * 4];
+    if (wave > 0) {
+        float *mine = red + (size_t)(wave - 1) * 64 * VA * VB * 4;
+#pragma unroll
+        for (int s = 0; s < VA; s++)
+#pragma unroll
+            for (int u = 0; u < VB; u++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) mine[((s * VB + u) * 4 + reg) * 64 + lane] = acc[s][u][reg];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int live = min(4, a.n_workers - blockIdx.x * 4);          // waves of this workgroup that had rows
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (w >= live) break;
+        const float *theirs = red + (size_t)(w - 1) * 64 * VA * VB * 4;
+#pragma unroll
+        for (int s = 0; s < VA; s++)
+#pragma unroll
+            for (int u = 0; u < VB; u++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) acc[s][u][reg] += theirs[((s * VB + u) * 4 + reg) * 64 + lane];
+    }
     // D_{s,u}[i][c] = S[blockA + VA*i + s][blockB + VB*c + u]
-    float *slab = a.slab + (size_t)worker * a.n * a.p_ld;
+    float *slab = a.slab + (size_t)blockIdx.x * a.n * a.p_ld;
 #pragma unroll
     for (int s = 0; s < VA; s++)
 #pragma unroll
@@ -328,16 +354,17 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     int per_cu = slab_per_worker <= (256u << 10) ? 16 : 4;
     int workers = ceil_div((int64_t)c->n_cu * per_cu, (int64_t)gy * gz);
     static const size_t cap_mb = getenv("GCNHIP_ATB_CAP_MB") ? (size_t)atoi(getenv("GCNHIP_ATB_CAP_MB")) : 12;   // experiments
-    while (workers > 4 && (size_t)workers * slab_per_worker > (cap_mb << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials
+    while (workers > 4 && (size_t)(workers / 4) * slab_per_worker > (cap_mb << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials (one slab per workgroup of 4 workers)
     if (workers > ceil_div(m, 256)) workers = ceil_div(m, 256);      // at least 64 K-steps per worker
     if (workers < 1) workers = 1;
     workers = (workers + 3) / 4 * 4;
     a.rows_per_worker = (ceil_div(m, workers) + 3) / 4 * 4;
     a.n_workers = ceil_div(m, a.rows_per_worker);
-    const int rc = ensure_slab(c, (size_t)a.n_workers * n * a.p_ld * sizeof(float));
+    const int n_slabs = ceil_div(a.n_workers, 4);
+    const int rc = ensure_slab(c, (size_t)n_slabs * n * a.p_ld * sizeof(float));
     if (rc) return rc;
     a.slab = c->slab;
-    dim3 grid(ceil_div(a.n_workers, 4), gy, gz);
+    dim3 grid(n_slabs, gy, gz);
 #define ATB(VA_, VB_) gemm_atb_kernel<VA_, VB_><<<grid, 256, 0, c->stream>>>(a)
     if (VA == 4 && VB == 4) ATB(4, 4);
     else if (VA == 4 && VB == 2) ATB(4, 2);
@@ -352,7 +379,7 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     GCNHIP_LAUNCH_CHECK();
     int rb = ceil_div((int64_t)n * p, 64);
     if (rb > 4096) rb = 4096;
-    slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(a.slab, a.n_workers, n, p, a.p_ld, out, ld_out);
+    slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(a.slab, n_slabs, n, p, a.p_ld, out, ld_out);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

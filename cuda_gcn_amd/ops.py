@@ -154,6 +154,15 @@ class Device:
             _ck(self.lib, self.lib.gcnhip_graphsum_rowmask(self.ctx, g.h, xin.ptr, ld_in, out.ptr, ld_out, dim, bb.ptr), "gcnhip_graphsum_rowmask")
         return out.download()[:, :dim]
 
+    def gather_rows(self, x, rows):
+        """dst[i] = x[rows[i]] through gcnhip_gather_rows (the packing step of the halo exchange)"""
+        x = np.ascontiguousarray(x, np.float32)
+        rows = np.ascontiguousarray(rows, np.int32)
+        xb, rb = self.buf(x), self.buf(rows if rows.size else np.zeros(1, np.int32))
+        out = self.buf(np.full((max(rows.size, 1), x.shape[1]), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_gather_rows(self.ctx, xb.ptr, x.shape[1], rb.ptr, int(rows.size), out.ptr), "gcnhip_gather_rows")
+        return out.download()[:rows.size]
+
     def to_bf16(self, x, ld_dst=None):
         """f32 rows -> bf16 table (uint16 [rows, ld_dst]) through gcnhip_f32_to_bf16"""
         x = np.asarray(x, np.float32)

@@ -116,7 +116,7 @@ def _gpu_count():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("run_async,flags", [(1, 0), (0, 32)])
+@pytest.mark.parametrize("run_async,flags", [(1, 0), (0, 32), (1, 32768), (0, 32768 | 256)])   # 32768: halo exchange (grouped ncclSend/ncclRecv)
 def test_two_ranks_rccl_match_single_gpu(run_async, flags):
     """the product's transport: one GPU per rank, RCCL over xGMI (in-place ncclAllGather, the fused all-reduce, the
     validation lane's split communicator).  Needs two GPUs; the one-GPU box of this pool skips it."""

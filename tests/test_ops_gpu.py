@@ -178,6 +178,16 @@ def test_aggregate_first_evaluation_form(dev, oracle, n, F, p):
     fa.free(); fx.free(); g.free()
 
 
+@pytest.mark.parametrize("ld", [48, 128, 5, 1, 4])
+def test_gather_rows_packs_exactly(dev, ld):
+    rng = np.random.default_rng(ld)
+    x = rng.standard_normal((3000, ld)).astype(np.float32)
+    rows = np.sort(rng.choice(3000, 1234, replace=False)).astype(np.int32)
+    assert np.array_equal(dev.gather_rows(x, rows), x[rows])
+    assert np.array_equal(dev.gather_rows(x, rows[:1]), x[rows[:1]])
+    assert dev.gather_rows(x, rows[:0]).shape == (0, ld)
+
+
 def test_edge_coef_bit_exact(dev):
     ds = datagen.make_dataset("cora-syn")
     gp, gi = ds["g_indptr"], ds["g_indices"]
