@@ -103,6 +103,11 @@ GCNHIP_SYMBOLS = {
     "gcnhip_matmul_fwd": (I, [P, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd_fused": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F]),
+    "gcnhip_rowpack_create": (I, [P, C.POINTER(P), I, I]),
+    "gcnhip_rowpack_destroy": (I, [P, P]),
+    "gcnhip_rowpack_expand": (I, [P, P, P, I]),
+    "gcnhip_matmul_bwd_packed": (I, [P, P, I, P, I, P, I, P, I, P, P, I, I, I, I, F]),
+    "gcnhip_graphsum_packed": (I, [P, P, P, P, I, P, I]),
     "gcnhip_pack_positive": (I, [P, P, I, I, I, P, I]),
     "gcnhip_f32_to_bf16": (I, [P, P, I, P, I, I64, I]),
     "gcnhip_graphsum_bf16": (I, [P, P, P, I, P, I, I, P, P, I, I, F, U64, P, U64, P]),

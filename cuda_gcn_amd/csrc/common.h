@@ -64,6 +64,12 @@ struct gcnhip_graph {
     std::vector<gcnhip_rowset *> *rowsets;   // owned
 };
 
+// packed rows (dense_kernels.h "packed rows"): one 128-byte slot per (row, 64-column half)
+struct gcnhip_rowpack {
+    int rows, cols, halves;
+    uint32_t *slots;    // [rows x halves x 32]
+};
+
 struct gcnhip_feat {
     int n_rows, n_cols;
     int64_t nnz;

@@ -34,12 +34,32 @@ struct RowStreamArgs {
     const float *H; int ldh; float scale;
     const uint32_t *hbits; int wpr;             // alternative mask source: bit (c & 31) of hbits[r*wpr + (c >> 5)] = (H[r,c] > 0)
     int vec_out;                                // C (and H) rows are 16-byte aligned: LDS-staged row stores
+    // PACK: rows leave as packed half-row slots (rowpack.h) instead of dense rows; C receives only the rows that do not fit
+    uint32_t *pack_slots; int pack_halves;      // [m x pack_halves x 32] dwords
 };
+
+// ---- packed rows (exact): a [rows x cols] matrix whose entries are mostly zero by a KNOWN mask ----------------
+// cols is cut into halves of 64 columns; half h of row r owns one 128-byte slot:
+//     dword 0-1 : the 64-bit mask of the half (bit c = column 64h + c may be non-zero)
+//     dword 2.. : the masked-in values in column order (at most PACK_CAP = 30)
+// A half with more than 30 masked-in columns does not fit: its slot carries only the mask and the row's dense
+// image (the caller's ordinary [rows x ld] buffer) holds that half.  One line per (row, half) instead of two.
+constexpr int PACK_CAP = 30;
+
+// bits 0..15 of x to bit positions 0, 4, 8, ... 60
+__device__ inline uint64_t spread4(uint32_t x) {
+    uint64_t v = x & 0xFFFFu;
+    v = (v | (v << 24)) & 0x000000FF000000FFull;
+    v = (v | (v << 12)) & 0x000F000F000F000Full;
+    v = (v | (v << 6)) & 0x0303030303030303ull;
+    v = (v | (v << 3)) & 0x1111111111111111ull;
+    return v;
+}
 
 // KCH > 0: the K extent is KCH chunks of 16 (K <= 128) and a wave issues all of its KCH
 // 16-byte loads of a row tile before the first MFMA (KCH KiB in flight per wave instead of
 // one dependent load per chunk).  KCH == 0: generic loop for longer K.
-template <int NT, bool VEC, bool FUSE, int KCH>
+template <int NT, bool VEC, bool FUSE, int KCH, bool PACK = false>
 __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float Bs[];
     constexpr int NCLD = NT * 16 + 4;        // +4: the four k-groups of a wave hit disjoint banks
@@ -124,6 +144,50 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
             for (int r0 = 0; r0 < 16; r0 += RPP) {
                 const int rr = r0 + lane / LPRW, cc = (lane % LPRW) * 4;
                 const int r = tile * 16 + rr, col = c_base + cc;
+                if constexpr (PACK) {
+                    // FUSE, whole 64-column halves (Nc % 64 == 0), LPRW = 16 or 32 lanes per row.  Every lane of
+                    // the wave takes part in the ballots; lanes of rows past m contribute zero bits.
+                    static_assert(!PACK || (FUSE && (NT == 4 || NT == 8)), "packed rows need the mask and whole halves");
+                    const bool live = r < a.m;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bool k0 = false, k1 = false, k2 = false, k3 = false;
+                    if (live) {
+                        v = *reinterpret_cast<const float4 *>(&Cs[rr * CLD + cc]);
+                        if (a.hbits) {
+                            const uint32_t kb = a.hbits[(size_t)r * a.wpr + (col >> 5)] >> (col & 31);
+                            k0 = kb & 1u; k1 = kb & 2u; k2 = kb & 4u; k3 = kb & 8u;
+                        } else {
+                            const float4 h = *reinterpret_cast<const float4 *>(a.H + (size_t)r * a.ldh + col);
+                            k0 = h.x > 0.f; k1 = h.y > 0.f; k2 = h.z > 0.f; k3 = h.w > 0.f;
+                        }
+                        v.x = k0 ? v.x * a.scale : 0.f; v.y = k1 ? v.y * a.scale : 0.f;
+                        v.z = k2 ? v.z * a.scale : 0.f; v.w = k3 ? v.w * a.scale : 0.f;
+                    }
+                    const int rg = lane / LPRW, lr = lane % LPRW, hb = lr >> 4, lh = lr & 15;
+                    const uint32_t rowmask = LPRW == 32 ? 0xFFFFFFFFu : 0xFFFFu;
+                    const uint32_t b0 = (uint32_t)(__ballot(k0) >> (LPRW * rg)) & rowmask, b1 = (uint32_t)(__ballot(k1) >> (LPRW * rg)) & rowmask;
+                    const uint32_t b2 = (uint32_t)(__ballot(k2) >> (LPRW * rg)) & rowmask, b3 = (uint32_t)(__ballot(k3) >> (LPRW * rg)) & rowmask;
+                    const uint32_t hsel = 0xFFFFu << (16 * hb), below = ((1u << lh) - 1u) << (16 * hb);
+                    const int n_half = __popc(b0 & hsel) + __popc(b1 & hsel) + __popc(b2 & hsel) + __popc(b3 & hsel);
+                    if (live) {
+                        const int half = (col >> 6);
+                        uint32_t *slot = a.pack_slots + ((size_t)r * a.pack_halves + half) * 32;
+                        if (lh == 0) {
+                            const uint64_t m64 = spread4(b0 >> (16 * hb)) | (spread4(b1 >> (16 * hb)) << 1) |
+                                                 (spread4(b2 >> (16 * hb)) << 2) | (spread4(b3 >> (16 * hb)) << 3);
+                            *reinterpret_cast<uint2 *>(slot) = make_uint2((uint32_t)m64, (uint32_t)(m64 >> 32));
+                        }
+                        if (n_half <= PACK_CAP) {
+                            int off = 2 + __popc(b0 & below) + __popc(b1 & below) + __popc(b2 & below) + __popc(b3 & below);
+                            if (k0) slot[off++] = __float_as_uint(v.x);
+                            if (k1) slot[off++] = __float_as_uint(v.y);
+                            if (k2) slot[off++] = __float_as_uint(v.z);
+                            if (k3) slot[off++] = __float_as_uint(v.w);
+                        } else {
+                            *reinterpret_cast<float4 *>(a.C + (size_t)r * a.ldc + col) = v;   // the half does not fit: dense image
+                        }
+                    }
+                } else
                 if (lane < RPP * LPRW && rr < 16 && r < a.m && col < a.Nc) {
                     float4 v = *reinterpret_cast<const float4 *>(&Cs[rr * CLD + cc]);
                     float *cp = a.C + (size_t)r * a.ldc + col;
@@ -387,13 +451,15 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
 // C[m x Nc] = A[m x K] . Bs  (Bs from B, optionally transposed), optional epilogue
 static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float *B, int ldb, int transB,
                             float *C, int ldc, int m, int K, int Nc, const float *H, int ldh, float scale,
-                            const uint32_t *hbits = nullptr, int wpr = 0) {
+                            const uint32_t *hbits = nullptr, int wpr = 0, uint32_t *pack_slots = nullptr, int pack_halves = 0) {
     RowStreamArgs a;
     a.hbits = hbits; a.wpr = wpr;
+    a.pack_slots = pack_slots; a.pack_halves = pack_halves;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.transB = transB; a.C = C; a.ldc = ldc;
     a.m = m; a.K = K; a.Nc = Nc; a.H = H; a.ldh = ldh; a.scale = scale;
     a.vec_out = (Nc >= 64 && ldc % 4 == 0 && aligned16(C) && (!H || hbits || (ldh % 4 == 0 && aligned16(H)))) ? 1 : 0;
     const bool vec = lda % 4 == 0 && aligned16(A);
+    if (pack_slots && !(a.vec_out && vec && (H || hbits) && Nc % 64 == 0 && pack_halves * 64 == Nc)) return -1;
     const int nt_total = ceil_div(Nc, 16);
     const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 3 ? 4 : nt_total));
     const int gy = ceil_div(nt_total, NT);
@@ -429,6 +495,26 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
             if (vec) RS1(NT_, true, false); else RS1(NT_, false, false);                                  \
         }                                                                                                 \
     } while (0)
+#define RSP2(NT_, K_)                                                                                     \
+    do {                                                                                                  \
+        auto kern = gemm_rowstream_kernel<NT_, true, true, K_, true>;                                     \
+        if (lds > 64 * 1024)                                                                              \
+            GCNHIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<grid, 256, lds, c->stream>>>(a);                                                           \
+    } while (0)
+#define RSP(NT_)                                                                                          \
+    do {                                                                                                  \
+        switch (Kp <= 128 ? Kp / 16 : 0) {                                                                \
+            case 1: RSP2(NT_, 1); break;                                                                  \
+            case 2: RSP2(NT_, 2); break;                                                                  \
+            case 3: RSP2(NT_, 3); break;                                                                  \
+            case 4: RSP2(NT_, 4); break;                                                                  \
+            default: RSP2(NT_, 0); break;                                                                 \
+        }                                                                                                 \
+    } while (0)
+    if (pack_slots) {
+        if (NT == 4) RSP(4); else RSP(8);
+    } else
     switch (NT) {
         case 1: RS(1); break;
         case 2: RS(2); break;
@@ -436,6 +522,8 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
         case 4: RS(4); break;
         default: RS(8); break;
     }
+#undef RSP
+#undef RSP2
 #undef RS
 #undef RS1
 #undef RS2

@@ -20,8 +20,9 @@
 //  * the ReLU + dropout of the first layer is an optional store epilogue.
 // The reference launches one block per row with `dim` threads and does a
 // global read-modify-write per edge (cuda_kernel.cu:126-143).
-#include "common.h"
+#include "dense_kernels.h"
 #include <algorithm>
+#include <string.h>
 
 struct GsArgs {
     const int *indptr, *indices;
@@ -157,6 +158,122 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
             }
         }
     }
+}
+
+// ---- packed rows, exact f32 (the backward of the hidden layer) ---------------------------------------
+// The gathered matrix is dH1 = mask . (dZ0 . W2^T): three quarters of it are zeros whose positions are known
+// (ReLU and dropout of H1).  Its producer (gemm_rowstream, PACK) writes every 64-column half of a row as one
+// 128-byte slot — 64-bit mask + the masked-in values in column order — so an edge costs ONE line per half
+// instead of two, with the f32 values untouched.  Work split exactly as graphsum_vec_kernel<8>: 8 lane groups
+// of 8 lanes, edge k*8+g of a 64-edge chunk goes to group g, groups combined by the same xor tree — so every
+// output element sees the same non-zero terms in the same order and the result is bit-identical to the dense
+// gather (adding c * 0 never changes a sum that started at +0).
+// A group loads its slot as 8 x 16 bytes (one request), parks it in the wave's LDS scratch, reads the mask back
+// (broadcast) and then each lane picks the values of its 8 columns: position = popcount of the mask below them.
+__global__ __launch_bounds__(256) void graphsum_packed_kernel(GsArgs a, const uint32_t *__restrict__ slots, int halves) {
+    __shared__ uint4 stage[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int t, half;
+    {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        half = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
+        const int g_id = xcd / a.n_slices;
+        t = a.bounds[g_id] + q * 4 + wave;
+        if (t >= a.bounds[g_id + 1]) return;               // wave-uniform
+    }
+    int row, e0, e1, slot;
+    if (a.n_tasks) {
+        const int4 tk = a.tasks[t];
+        row = tk.x; e0 = tk.y; e1 = tk.z; slot = tk.w;
+    } else {
+        row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
+    }
+    const int g = lane >> 3, l = lane & 7;
+    const uint32_t *sbase = slots + (size_t)half * 32 + l * 4;
+    const size_t row_stride = (size_t)halves * 32;
+    const uint32_t *mine = reinterpret_cast<const uint32_t *>(&stage[wave][g * 8]);
+    const uint32_t sh8 = 8u * (l & 3);                                            // this lane's byte inside its mask word
+    const uint32_t below_lo = l < 4 ? (1u << (8 * l)) - 1u : 0xFFFFFFFFu;         // mask bits of the columns before this lane's
+    const uint32_t below_hi = l < 4 ? 0u : (1u << (8 * (l - 4))) - 1u;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.f;
+    for (int base = e0; base < e1; base += WAVE) {
+        const int cnt = min(WAVE, e1 - base);
+        int my_idx = 0;
+        float my_c = 0.f;
+        if (lane < cnt) {
+            my_idx = a.indices[base + lane];
+            my_c = a.coef[base + lane];
+        }
+        const int iters = (cnt + 7) >> 3;
+        // PACKED_U edges per lane group in flight: their slot loads are issued together, then each is parked in LDS and
+        // decoded without branches (a branch per column serialises the loop: one load in flight per wave)
+        constexpr int PACKED_U = 4;
+        for (int k0 = 0; k0 < iters; k0 += PACKED_U) {
+            uint4 piece[PACKED_U];
+            int jj[PACKED_U];
+            float cc[PACKED_U];
+#pragma unroll
+            for (int u = 0; u < PACKED_U; u++) {
+                const int src = (k0 + u) * 8 + g;              // >= 64 wraps in the shuffle; masked by `on`
+                jj[u] = __shfl(my_idx, src & 63, WAVE);
+                cc[u] = __shfl(my_c, src & 63, WAVE);
+                const bool on = src < cnt;
+                piece[u] = make_uint4(0u, 0u, 0u, 0u);         // empty mask: contributes nothing
+                if (on) piece[u] = *reinterpret_cast<const uint4 *>(sbase + (size_t)jj[u] * row_stride);
+            }
+#pragma unroll
+            for (int u = 0; u < PACKED_U; u++) {
+                stage[wave][lane] = piece[u];
+                __builtin_amdgcn_wave_barrier();
+                // 32-bit arithmetic only; per column: rank below it (and + bcnt), LDS address, read, bit -> all-ones,
+                // and, fmac.  A masked-out column adds c * (+0), exactly what the dense gather adds there.
+                const uint32_t mlo = mine[0], mhi = mine[1];
+                const int n_half = __popc(mlo) + __popc(mhi);
+                const bool fits = n_half <= PACK_CAP;
+                const uint32_t bits8 = fits ? ((l < 4 ? mlo : mhi) >> sh8) & 0xFFu : 0u;
+                const int off0 = fits ? 2 + __popc(mlo & below_lo) + __popc(mhi & below_hi) : 0;
+                const float c = cc[u];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int off = off0 + __popc(bits8 & ((1u << i) - 1u));          // <= 31 when the half fits
+                    const uint32_t keep = (uint32_t)(((int32_t)(bits8 << (31 - i))) >> 31);   // bit i -> 0 or ~0
+                    acc[i] = fmaf(c, __uint_as_float(mine[off] & keep), acc[i]);
+                }
+                if (!fits) {                                   // this half did not fit its slot: dense image (rare)
+                    const float *d = a.in + (size_t)jj[u] * a.ld_in + half * 64 + 8 * l;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(d), v1 = *reinterpret_cast<const float4 *>(d + 4);
+                    acc[0] = fmaf(c, v0.x, acc[0]); acc[1] = fmaf(c, v0.y, acc[1]); acc[2] = fmaf(c, v0.z, acc[2]); acc[3] = fmaf(c, v0.w, acc[3]);
+                    acc[4] = fmaf(c, v1.x, acc[4]); acc[5] = fmaf(c, v1.y, acc[5]); acc[6] = fmaf(c, v1.z, acc[6]); acc[7] = fmaf(c, v1.w, acc[7]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int m = 8; m < WAVE; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
+    if (g == 0) {
+        const int col0 = half * 64 + 8 * l;
+        float *o = slot >= 0 ? a.partials + (size_t)slot * a.part_ld + col0 : a.out + (size_t)row * a.ld_out + col0;
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// slots -> dense image (tests, introspection): halves that fit are written from their slot, the others are already dense
+__global__ __launch_bounds__(256) void rowpack_expand_kernel(const uint32_t *__restrict__ slots, int halves, int64_t n_half_rows,
+                                                             float *__restrict__ dense, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_half_rows) return;
+    const uint32_t *s = slots + i * 32;
+    const uint64_t m = (uint64_t)s[0] | ((uint64_t)s[1] << 32);
+    if (__popcll(m) > PACK_CAP) return;
+    float *d = dense + (i / halves) * ld + (i % halves) * 64;
+    int off = 2;
+    for (int c = 0; c < 64; c++) d[c] = ((m >> c) & 1ull) ? __uint_as_float(s[off++]) : 0.f;
 }
 
 // ---- bf16 table, f32 accumulate (opt-in storage format) ------------------------
@@ -480,6 +597,63 @@ int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const flo
                                  const uint8_t *keep_mask) {
     if (training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 1, training, p, seed, d_epoch, elem_offset, keep_mask);
+}
+
+int gcnhip_rowpack_create(gcnhip_ctx *c, gcnhip_rowpack **out, int rows, int cols) {
+    if (!c || !out || rows < 0 || cols < 64 || cols % 64 != 0) return -1;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    gcnhip_rowpack *p = new gcnhip_rowpack();
+    p->rows = rows; p->cols = cols; p->halves = cols / 64; p->slots = nullptr;
+    const size_t bytes = (size_t)std::max(rows, 1) * p->halves * 128;
+    hipError_t e = hipMalloc((void **)&p->slots, bytes);
+    if (e != hipSuccess) { delete p; return (int)e; }
+    e = hipMemsetAsync(p->slots, 0, bytes, c->stream);      // empty masks: every row reads as zero until it is written
+    if (e != hipSuccess) { hipFree(p->slots); delete p; return (int)e; }
+    *out = p;
+    return 0;
+}
+int gcnhip_rowpack_destroy(gcnhip_ctx *c, gcnhip_rowpack *p) {
+    if (!p) return 0;
+    hipSetDevice(c->device);
+    if (p->slots) hipFree(p->slots);
+    delete p;
+    return 0;
+}
+int gcnhip_rowpack_expand(gcnhip_ctx *c, const gcnhip_rowpack *p, float *dense, int ld) {
+    if (!c || !p || !dense || ld < p->cols) return -1;
+    const int64_t n = (int64_t)p->rows * p->halves;
+    if (n == 0) return 0;
+    rowpack_expand_kernel<<<ceil_div(n, 256), 256, 0, c->stream>>>(p->slots, p->halves, n, dense, ld);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int gcnhip_graphsum_packed(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_rowpack *p, const float *dense, int ld_dense,
+                           float *out, int ld_out) {
+    if (!c || !g || !p || !dense || !out || p->rows != g->n_cols || ld_dense < p->cols || ld_out < p->cols) return -1;
+    if (ld_dense % 4 != 0 || ld_out % 4 != 0 || !aligned16(dense) || !aligned16(out)) return -1;
+    if (g->n_rows == 0) return 0;
+    if (g->n_slots && g->part_ld < p->cols) return -1;
+    GsArgs a;
+    memset(&a, 0, sizeof a);
+    a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
+    a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows;
+    a.in = dense; a.out = out; a.partials = g->partials;
+    a.ld_in = ld_dense; a.ld_out = ld_out; a.part_ld = g->part_ld; a.dim = p->cols;
+    const bool sliced = p->halves > 1 && 8 % p->halves == 0;
+    a.n_slices = sliced ? p->halves : 1;
+    const int G = 8 / a.n_slices;
+    const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
+    int max_blocks = 1;
+    for (int k = 0; k <= 8; k++) a.bounds[k] = g->bounds[lg][k];
+    for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
+    graphsum_packed_kernel<<<dim3(max_blocks * 8, sliced ? 1 : p->halves), 256, 0, c->stream>>>(a, p->slots, p->halves);
+    GCNHIP_LAUNCH_CHECK();
+    if (g->n_split_rows) {
+        graphsum_finalize_kernel<<<g->n_split_rows, 256, 0, c->stream>>>(a, g->split_rows, g->n_split_rows);
+        GCNHIP_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 int gcnhip_f32_to_bf16(gcnhip_ctx *c, const float *src, int ld_src, uint16_t *dst, int ld_dst, int64_t rows, int dim) {

@@ -47,6 +47,21 @@ int gcnhip_matmul_bwd_fused(gcnhip_ctx *c, const float *a, int lda, const float 
     return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, da, ldda, db, lddb, m, n, p, 1, relu_dropout_scale);
 }
 
+// the same with da leaving as packed rows (dense_kernels.h): da_dense receives only the halves that do not fit a slot
+int gcnhip_matmul_bwd_packed(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                             const float *dc, int lddc, float *da_dense, int ldda, gcnhip_rowpack *pack,
+                             float *db, int lddb, int m, int n, int p, float relu_dropout_scale) {
+    if (!c || !a || !b || !dc || !da_dense || !pack || m < 0 || n <= 0 || p <= 0 || lda < n || ldb < p || lddc < p || ldda < n) return -1;
+    if (pack->rows != m || pack->cols != n) return -1;
+    if (db && lddb < p) return -1;
+    if (m == 0) return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, nullptr, 0, db, lddb, m, n, p, 0, 1.f);
+    if (db) {
+        const int rc = launch_atb(c, a, lda, dc, lddc, db, lddb, m, n, p, 0, 0.f, 0, nullptr, 0, nullptr);
+        if (rc) return rc;
+    }
+    return launch_rowstream(c, dc, lddc, b, ldb, 1, da_dense, ldda, m, p, n, a, lda, relu_dropout_scale, nullptr, 0, pack->slots, pack->halves);
+}
+
 // da for ALL m rows from a bit mask instead of the forward activations (multi-GPU: every rank rebuilds the
 // whole dH1 from the gathered dZ0 and 1 bit per element of H1, instead of gathering dH1 itself)
 int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *c, const float *b, int ldb, const float *dc, int lddc,

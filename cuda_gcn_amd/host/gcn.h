@@ -45,6 +45,7 @@ enum HipGCNFlags {
     HIPGCN_NO_AGG_FIRST_EVAL = 8192, // evaluation forwards keep the reference's order A^.(X.W1) instead of (A^.X).W1 with A^.X built once
     HIPGCN_EXCHANGE_ALLGATHER = 16384, // multi-GPU: always all-gather whole row blocks before an aggregation
     HIPGCN_EXCHANGE_HALO = 32768,      // ... or always exchange only the rows some local edge points at (default: decided per graph)
+    HIPGCN_PACKED_DH1 = 65536,         // opt-in: dH1 reaches the hidden layer's backward gather as packed rows (same bits; measured slower)
     HIPGCN_NULL_COMM = 1024,     // world > 1 without transport: collectives are no-ops (per-rank compute timing only)
     HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
 };
@@ -129,7 +130,8 @@ private:
     const float *full_vals = nullptr;
     bool replicate_l1 = false;
     bool rebuild_dh1 = false;                                  // multi-GPU backward: gather dZ0 + mask bits, rebuild dH1 everywhere
-    uint32_t *d_pos_bits = nullptr;                            // [world * rows_max * wpr]
+    uint32_t *d_pos_bits = nullptr;                            // [table_rows * wpr]
+    gcnhip_rowpack *dh1_pack = nullptr;                        // dH1 as packed rows (single GPU, hidden % 64 == 0)
     std::vector<std::unique_ptr<HipVariable>> variables;       // index = reference variable number
     HipVariable *input = nullptr, *output = nullptr;
     const float *input_vals = nullptr;                         // what SparseMatmul reads

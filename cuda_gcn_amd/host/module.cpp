@@ -25,7 +25,10 @@ void HipMatmul::backward() {
         env->timers->start(TMR_MATMUL_BW);
         GCNHIP_CHECK(gcnhip_matmul_bwd_da_bits(env->ctx, b->data, b->ld, c->full_grad, c->ld, a->full_grad, a->ld,
                                                all_rows, n, p, pos_bits_full, wpr, fused_bwd_scale));
-    } else if (fused_bwd_scale > 0.f)
+    } else if (fused_bwd_scale > 0.f && da_pack)
+        GCNHIP_CHECK(gcnhip_matmul_bwd_packed(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
+                                              a->grad, a->ld, da_pack, b->grad, b->ld, m, n, p, fused_bwd_scale));
+    else if (fused_bwd_scale > 0.f)
         GCNHIP_CHECK(gcnhip_matmul_bwd_fused(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                              a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale));
     else
@@ -183,7 +186,9 @@ void HipGraphSum::backward() {
     const float *src = out->full_grad ? out->full_grad : out->grad;
     env->timers->start(TMR_GRAPHSUM_BW);
     if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-    if (row_bits)
+    if (out_grad_pack)
+        GCNHIP_CHECK(gcnhip_graphsum_packed(env->ctx, graph, out_grad_pack, src, out->ld, in->grad, in->ld));
+    else if (row_bits)
         GCNHIP_CHECK(gcnhip_graphsum_rowmask(env->ctx, graph, src, out->ld, in->grad, in->ld, dim, row_bits));
     else
         GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, out->ld, in->grad, in->ld, dim));

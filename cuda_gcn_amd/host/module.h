@@ -51,6 +51,9 @@ public:
     // one bit per element of a > 0, and every rank rebuilds da for ALL rows (gcnhip_matmul_bwd_da_bits)
     const uint32_t *pos_bits_full = nullptr;    // [all_rows x wpr], gathered by the producer of `a`
     int wpr = 0, all_rows = 0;
+    // single GPU, fused backward: da leaves as packed rows (gcnhip_matmul_bwd_packed); a->grad keeps only the halves
+    // that do not fit a slot.  The consumer is the GraphSum that owns the same pack.
+    gcnhip_rowpack *da_pack = nullptr;
     HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
     void forward(bool) override;
     void backward() override;
@@ -94,7 +97,9 @@ public:
     const uint32_t *const *bwd_row_bits = nullptr;
     // rows of `out` that the consumer reads in forward() (bit = 1); the others are not computed.  NULL: all rows.
     // The last aggregation sets it: loss and accuracy read only rows of the scored split (module.cpp:131-133).
-    gcnhip_rowset *const *fwd_out_rows = nullptr;              // a subset registered on `graph` (gcnhip_graph_add_rowset)
+    gcnhip_rowset *const *fwd_out_rows = nullptr;
+    // backward(): out->grad arrives as packed rows (written by HipMatmul::backward into the same pack)
+    gcnhip_rowpack *out_grad_pack = nullptr;              // a subset registered on `graph` (gcnhip_graph_add_rowset)
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
     ~HipGraphSum() override;

@@ -275,6 +275,32 @@ class Device:
                                                             m, n, p, fused_scale), "gcnhip_matmul_bwd_fused")
         return da.download()[:, :n], db.download()[:, :p]
 
+    def packed_backward_gather(self, g: "Graph", h, b, dc, scale):
+        """The hidden layer's backward through packed rows: da = (h > 0) ? scale * dc . b^T : 0 written as packed rows
+        (gcnhip_matmul_bwd_packed), then out = A^ . da gathered from the slots (gcnhip_graphsum_packed).
+        Returns (da expanded to dense by gcnhip_rowpack_expand, db, out, number of half rows that did not fit a slot)."""
+        h, b, dc = (np.asarray(t, np.float32) for t in (h, b, dc))
+        m, n = h.shape
+        p = b.shape[1]
+        ldp = (p + 3) // 4 * 4
+        hb, bb, dcb = self.buf(h), self.padded(b, ldp), self.padded(dc, ldp)
+        da = self.buf(np.full((m, n), np.nan, np.float32))
+        db = self.buf(np.full((n, ldp), np.nan, np.float32))
+        pk = C.c_void_p()
+        _ck(self.lib, self.lib.gcnhip_rowpack_create(self.ctx, C.byref(pk), m, n), "gcnhip_rowpack_create")
+        try:
+            _ck(self.lib, self.lib.gcnhip_matmul_bwd_packed(self.ctx, hb.ptr, n, bb.ptr, ldp, dcb.ptr, ldp, da.ptr, n, pk,
+                                                             db.ptr, ldp, m, n, p, scale), "gcnhip_matmul_bwd_packed")
+            out = self.buf(np.full((g.n_rows, n), np.nan, np.float32))
+            g.reserve(n)
+            _ck(self.lib, self.lib.gcnhip_graphsum_packed(self.ctx, g.h, pk, da.ptr, n, out.ptr, n), "gcnhip_graphsum_packed")
+            raw = da.download()
+            overflow = int(np.isfinite(raw).any(axis=1).sum()) if np.isnan(raw).any() else m
+            _ck(self.lib, self.lib.gcnhip_rowpack_expand(self.ctx, pk, da.ptr, n), "gcnhip_rowpack_expand")
+            return da.download(), db.download()[:, :p], out.download(), overflow
+        finally:
+            self.lib.gcnhip_rowpack_destroy(self.ctx, pk)
+
     def pack_positive(self, h, ld=None):
         """bit (r, c) = h[r, c] > 0, 32 columns per little-endian word -> uint32 [rows, ceil(dim/32)]"""
         h = np.asarray(h, np.float32)

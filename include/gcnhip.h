@@ -44,7 +44,8 @@ extern "C" {
 
 typedef struct gcnhip_ctx gcnhip_ctx;       /* device + stream + scratch */
 typedef struct gcnhip_graph gcnhip_graph;
-typedef struct gcnhip_rowset gcnhip_rowset;   /* a registered subset of an adjacency object's rows */   /* prepared adjacency (CUDASparseIndex of the graph) */
+typedef struct gcnhip_rowset gcnhip_rowset;
+typedef struct gcnhip_rowpack gcnhip_rowpack; /* a mostly-zero matrix stored as packed rows (see gcnhip_matmul_bwd_packed) */   /* a registered subset of an adjacency object's rows */   /* prepared adjacency (CUDASparseIndex of the graph) */
 typedef struct gcnhip_feat gcnhip_feat;     /* prepared feature matrix (CUDASparseIndex of X + its values) */
 
 /* ---- context / runtime (replaces the implicit null stream + CUDA_CHECK) ---- */
@@ -216,6 +217,23 @@ int gcnhip_matmul_bwd(gcnhip_ctx *ctx, const float *a, int lda, const float *b, 
 int gcnhip_matmul_bwd_fused(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
                             const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
                             int m, int n, int p, float relu_dropout_scale);
+
+/* Packed dH1 (exact).  ReLU and dropout zero about three quarters of dH1 = mask . (dZ0 . W2^T), at positions known
+ * from H1, and its only reader is the hidden layer's backward aggregation (module.cpp:103-119), which pays per
+ * 128-byte line gathered.  gcnhip_matmul_bwd_packed is gcnhip_matmul_bwd_fused writing every 64-column half of a row
+ * as ONE 128-byte slot (64-bit mask + the masked-in f32 values in column order, at most 30); a half with more
+ * masked-in columns is written to da_dense as usual and its slot holds only the mask.  gcnhip_graphsum_packed gathers
+ * from the slots (falling back to `dense` for halves that did not fit): half the lines per edge, and — same lane
+ * groups, same order of the non-zero terms — bit-identical to gcnhip_graphsum on the dense matrix.  cols % 64 == 0.
+ * gcnhip_rowpack_expand rebuilds the dense image in place (tests, introspection). */
+int gcnhip_rowpack_create(gcnhip_ctx *ctx, gcnhip_rowpack **p, int rows, int cols);
+int gcnhip_rowpack_destroy(gcnhip_ctx *ctx, gcnhip_rowpack *p);
+int gcnhip_rowpack_expand(gcnhip_ctx *ctx, const gcnhip_rowpack *p, float *dense, int ld);
+int gcnhip_matmul_bwd_packed(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
+                             const float *dc, int lddc, float *da_dense, int ldda, gcnhip_rowpack *pack,
+                             float *db, int lddb, int m, int n, int p, float relu_dropout_scale);
+int gcnhip_graphsum_packed(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_rowpack *p, const float *dense, int ld_dense,
+                           float *out, int ld_out);
 
 /* Multi-GPU form of the same backward.  dH1 = mask . (dZ0 . W2^T) is cheap to recompute and 128 floats wide,
  * while its inputs are 48 floats (dZ0) and 1 bit per element (mask = H1 > 0): ranks all-gather those and each

@@ -48,6 +48,8 @@ enum {
     GCNHOST_EXCHANGE_ALLGATHER = 16384, /* multi-GPU: always all-gather whole row blocks before an aggregation */
     GCNHOST_EXCHANGE_HALO = 32768,      /* ... or always exchange only the needed rows, peer to peer (default: decided per graph;
                                            env HIPGCN_EXCHANGE=halo|allgather) */
+    GCNHOST_PACKED_DH1 = 65536,       /* opt-in: dH1 travels to the hidden layer's backward gather as packed rows (bit-identical to the
+                                         dense gather, measured slower on gfx950; env HIPGCN_PACKED_DH1=1 does the same) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 

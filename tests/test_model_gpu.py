@@ -294,6 +294,23 @@ def test_aggregate_first_eval_matches_reference_order(name, hidden):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,hidden", [("reddit-mini", 128), ("cora-syn", 64)])
+def test_packed_dh1_is_bit_identical_to_dense(name, hidden):
+    """dH1 travelling as packed rows from the Matmul backward to the hidden layer's backward aggregation changes
+    no bit of any weight or reported number"""
+    from cuda_gcn_amd.model import HipGCNModel, PACKED_DH1
+    ds = datagen.make_dataset(name)
+    a = HipGCNModel(ds, seed=8, hidden_dim=hidden, dropout=0.5, epochs=12)
+    b = HipGCNModel(ds, seed=8, flags=PACKED_DH1, hidden_dim=hidden, dropout=0.5, epochs=12)
+    ta, tb = a.run_epochs(10), b.run_epochs(10)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert a.train_epoch() == b.train_epoch()
+    assert np.array_equal(a.var(2).view(np.uint32), b.var(2).view(np.uint32))
+    assert np.array_equal(a.var(3, True).view(np.uint32), b.var(3, True).view(np.uint32))     # dH1 itself (expanded)
+    assert np.array_equal(a.var(1, True).view(np.uint32), b.var(1, True).view(np.uint32))     # dH0 = A^ . dH1
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""

@@ -188,6 +188,35 @@ def test_gather_rows_packs_exactly(dev, ld):
     assert dev.gather_rows(x, rows[:0]).shape == (0, ld)
 
 
+@pytest.mark.parametrize("gname", ["cora-syn", "hub"])
+@pytest.mark.parametrize("n,density", [(128, 0.25), (64, 0.25), (256, 0.3), (128, 0.6), (128, 1.0), (128, 0.0)])
+def test_packed_rows_backward_is_bit_identical_to_dense(dev, gname, n, density):
+    """dH1 as packed rows (gcnhip_matmul_bwd_packed + gcnhip_graphsum_packed) against the dense path
+    (gcnhip_matmul_bwd_fused + gcnhip_graphsum): the same bits, whatever share of the halves overflows their slot
+    (density 0.6: most halves hold more than 30 values; 1.0: all of them; 0.0: empty masks)"""
+    gp, gi = hub_graph() if gname == "hub" else (lambda d: (d["g_indptr"], d["g_indices"]))(datagen.make_dataset(gname))
+    m = gp.size - 1
+    rng = np.random.default_rng(n + int(density * 100))
+    p = 41
+    h = np.where(rng.random((m, n)) < density, rng.random((m, n)) + 0.1, 0.0).astype(np.float32)   # the forward output: > 0 where kept
+    h[5] = 0.0                                                # an empty row
+    if density > 0:
+        h[7, :] = 1.0                                         # a full row (both halves overflow)
+        h[9, :64] = 1.0                                       # one half overflows, the other does not
+    b = rng.standard_normal((n, p)).astype(np.float32)
+    dc = rng.standard_normal((m, p)).astype(np.float32)
+    g = dev.graph(gp, gi)
+    da_ref, db_ref = dev.matmul_bwd(h, b, dc, fused_scale=2.0)
+    out_ref = dev.graphsum(g, da_ref)
+    da, db, out, overflow = dev.packed_backward_gather(g, h, b, dc, 2.0)
+    assert np.array_equal(da.view(np.uint32), da_ref.view(np.uint32))
+    assert np.array_equal(db.view(np.uint32), db_ref.view(np.uint32))
+    assert np.array_equal(out.view(np.uint32), out_ref.view(np.uint32))
+    if 0 < density <= 0.3 and n == 128:
+        assert 0 < overflow < m / 4                          # the planted rows, and few others
+    g.free()
+
+
 def test_edge_coef_bit_exact(dev):
     ds = datagen.make_dataset("cora-syn")
     gp, gi = ds["g_indptr"], ds["g_indices"]
