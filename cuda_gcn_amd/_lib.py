@@ -123,6 +123,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_dropout_bwd_2d": (I, [P, P, I, I, I, P, F]),
     "gcnhip_relu_dropout_bwd": (I, [P, P, I, P, I, I, I, F]),
     "gcnhip_xent_fwd": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P]),
+    "gcnhip_xent_fwd_rows": (I, [P, P, I, P, I, P, P, I, I, I, I, I, P, P]),
     "gcnhip_accuracy": (I, [P, P, I, P, I, I, P]),
     "gcnhip_set_truth": (I, [P, P, P, P, I, I]),
     "gcnhip_sumsq": (I, [P, P, I64, P]),

@@ -15,6 +15,7 @@ struct XentArgs {
     int training, shift, acc_only;
     int count;                 // > 0: known number of labelled rows
     const int32_t *d_count;    // else read here
+    const int32_t *rows;       // optional: only these rows (all labelled) are visited, n_rows = their number
     float *part_f;             // [blocks] loss partials
     int32_t *part_i;           // [blocks*2] {correct, total}
 };
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
     // Reddit scale; without the prefetch every row paid a full memory latency: 90 us for 233 K rows)
     float nv[XENT_MAXC_REG];
     int nt = -1;
-    auto prefetch = [&](int r) {
+    auto prefetch = [&](int q) {
+        const int r = a.rows ? a.rows[q] : q;
         nt = a.truth[r];
         const float *lg = a.logits + (size_t)r * a.ld;
 #pragma unroll
@@ -52,12 +54,13 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
         }
     };
     if (r0 < r1) prefetch(r0);
-    for (int r = r0; r < r1; r++) {
+    for (int q = r0; q < r1; q++) {
+        const int r = a.rows ? a.rows[q] : q;
         const int t = nt;
         float v[XENT_MAXC_REG];
 #pragma unroll
         for (int q = 0; q < XENT_MAXC_REG; q++) v[q] = nv[q];
-        if (r + 1 < r1) prefetch(r + 1);
+        if (q + 1 < r1) prefetch(q + 1);
         float *lg = a.logits + (size_t)r * a.ld;
         float *gr = a.grad ? a.grad + (size_t)r * a.ld_grad : nullptr;
         if (t < 0) {                                   // unlabelled: grad row stays 0 (module.cpp:129,132)
@@ -197,7 +200,21 @@ int gcnhip_xent_fwd(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_gr
     a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_rows; a.C = num_classes;
     a.training = training; a.shift = shift_in_place; a.acc_only = 0;
-    a.count = count; a.d_count = nullptr;
+    a.count = count; a.d_count = nullptr; a.rows = nullptr;
+    return xent_launch(c, a, d_result, d_result_i);
+}
+
+int gcnhip_xent_fwd_rows(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_grad,
+                         const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
+                         int count, int shift_in_place, float *d_result, int32_t *d_result_i) {
+    if (!c || !logits || !truth || !d_result || num_classes <= 0 || ld < num_classes || n_listed < 0 || count <= 0) return -1;
+    if (n_listed > 0 && !d_rows) return -1;
+    if (training && (!grad || ld_grad < num_classes)) return -1;
+    XentArgs a;
+    a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
+    a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_listed; a.C = num_classes;
+    a.training = training; a.shift = shift_in_place; a.acc_only = 0;
+    a.count = count; a.d_count = nullptr; a.rows = d_rows;
     return xent_launch(c, a, d_result, d_result_i);
 }
 
@@ -207,7 +224,7 @@ int gcnhip_accuracy(gcnhip_ctx *c, const float *logits, int ld, const int32_t *t
     XentArgs a;
     a.logits = const_cast<float *>(logits); a.grad = nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = 0; a.n_rows = n_rows; a.C = num_classes;
-    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr;
+    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr; a.rows = nullptr;
     return xent_launch(c, a, nullptr, d_result_i);
 }
 

@@ -155,6 +155,16 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // one registered row subset per split.
     if (getenv("HIPGCN_ALL_ROWS")) flags |= HIPGCN_ALL_ROWS;
     if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(env.ctx, graph, split_rows);
+    if (!(flags & HIPGCN_MODULAR)) {
+        // the loss walks the rows of the scored split only (it skips the others anyway, module.cpp:131-133)
+        for (int s = 1; s <= 3; s++) {
+            std::vector<int32_t> rows;
+            for (int r = 0; r < n_local; r++)
+                if (data->split[r0 + r] == s) rows.push_back(r);
+            split_local_n[s] = (int)rows.size();
+            d_split_list[s] = dev_upload(env.ctx, rows.data(), rows.size());
+        }
+    }
 
     // training-split bit per table row (= node, on one GPU): dZ is zero elsewhere, GraphSum's backward skips those rows
     {
@@ -357,7 +367,9 @@ void HipGCN::build_modules() {
         modules.push_back(gs);
         modules.push_back(mm);
         { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->fwd_out_rows = &cur_out_rows; modules.push_back(gs); }
-        modules.push_back(new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false));
+        auto *ce = new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false);
+        ce->rows_list = &cur_rows; ce->rows_n = &cur_rows_n;
+        modules.push_back(ce);
     }
 }
 
@@ -468,7 +480,11 @@ void HipGCN::build_eval_lane() {
     }
     L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
     { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_rows = &L.out_rows; L.modules.push_back(gs); }
-    L.modules.push_back(new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false));
+    {
+        auto *ce = new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false);
+        ce->rows_list = &L.rows; ce->rows_n = &L.rows_n;
+        L.modules.push_back(ce);
+    }
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_weights));
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_done));
     GCNHIP_CHECK(gcnhip_ctx_sync(L.env.ctx));
@@ -527,6 +543,7 @@ void HipGCN::release() {
     gcnhip_free(env.ctx, d_keep0);
     gcnhip_free(env.ctx, d_keep1);
     gcnhip_free(env.ctx, d_train_bits);
+    for (int s = 1; s <= 3; s++) gcnhip_free(env.ctx, d_split_list[s]);
     gcnhip_free(env.ctx, d_pos_bits);
     if (dh1_pack) gcnhip_rowpack_destroy(env.ctx, dh1_pack);
     timers.reset();
@@ -563,6 +580,8 @@ void HipGCN::set_truth(int s) {                 // gcn.cpp:78-81: here a pointer
     cur_truth = d_truth[s];
     cur_count = split_count[s];
     cur_out_rows = split_rows[s];
+    cur_rows = d_split_list[s];
+    cur_rows_n = split_local_n[s];
 }
 
 // replay the reference's RNG consumption for one training epoch: nnzX draws for
@@ -630,6 +649,8 @@ void HipGCN::lane_begin(int s) {
     L.truth = d_truth[s];
     L.count = split_count[s];
     L.out_rows = L.split_rows[s];
+    L.rows = d_split_list[s];
+    L.rows_n = split_local_n[s];
 }
 
 void HipGCN::lane_end(int s) {

@@ -148,6 +148,10 @@ private:
     const uint32_t *bwd_bits = nullptr;
     gcnhip_rowset *split_rows[4] = {};                         // rows of `graph` whose node is in split s (all the loss reads); owned by graph
     gcnhip_rowset *cur_out_rows = nullptr;                     // follows set_truth; NULL with HIPGCN_ALL_ROWS
+    int32_t *d_split_list[4] = {};                             // local row ids of split s, ascending (the loss walks only these)
+    int split_local_n[4] = {};
+    int32_t *cur_rows = nullptr;
+    int cur_rows_n = 0;
     int split_count[4] = {};
     int cur_count = 0;
     float *d_ring = nullptr;
@@ -176,6 +180,8 @@ private:
         int32_t *truth = nullptr;
         gcnhip_rowset *split_rows[4] = {};                     // the lane has its own adjacency object
         gcnhip_rowset *out_rows = nullptr;
+        int32_t *rows = nullptr;
+        int rows_n = 0;
         int count = 0;
         void *ev_weights = nullptr, *ev_done = nullptr;        // Adam(e) -> eval(e);  eval(e) -> Adam(e+1)
         bool pending = false;

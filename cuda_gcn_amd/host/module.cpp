@@ -204,6 +204,10 @@ HipCrossEntropyLoss::HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32
 
 void HipCrossEntropyLoss::forward(bool training) {
     env->timers->start(TMR_LOSS_FW);
+    if (rows_list && *rows_list && *count > 0)
+        GCNHIP_CHECK(gcnhip_xent_fwd_rows(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, *rows_list, *rows_n,
+                                          num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i));
+    else
     GCNHIP_CHECK(gcnhip_xent_fwd(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, logits->rows,
                                  num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i));
     env->timers->stop(TMR_LOSS_FW);

@@ -124,6 +124,10 @@ class HipCrossEntropyLoss : public Module {
     int num_classes;
     bool shift_in_place;
 public:
+    // rows of the current split on this rank (ascending) and their number: only they are visited (the other rows'
+    // gradients are zero from allocation on).  NULL: every row is visited, as the reference does.
+    int32_t *const *rows_list = nullptr;
+    const int *rows_n = nullptr;
     HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32_t *const *truth, const int *count,
                         float *d_result, int32_t *d_result_i, int num_classes, bool shift_in_place);
     void forward(bool) override;

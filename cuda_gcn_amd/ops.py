@@ -375,6 +375,23 @@ class Device:
         return dict(loss_sum=float(r[0]), count=float(r[1]), correct=int(ri[0]), total=int(ri[1]),
                     logits=lb.download()[:, :c], grad=gb.download()[:, :c] if training else None)
 
+    def xent_fwd_rows(self, logits, truth, training=True, shift_in_place=False, ld=None, grad_fill=0.0):
+        """gcnhip_xent_fwd_rows over the list of labelled rows; grad rows outside the list keep grad_fill"""
+        logits = np.asarray(logits, np.float32)
+        truth = np.ascontiguousarray(truth, np.int32)
+        n, c = logits.shape
+        ld = ld or c
+        rows = np.flatnonzero(truth >= 0).astype(np.int32)
+        lb = self.padded(logits, ld)
+        gb = self.buf(np.full((n, ld), grad_fill, np.float32))
+        tb, rb = self.buf(truth), self.buf(rows if rows.size else np.zeros(1, np.int32))
+        res, resi = self.buf(np.zeros(4, np.float32)), self.buf(np.zeros(2, np.int32))
+        _ck(self.lib, self.lib.gcnhip_xent_fwd_rows(self.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, rb.ptr, int(rows.size), c, int(training),
+                                                     max(int(rows.size), 1), int(shift_in_place), res.ptr, resi.ptr), "gcnhip_xent_fwd_rows")
+        r, ri = res.download(), resi.download()
+        return dict(loss_sum=float(r[0]), count=float(r[1]), correct=int(ri[0]), total=int(ri[1]),
+                    logits=lb.download()[:, :c], grad=gb.download()[:, :c] if training else None)
+
     def accuracy(self, logits, truth, ld=None):
         logits = np.asarray(logits, np.float32)
         n, c = logits.shape

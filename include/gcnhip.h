@@ -301,6 +301,14 @@ int gcnhip_relu_dropout_bwd(gcnhip_ctx *ctx, float *grad, int ld_grad, const flo
 int gcnhip_xent_fwd(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_grad,
                     const int32_t *truth, int n_rows, int num_classes, int training,
                     int count, int shift_in_place, float *d_result, int32_t *d_result_i);
+/* The same over a list of rows known to be labelled (d_rows[n_listed], ascending row ids of one split; count = the
+ * split's size over all ranks): only those rows of logits are read and only those rows of grad are written — the
+ * caller guarantees that every other row of grad is already zero (it is after allocation, and stays so because the
+ * training split never changes).  Losses are added in list order per wave, so the result equals gcnhip_xent_fwd's
+ * to rounding, not bit for bit. */
+int gcnhip_xent_fwd_rows(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_grad,
+                         const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
+                         int count, int shift_in_place, float *d_result, int32_t *d_result_i);
 /* accuracy alone (cuda_gcn.cu:100-120 without the 38 MB D2H) */
 int gcnhip_accuracy(gcnhip_ctx *ctx, const float *logits, int ld, const int32_t *truth,
                     int n_rows, int num_classes, int32_t *d_result_i);

@@ -583,6 +583,13 @@ def test_xent_vs_oracle(dev, oracle, n, c, ld):
             if training:
                 close(r["grad"], grad, rtol=1e-5, atol=1e-8)
     assert dev.accuracy(lg, tr, ld=ld) == np_accuracy(lg, tr)
+    # the list form: only labelled rows are visited; their results are the full pass's, the other grad rows are untouched
+    full = dev.xent_fwd(lg, tr, training=True, count=cnt, shift_in_place=False, ld=ld)
+    lst = dev.xent_fwd_rows(lg, tr, training=True, ld=ld, grad_fill=7.0)
+    lab = tr >= 0
+    assert (lst["correct"], lst["total"]) == (full["correct"], full["total"])
+    assert abs(lst["loss_sum"] - full["loss_sum"]) <= 1e-5 * max(1.0, abs(full["loss_sum"]))
+    assert np.array_equal(lst["grad"][lab], full["grad"][lab]) and np.all(lst["grad"][~lab] == 7.0)
 
 
 def test_xent_golden(dev, mods):
