@@ -15,9 +15,10 @@ N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks
 RANK / WORLD_SIZE are then set), or this file does: a parent that has not
 touched the GPU (no torch import, no native library) starts the N ranks with
 torch.distributed.run as CHILD processes, relays rank 0's JSON line and exits
-with their return code.  A hung child group is killed after GCN_BENCH_TIMEOUT
-seconds (default 900) and, once, started again as fresh children without the
-validation lane.
+with their return code (a hung child group is killed after GCN_BENCH_TIMEOUT
+seconds).  It runs the plain one-stream schedule first, then tries the
+schedule with the validation forward overlapped on a second stream as fresh
+children, and prints the faster valid line.
 
 Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
   * `value` / `ms_per_step`: exactly K epochs, barrier + synchronize on both sides, max over ranks,
@@ -76,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--bf16-tables", action="store_true",
                     help="opt-in, NOT the headline: GraphSum gathers bfloat16 copies of its inputs (f32 sums); reported as dtype f32+bf16-tables")
     ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
-                    help="validation forward on a second stream (auto: only with more than one GPU)")
+                    help="validation forward on a second stream, overlapped with the next training epoch (auto = off)")
     return ap.parse_args(argv)
 
 
@@ -89,43 +90,67 @@ def _free_port():
     return p
 
 
-def launch_ranks(n_gpus, argv):
-    """Parent of an N-rank run.  Runs before torch or any native library is imported: this process
-    never initialises the GPU, it only starts children, so nothing here is an exec from a GPU process."""
-    timeout = float(os.environ.get("GCN_BENCH_TIMEOUT", "900"))
-    attempts = [list(argv), list(argv) + ["--eval-lane", "off"]]        # argparse: the last --eval-lane wins
-    rc = 1
-    for k, extra in enumerate(attempts):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
-        log("starting", n_gpus, "ranks:", " ".join(cmd[1:]))
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+def _run_ranks(n_gpus, extra, timeout):
+    """one group of N rank processes (children of this GPU-free parent); returns (rc, JSON line or None)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
+    log("starting", n_gpus, "ranks:", " ".join(cmd[1:]))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        log(f"ranks still running after {timeout:.0f} s: killing process group {p.pid}")
         try:
-            out, _ = p.communicate(timeout=timeout)
-            rc = p.returncode
-        except subprocess.TimeoutExpired:
-            log(f"ranks still running after {timeout:.0f} s: killing process group {p.pid}")
-            try:
-                os.killpg(p.pid, signal.SIGKILL)       # exactly the group this parent started
-            except ProcessLookupError:
-                pass
-            out, _ = p.communicate()
-            rc = 124
-        line = None
-        for ln in (out or "").splitlines():
-            if ln.startswith("{") and '"metric"' in ln:
-                line = ln
-            else:
-                print(ln, file=sys.stderr)
-        if rc == 0 and line is not None:
-            print(line, flush=True)
-            return 0
-        log(f"attempt {k + 1} failed (rc {rc}{'' if line else ', no JSON line'})")
+            os.killpg(p.pid, signal.SIGKILL)       # exactly the group this parent started
+        except ProcessLookupError:
+            pass
+        out, _ = p.communicate()
+        rc = 124
+    line = None
+    for ln in (out or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if rc == 0 and line is None:
+        rc = 1
+    return rc, line
+
+
+def launch_ranks(n_gpus, argv):
+    """Parent of an N-rank run.  Runs before torch or any native library is imported: this process never
+    initialises the GPU, it only starts children, so nothing here is an exec from a GPU process.
+
+    The row-partitioned epoch exists in two schedules: everything on one stream (`--eval-lane off`: the plain,
+    conservative one) and the validation forward on a second stream / communicator overlapped with the next
+    training epoch (`on`).  Unless the caller chose one, the plain schedule runs first — its line is the safe
+    result — then the overlapped one is tried as fresh children with a short deadline, and the faster valid
+    line is printed (its `config.eval_lane` says which; the other value is kept as `other_schedule`)."""
+    timeout = float(os.environ.get("GCN_BENCH_TIMEOUT", "600"))
+    if "--eval-lane" in argv:
+        rc, line = _run_ranks(n_gpus, list(argv), timeout)
         if rc == 0:
-            rc = 1
-        if "--eval-lane" in argv:                       # the caller chose the lane mode: no second variant to try
-            break
-    return rc
+            print(line, flush=True)
+        return rc
+    rc, line = _run_ranks(n_gpus, list(argv) + ["--eval-lane", "off"], timeout)
+    if rc != 0:
+        log(f"plain schedule failed (rc {rc})")
+        return rc
+    first = json.loads(line)
+    t_try = float(os.environ.get("GCN_BENCH_LANE_TIMEOUT", "240"))
+    rc2, line2 = _run_ranks(n_gpus, list(argv) + ["--eval-lane", "on"], t_try)
+    best = first
+    if rc2 == 0:
+        second = json.loads(line2)
+        lo, hi = sorted((first, second), key=lambda d: d["value"])
+        best = hi
+        best["other_schedule"] = {"eval_lane": lo["config"].get("eval_lane"), "value": lo["value"], "ms_per_step": lo["ms_per_step"]}
+    else:
+        log(f"overlapped schedule failed or timed out (rc {rc2}); keeping the plain schedule's line")
+        best["other_schedule"] = {"eval_lane": "on", "value": None, "failed_rc": rc2}
+    print(json.dumps(best), flush=True)
+    return 0
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline
@@ -278,7 +303,9 @@ def main():
         box = [nccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         nccl_id = box[0]
-    lane_flag = {"auto": 0, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
+    # auto = the plain one-stream schedule: the overlapped one (second stream + split communicator) is opt-in here
+    # until it has been measured on a multi-GPU node; the self-launching parent above tries both
+    lane_flag = {"auto": NO_EVAL_LANE, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
     base_flags = lane_flag | (BF16_TABLES if args.bf16_tables else 0)
     n_epochs_total = args.warmup + args.steps * (2 + args.bursts) + 64
 
@@ -402,6 +429,7 @@ def main():
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": schedule,
+                       "eval_lane": "on" if args.eval_lane == "on" else "off",
                        "exchange": exchange,       # rank 0's view: all-gather of row blocks or halo lists, rows moved per exchange
                        "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
                                        "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",
