@@ -42,7 +42,7 @@ def main():
         deg = np.diff(gp)
         print(f"rmat scale {scale}: N={N} nnzA={gi.size} max_deg={deg.max()} built in {time.time() - t0:.1f}s", flush=True)
         rng = np.random.default_rng(0)
-        variants = [("degree order", None)]
+        variants = [("dealt-256", "dealt")] if not (len(sys.argv) > 4 and sys.argv[4] == "orders") else [("degree order", None)]
         if len(sys.argv) > 4 and sys.argv[4] == "orders":     # which task order suits a graph whose ids carry locality?
             variants += [("random 41 groups", np.random.default_rng(1).integers(0, 41, N).astype(np.int32))]
             variants += [(f"id >> {k}", (np.arange(N, dtype=np.int64) >> k).astype(np.int32)) for k in (16, 12)]
@@ -50,8 +50,10 @@ def main():
             variants += [(f"degree rank dealt into {G} groups", (rank % G).astype(np.int32)) for G in (8, 41, 256, 2048)]
         for tag, groups in variants:
             dev = Device(0); lib = dev.lib
-            g = dev.graph(gp, gi, row_group=groups)
-            for dim in (128, 256, 48):
+            g = dev.graph(gp, gi, row_group=None if isinstance(groups, str) else groups)
+            if isinstance(groups, str):
+                g.set_schedule(2, None, 256)              # the schedule HipGCN picks on R-MAT (and bench.py's HBM-regime leg uses)
+            for dim in ((h,) if (len(sys.argv) > 4 and sys.argv[4] == "only_h") else (128, 256, 48)):
                 x = dev.buf(rng.standard_normal((N, dim), dtype=np.float32)); o = dev.buf((N, dim))
                 d_eff = 41 if dim == 48 else dim
                 ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, dim, o.ptr, dim, d_eff), "gs"), iters=10)
