@@ -80,6 +80,26 @@ def test_trace_dropout_host_masks_vs_oracle(oracle, name, hidden, mode):
     m.close(); om.close()
 
 
+def test_rmat_shaped_model_trace_vs_oracle(oracle):
+    """BASELINE configs[4]'s model shape (R-MAT graph, dense 256 features -> 128 -> 41) at a scale whose largest
+    degree product (9705^2 at scale 16) is still below 2^31, so the reference's int arithmetic (module.cpp:91-93)
+    is defined and the oracle is a valid checker: 6 epochs with the reference's dropout decisions replayed"""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+    ds = datagen.make_dataset("rmat-16-256")
+    assert int(np.diff(ds["g_indptr"]).max()) ** 2 < 2 ** 31
+    om = oracle.model(ds, seed_time=2, hidden_dim=128, dropout=0.5)
+    m = HipGCNModel(ds, seed=2, flags=HOST_MASKS, hidden_dim=128, dropout=0.5, epochs=6)
+    assert m.schedule().startswith("dealt") or m.schedule() == "degree"
+    for e in range(6):
+        got = m.train_epoch() + m.eval(2)
+        want = om.train_epoch() + om.eval(2)
+        assert abs(got[0] - want[0]) <= 2e-4 and abs(got[2] - want[2]) <= 2e-4, (e, got, want)
+        assert abs(got[1] - want[1]) <= 2.0 / int((ds["split"] == 1).sum()) and abs(got[3] - want[3]) <= 2.0 / int((ds["split"] == 2).sum())
+    gt, wt = m.eval(3), om.eval(3)
+    assert abs(gt[0] - wt[0]) <= 2e-4
+    m.close(); om.close()
+
+
 @pytest.mark.parametrize("name,seed,dropout", [("cora-syn", 1, 0.0), ("cora-syn", 2, 0.5), ("citeseer-syn", 1, 0.0),
                                                ("pubmed-syn", 1, 0.5), ("tiny-syn", 3, 0.5)])
 def test_trace_vs_reference_golden(name, seed, dropout):
