@@ -419,7 +419,9 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     int workers = ceil_div((int64_t)c->n_cu * per_cu, (int64_t)gy * gz);
     static const size_t cap_mb = getenv("GCNHIP_ATB_CAP_MB") ? (size_t)atoi(getenv("GCNHIP_ATB_CAP_MB")) : 12;   // experiments
     while (workers > 4 && (size_t)(workers / 4) * slab_per_worker > (cap_mb << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials (one slab per workgroup of 4 workers)
-    if (workers > ceil_div(m, 256)) workers = ceil_div(m, 256);      // at least 64 K-steps per worker
+    // at least 8 K-steps (32 rows) per worker.  (64 until round 2: on a Cora-sized product that left 12 waves with
+    // 57 dependent K-steps each — 41 us of a 126 us epoch; the workgroup-level sum made more workers free.)
+    if (workers > ceil_div(m, 32)) workers = ceil_div(m, 32);
     if (workers < 1) workers = 1;
     workers = (workers + 3) / 4 * 4;
     a.rows_per_worker = (ceil_div(m, workers) + 3) / 4 * 4;

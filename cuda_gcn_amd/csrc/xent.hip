@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void xent_finalize_kernel(const float *part_f,
 
 static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_result_i) {
     if (a.C > XENT_MAXC_REG * WAVE) return -1;
-    int blocks = ceil_div(a.n_rows, 4 * 8);             // ~8 rows per wave
+    int blocks = ceil_div(a.n_rows, 4 * 2);             // ~2 rows per wave on small inputs (each row is a dependent load chain); the cap below decides on large ones
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;                   // part_i holds 2 ints per block in red_i[0, 4096)
     if (a.n_rows == 0) blocks = 1;                      // a rank that owns no rows still reports zeros
