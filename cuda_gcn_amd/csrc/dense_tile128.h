@@ -214,6 +214,97 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
         }
 }
 
+// Eight-wave form of the FAST forward tile (same 128 x 128 x 32 staging, same LDS images, same MFMA and the same
+// k order per output element => identical bits): 512 threads as 4 x 2 waves of 32 x 64, so a wave keeps 32
+// accumulator registers instead of 64 and a SIMD holds twice the waves to feed its MFMA pipe across the two
+// barriers of a K chunk.  Launch sites use it when every FAST condition holds.
+__global__ __launch_bounds__(512) void dense_fwd_t128w8_kernel(Tile128Args a) {
+    __shared__ float As[T_BM * T_ALD];
+    __shared__ __attribute__((aligned(16))) float Bs[T_BK * T_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                // rows 32*wm .. +31, cols 64*wn .. +63
+    const int li = lane & 31, kq = lane >> 5;
+    const int row_base = blockIdx.x * T_BM, col_base = blockIdx.y * T_BN;
+    constexpr int LPR = T_BK / 4;                           // lanes per A row (16 bytes each)
+    constexpr int A_PIECES = T_BM * T_BK / (512 * 4);       // 2
+    float areg[A_PIECES][4];
+    uint64_t kreg[A_PIECES];
+    float4 breg[2];
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 512 + tid;
+            const int r = idx / LPR, c = (idx % LPR) * 4;
+            const int row = min(row_base + r, a.m - 1), col = k0 + c;
+            const float4 v = *reinterpret_cast<const float4 *>(a.x + (size_t)row * a.ldx + col);
+            areg[pc][0] = v.x; areg[pc][1] = v.y; areg[pc][2] = v.z; areg[pc][3] = v.w;
+            if (a.bits) {
+                const uint64_t w = ((uint64_t)row * a.K + col) >> 5;
+                kreg[pc] = (uint64_t)a.bits[w] | ((uint64_t)a.bits[w + 1] << 32);
+            }
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; pc++) {
+            const int idx = (pc * 512 + tid) * 4;
+            const int k = idx / T_BN, c = idx % T_BN;
+            breg[pc] = *reinterpret_cast<const float4 *>(a.w + (size_t)min(k0 + k, a.K - 1) * a.ldw + col_base + c);   // zeroed in stash()
+        }
+    };
+    auto stash = [&](int cur_k0) {
+#pragma unroll
+        for (int pc = 0; pc < A_PIECES; pc++) {
+            const int idx = pc * 512 + tid;
+            const int r = idx / LPR, c = (idx % LPR) * 4;
+            const int brow = min(row_base + r, a.m - 1);
+            const uint32_t kb = a.bits ? (uint32_t)(kreg[pc] >> (uint32_t)(((uint64_t)brow * a.K + cur_k0 + c) & 31)) : 0xFu;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                As[r * T_ALD + c + s] = a.bits ? ((kb >> s & 1u) ? areg[pc][s] * a.scale : 0.f) : areg[pc][s];
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; pc++) {
+            const int idx = (pc * 512 + tid) * 4;
+            float4 v = breg[pc];
+            if (cur_k0 + idx / T_BN >= a.K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&Bs[idx]) = v;
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    fetch(0);
+    for (int k0 = 0; k0 < a.K; k0 += T_BK) {
+        __syncthreads();
+        stash(k0);
+        __syncthreads();
+        if (k0 + T_BK < a.K) fetch(k0 + T_BK);
+        const float *Ap = &As[(wm * 32 + li) * T_ALD + kq];
+        const float *Bp = &Bs[kq * T_BN + wn * 64 + li];
+#pragma unroll
+        for (int kk = 0; kk < T_BK; kk += 2) {
+            const float a0 = Ap[kk];
+            const float b0 = Bp[kk * T_BN], b1 = Bp[kk * T_BN + 32];
+            acc[0] = MFMA32(a0, b0, acc[0]);
+            acc[1] = MFMA32(a0, b1, acc[1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = col_base + wn * 64 + j * 32 + li;
+        if (col >= a.p) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = row_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+            if (row < a.m) a.out[(size_t)row * a.ldo + col] = (a.relu && !(acc[j][r] > 0.f)) ? 0.f : acc[j][r];
+        }
+    }
+}
+
 // -------------------------------------------------------------------- backward
 // grid (S splits of the row range, K tiles of 128 X-columns, p tiles of 128).
 // LDS tiles are k-major exactly as loaded: As[k][xcol], Bs[k][pcol]; both MFMA
@@ -355,3 +446,4 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
             }
         }
 }
+
