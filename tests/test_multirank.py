@@ -56,6 +56,15 @@ def test_partitioned_aggregation_gloo_cpu(name, world):
         assert os.path.exists(out)
 
 
+@pytest.mark.parametrize("name,world", [("cora-syn", 3), ("rmat-11", 8)])
+def test_halo_exchange_point_to_point_gloo_cpu(name, world):
+    """the HALO plan's send / receive lists driven by real point-to-point messages between `world` processes"""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ok.npy")
+        launch(world, ["cpu_halo", name, out])
+        assert os.path.exists(out)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world,dropout,run_async,flags", [
     ("cora-syn", 2, 0.0, 0, 0), ("cora-syn", 2, 0.5, 0, 0), ("tiny-syn", 3, 0.5, 1, 0), ("pubmed-syn", 2, 0.5, 1, 0),
