@@ -487,6 +487,7 @@ void HipGCN::build_eval_lane() {
     }
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_weights));
     GCNHIP_CHECK(gcnhip_event_create(&L.ev_done));
+    GCNHIP_CHECK(gcnhip_event_create(&L.ev_fork));
     GCNHIP_CHECK(gcnhip_ctx_sync(L.env.ctx));
 }
 
@@ -504,6 +505,7 @@ void HipGCN::destroy_lane() {
         gcnhip_free(L.env.ctx, L.d_result); gcnhip_free(L.env.ctx, L.d_result_i); gcnhip_free(L.env.ctx, L.env.d_epoch);
         if (L.ev_weights) gcnhip_event_destroy(L.ev_weights);
         if (L.ev_done) gcnhip_event_destroy(L.ev_done);
+        if (L.ev_fork) gcnhip_event_destroy(L.ev_fork);
         L.timers.reset();
         exchange_buffers_destroy(&L.xbuf);
         L.comm.reset();
@@ -680,6 +682,21 @@ void HipGCN::eval_then_train_zipped(int s) {
     lane_begin(s);
     train_begin();
     const size_t nb = lane->modules.size(), na = modules.size();
+    if (env.comm->size() == 1) {
+        // One GPU: nothing to exchange, so the point of the second stream is to run kernels with different bottlenecks
+        // side by side.  Both passes start with the same MFMA-bound GEMM; the validation pass is therefore released
+        // only when the training GEMM has finished, and its GEMM then shares the chip with the gather-bound
+        // hidden-width aggregation of the training pass.
+        modules[0]->forward(true);
+        GCNHIP_CHECK(gcnhip_event_record(env.ctx, lane->ev_fork));
+        GCNHIP_CHECK(gcnhip_stream_wait_event(lane->env.ctx, lane->ev_fork));
+        for (size_t i = 0; i < nb; i++) lane->modules[i]->forward(false);
+        lane_end(s);
+        for (size_t i = 1; i < na; i++) modules[i]->forward(true);
+        for (int i = (int)na - 1; i >= 0; i--) modules[i]->backward();
+        train_end();
+        return;
+    }
     for (size_t i = 0; i < std::max(na, nb); i++) {
         if (i < nb) lane->modules[i]->forward(false);
         if (i < na) modules[i]->forward(true);

@@ -184,6 +184,7 @@ private:
         int rows_n = 0;
         int count = 0;
         void *ev_weights = nullptr, *ev_done = nullptr;        // Adam(e) -> eval(e);  eval(e) -> Adam(e+1)
+        void *ev_fork = nullptr;                               // one GPU: training GEMM done -> the validation pass may start
         bool pending = false;
         long epoch_word = -1;                                  // host shadow of *env.d_epoch (starts at 0xFFFFFFFF)
     };
