@@ -23,12 +23,13 @@
 #include "dense_kernels.h"
 #include <algorithm>
 #include <string.h>
+#include <stdlib.h>
 
 struct GsArgs {
     const int *indptr, *indices;
     const float *coef;
     const int4 *tasks;
-    int n_tasks, n_rows;
+    int n_tasks, n_rows, nnz;
     const float *in;
     const uint16_t *in_bf;   // bf16 copy of the gathered table (opt-in storage format); row stride ld_in values
     float *out;
@@ -88,6 +89,60 @@ __device__ inline float4 relu_dropout4(float4 v, const GsArgs &a, int64_t r, int
     return make_float4(x[0], x[1], x[2], x[3]);
 }
 
+#ifndef GS_U
+#define GS_U 4
+#endif
+// One chunk of <= 64 edges whose (index, coef) pairs sit in the wave's lanes: acc += sum over the chunk, lane group g
+// taking edges g, g + G, ... in order (the order every form of the kernel keeps, so all of them agree bit for bit).
+template <int L>
+__device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in, int my_idx, float my_c, int cnt, int g, float4 acc) {
+    constexpr int G = WAVE / L;
+    const int iters = (cnt + G - 1) / G;
+    // GS_U row loads per lane group are in flight together whenever the next GS_U iterations are all real edges
+    // (a wave-uniform test, so the loads need no predicate and nothing has to wait inside a branch).  Until round
+    // 2 this was a `#pragma unroll 8` over a loop with the load inside a per-lane branch: the compiler kept ONE
+    // load in flight per wave — a 100-edge row was 13 dependent round trips — and the kernel was bound by
+    // latency x resident waves (4 instead of 8 waves per SIMD: 1.08 -> 1.87 ms).  Same order of the sum.
+    int k = 0;
+    if (!a.row_bits) {
+        for (; (k + GS_U) * G <= cnt; k += GS_U) {
+            float4 v[GS_U];
+            float cc[GS_U];
+#pragma unroll
+            for (int u = 0; u < GS_U; u++) {
+                const int src = (k + u) * G + g;
+                const int j = __shfl(my_idx, src, WAVE);
+                cc[u] = __shfl(my_c, src, WAVE);
+                v[u] = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld_in);
+            }
+#pragma unroll
+            for (int u = 0; u < GS_U; u++) acc = f4_fma(cc[u], v[u], acc);
+        }
+    }
+    // the tail of a row, and rows read through an input mask: the same batches, with the lanes that have no edge
+    // (or an edge whose row is known to be zero) reading the chunk's first neighbour instead and keeping their sum
+    const int j_safe = __shfl(my_idx, 0, WAVE);
+    for (; k < iters; k += GS_U) {
+        float4 v[GS_U];
+        float cc[GS_U];
+        bool on[GS_U];
+#pragma unroll
+        for (int u = 0; u < GS_U; u++) {
+            const int src = (k + u) * G + g;
+            const int j = __shfl(my_idx, src & 63, WAVE);
+            cc[u] = __shfl(my_c, src & 63, WAVE);
+            on[u] = src < cnt && cc[u] != 0.f;         // padded lanes and known-zero rows contribute nothing
+            v[u] = *reinterpret_cast<const float4 *>(in + (size_t)(on[u] ? j : j_safe) * a.ld_in);
+        }
+#pragma unroll
+        for (int u = 0; u < GS_U; u++) {
+            const float4 n = f4_fma(cc[u], v[u], acc);
+            acc.x = on[u] ? n.x : acc.x; acc.y = on[u] ? n.y : acc.y; acc.z = on[u] ? n.z : acc.z; acc.w = on[u] ? n.w : acc.w;
+        }
+    }
+    return acc;
+}
+
 // L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
 template <int L>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
@@ -119,7 +174,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     const int g = lane / L, l = lane % L;
     const int col0 = (cslice * L + l) * 4;                  // first column of this lane's float4
     const bool active = col0 < a.dim;
-    const float *in = a.in + col0;
+    const float *in = a.in + (active ? col0 : 0);           // lanes past the last column read (and discard) columns 0..3
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = e0; base < e1; base += WAVE) {
         const int cnt = min(WAVE, e1 - base);
@@ -130,17 +185,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
             my_c = a.coef[base + lane];                    // > 0 for every real edge
             if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
         }
-        const int iters = (cnt + G - 1) / G;
-#pragma unroll 8
-        for (int k = 0; k < iters; k++) {
-            const int src = k * G + g;
-            const int j = __shfl(my_idx, src, WAVE);
-            const float c = __shfl(my_c, src, WAVE);
-            if (active && src < cnt && c != 0.f) {         // padded lanes and known-zero rows are never read
-                const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld_in);
-                acc = f4_fma(c, v, acc);
-            }
-        }
+        acc = gather_chunk<L>(a, in, my_idx, my_c, cnt, g, acc);
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -157,6 +202,80 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
                 for (int i = 0; col0 + i < a.dim; i++) o[i] = x[i];
             }
         }
+    }
+}
+
+// ---- EXPERIMENT: persistent form that also keeps the next chunk's (index, coef) pairs in flight -------------------
+// A wave walks tasks t, t + stride, ... of its XCD group's range; while the rows of chunk k are gathered, the pairs of
+// chunk k+1 (of the same task, or the first chunk of the wave's next task, whose record was fetched a task earlier) are
+// on their way, so one round trip per batch of rows remains.  Same lane groups, same edge order, same reduction tree:
+// bit-identical results.  Measured SLOWER than a wave per task (1.15 vs 0.85 ms, hidden width, Reddit scale) and
+// therefore not the default (GCNHIP_GS_PIPE selects it): see the launch site.
+template <int L>
+__global__ __launch_bounds__(256, 8) void graphsum_pipe_kernel(GsArgs a) {
+    constexpr int G = WAVE / L;
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int cslice = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
+    const int g_id = xcd / a.n_slices;
+    const int t_end = a.bounds[g_id + 1];
+    const int stride = (gridDim.x >> 3) * 4;                // waves of this XCD
+    // wave-uniform by construction; saying so lets the task records live in scalar registers
+    int t = __builtin_amdgcn_readfirstlane(a.bounds[g_id] + q * 4 + (int)(threadIdx.x >> 6));
+    if (t >= t_end) return;
+    const int g = lane / L, l = lane % L;
+    const int col0 = (cslice * L + l) * 4;
+    const bool active = col0 < a.dim;
+    const float *in = a.in + (active ? col0 : 0);
+    const int last_edge = a.nnz - 1;
+
+    // every prefetch below is an UNCONDITIONAL load from a clamped address: a load inside a branch makes the compiler
+    // wait for it at the end of that branch, which would put the round trip back on the critical path
+    int4 tk = a.tasks[t];
+    int t_nx = t + stride;
+    int4 tk_nx = a.tasks[min(t_nx, t_end - 1)];
+    int base = tk.y;
+    int cnt = min(WAVE, tk.z - base);
+    int my_idx = a.indices[min(base + lane, last_edge)];
+    float my_c = a.coef[min(base + lane, last_edge)];
+    if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (;;) {
+        // ---- the item after this one: next chunk of the task, or first chunk of the wave's next task
+        const bool last = base + WAVE >= tk.z;
+        const bool more = !last || t_nx < t_end;
+        const int nbase = last ? tk_nx.y : base + WAVE;
+        const int nend = last ? tk_nx.z : tk.z;
+        const int ncnt = more ? min(WAVE, nend - nbase) : 0;
+        const int n_idx = a.indices[min(max(nbase + lane, 0), last_edge)];      // in flight while this chunk's rows are gathered
+        float n_c = a.coef[min(max(nbase + lane, 0), last_edge)];
+        // ---- this chunk
+        acc = gather_chunk<L>(a, in, my_idx, my_c, cnt, g, acc);
+        if (a.row_bits && !((a.row_bits[n_idx >> 5] >> (n_idx & 31)) & 1u)) n_c = 0.f;
+        if (last) {
+#pragma unroll
+            for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+            if (g == 0 && active) {
+                if (tk.w >= 0) {
+                    *reinterpret_cast<float4 *>(a.partials + (size_t)tk.w * a.part_ld + col0) = acc;
+                } else {
+                    if (a.fuse) acc = relu_dropout4(acc, a, tk.x, col0);
+                    float *o = a.out + (size_t)tk.x * a.ld_out + col0;
+                    if (col0 + 4 <= a.dim) {
+                        *reinterpret_cast<float4 *>(o) = acc;
+                    } else {
+                        const float x[4] = {acc.x, acc.y, acc.z, acc.w};
+                        for (int i = 0; col0 + i < a.dim; i++) o[i] = x[i];
+                    }
+                }
+            }
+            if (!more) break;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            tk = tk_nx;
+            t_nx += stride;
+            tk_nx = a.tasks[min(t_nx, t_end - 1)];             // needed at the new task's last chunk, one round trip away at least
+        }
+        base = nbase; cnt = ncnt; my_idx = n_idx; my_c = n_c;
     }
 }
 
@@ -311,7 +430,7 @@ __global__ __launch_bounds__(256) void graphsum_bf16_kernel(GsArgs a) {
     const int g = lane / L, l = lane % L;
     const int col0 = (cslice * L + l) * 8;
     const bool active = col0 < a.dim;
-    const uint16_t *in = a.in_bf + col0;
+    const uint16_t *in = a.in_bf + (active ? col0 : 0);     // lanes past the last column read (and discard) columns 0..7
     float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
     for (int base = e0; base < e1; base += WAVE) {
         const int cnt = min(WAVE, e1 - base);
@@ -323,14 +442,42 @@ __global__ __launch_bounds__(256) void graphsum_bf16_kernel(GsArgs a) {
             if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
         }
         const int iters = (cnt + G - 1) / G;
-#pragma unroll 8
-        for (int k = 0; k < iters; k++) {
-            const int src = k * G + g;
-            const int j = __shfl(my_idx, src, WAVE);
-            const float c = __shfl(my_c, src, WAVE);
-            if (active && src < cnt && c != 0.f) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(in + (size_t)j * a.ld_in);
-                bf8_fma(c, v, lo, hi);
+        // batches of GS_U row loads in flight, as gather_chunk does for the f32 table
+        int k = 0;
+        if (!a.row_bits) {
+            for (; (k + GS_U) * G <= cnt; k += GS_U) {
+                uint4 v[GS_U];
+                float cc[GS_U];
+#pragma unroll
+                for (int u = 0; u < GS_U; u++) {
+                    const int src = (k + u) * G + g;
+                    const int j = __shfl(my_idx, src, WAVE);
+                    cc[u] = __shfl(my_c, src, WAVE);
+                    v[u] = *reinterpret_cast<const uint4 *>(in + (size_t)j * a.ld_in);
+                }
+#pragma unroll
+                for (int u = 0; u < GS_U; u++) bf8_fma(cc[u], v[u], lo, hi);
+            }
+        }
+        const int j_safe = __shfl(my_idx, 0, WAVE);
+        for (; k < iters; k += GS_U) {
+            uint4 v[GS_U];
+            float cc[GS_U];
+            bool on[GS_U];
+#pragma unroll
+            for (int u = 0; u < GS_U; u++) {
+                const int src = (k + u) * G + g;
+                const int j = __shfl(my_idx, src & 63, WAVE);
+                cc[u] = __shfl(my_c, src & 63, WAVE);
+                on[u] = src < cnt && cc[u] != 0.f;
+                v[u] = *reinterpret_cast<const uint4 *>(in + (size_t)(on[u] ? j : j_safe) * a.ld_in);
+            }
+#pragma unroll
+            for (int u = 0; u < GS_U; u++) {
+                float4 nlo = lo, nhi = hi;
+                bf8_fma(cc[u], v[u], nlo, nhi);
+                lo.x = on[u] ? nlo.x : lo.x; lo.y = on[u] ? nlo.y : lo.y; lo.z = on[u] ? nlo.z : lo.z; lo.w = on[u] ? nlo.w : lo.w;
+                hi.x = on[u] ? nhi.x : hi.x; hi.y = on[u] ? nhi.y : hi.y; hi.z = on[u] ? nhi.z : hi.z; hi.w = on[u] ? nhi.w : hi.w;
             }
         }
     }
@@ -496,6 +643,15 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     int max_blocks = 1;
     for (int k = 0; k <= 8; k++) a.bounds[k] = xb[lg][k];
     for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
+    // EXPERIMENT (GCNHIP_GS_PIPE): the persistent form that also prefetches the next chunk's indices.  Measured slower
+    // than a wave per task once the row loads are batched (1.15 vs 0.85 ms at Reddit scale): fresh waves arriving in
+    // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
+    static const bool pipe = getenv("GCNHIP_GS_PIPE") != nullptr;
+    if (pipe && a.n_tasks && !a.out_bits) {
+        const int per_xcd = std::min(max_blocks, 32 * 8);
+        graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
+        return;
+    }
     graphsum_vec_kernel<L><<<dim3(max_blocks * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
 }
 template <int L>
@@ -517,7 +673,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     GsArgs a;
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
     // a registered row subset brings its own compacted task list (same order, same segment slots)
-    a.tasks = rs ? rs->tasks : g->tasks; a.n_tasks = rs ? rs->n_tasks : g->n_tasks; a.n_rows = g->n_rows;
+    a.tasks = rs ? rs->tasks : g->tasks; a.n_tasks = rs ? rs->n_tasks : g->n_tasks; a.n_rows = g->n_rows; a.nnz = g->nnz;
     const int (*xb)[9] = rs ? rs->bounds : g->bounds;
     const int4 *split_rows = rs ? rs->split_rows : g->split_rows;
     const int n_split_rows = rs ? rs->n_split_rows : g->n_split_rows;
@@ -637,7 +793,7 @@ int gcnhip_graphsum_packed(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_ro
     GsArgs a;
     memset(&a, 0, sizeof a);
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
-    a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows;
+    a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows; a.nnz = g->nnz;
     a.in = dense; a.out = out; a.partials = g->partials;
     a.ld_in = ld_dense; a.ld_out = ld_out; a.part_ld = g->part_ld; a.dim = p->cols;
     const bool sliced = p->halves > 1 && 8 % p->halves == 0;
