@@ -45,10 +45,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL needs it)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
-# MI355X_MICROARCH.md "Indexed rows": a CU gathers rows served by its XCD's L2 at 66-73 GB/s and rows served by the
-# Infinity Cache at 33.5 GB/s (256 CUs: 18.4 and 8.6 TB/s chip-wide)
-L2_ROW_GBPS_PER_CU, MALL_ROW_GBPS_PER_CU, N_CU = 72.0, 33.5, 256
-PMC_FILES = ["r02_graphsum_pmc.json", "r01_graphsum_pmc.json"]           # newest first (profiles/)
+L2_AGG_GBPS = 34500.0         # "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
+MALL_GATHER_GBPS = 8600.0     # "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache: 33.5 GB/s per CU = 8.6 TB/s
+PMC_FILES = ["r02_graphsum_pmc.json"]           # newest first (profiles/)
 PMC_RMAT_FILES = ["r02_graphsum_pmc_rmat.json"]
 
 
@@ -394,17 +393,25 @@ def main():
             pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<8>")
         traffic = pmc.get("traffic_bytes_per_launch") if (pmc and world == 1) else None
         cache_resident = table_mb * 1e6 <= 256 * 2**20
-        if cache_resident and pmc and "l2_hit_rate" in pmc:
+        if cache_resident and pmc and "traffic_bytes_per_launch" in pmc:
             # The gathered table sits in the Infinity Cache: HBM is not what bounds the kernel (B_gs / t exceeds the HBM
-            # peak).  What does is the rate at which the CUs can gather 128-byte lines from their XCD's L2 and, past it,
-            # from the Infinity Cache: the guide's two per-CU row-gather rates blended at the PMC-measured L2 hit rate.
-            h = pmc["l2_hit_rate"]
-            peak = N_CU / (h / L2_ROW_GBPS_PER_CU + (1.0 - h) / MALL_ROW_GBPS_PER_CU)
+            # peak).  Two resources do: every gathered byte crosses an XCD's L2 (34.5 TB/s aggregate, MI355X_MICROARCH.md
+            # "L2"), and the bytes that miss L2 (PMC: 2*FETCH_SIZE + WRITE_SIZE per launch) come from the Infinity Cache,
+            # for which the highest row-gather rate the guide reports is 8.6 TB/s ("Indexed rows", 38 MB table).  The
+            # launch cannot be shorter than the longer of the two transfers; peak = gathered bytes / that floor.
+            # (Round 1-2's blend of the guide's PER-CU row-gather rates, 72 and 33.5 GB/s, gave 12.7 TB/s; the guide calls
+            # those lower bounds, and with four row loads in flight per lane group the kernel now gathers faster than that.)
+            gathered_bytes = ib * info["local_edges"] * d_eff
+            fabric = pmc["traffic_bytes_per_launch"] * (info["local_edges"] / ds["g_indices"].size)   # this rank's share
+            t_l2, t_fabric = gathered_bytes / (L2_AGG_GBPS * 1e9), fabric / (MALL_GATHER_GBPS * 1e9)
+            t_floor = max(t_l2, t_fabric)
+            peak = gathered_bytes / t_floor / 1e9
             roof = {"bound": "cache-gather", "kernel": kernel, "achieved": gathered, "peak": peak, "unit": "GB/s", "frac": gathered / peak,
-                    "traffic": traffic, "l2_hit_rate": h,
-                    "what": "achieved = gathered neighbour-row bytes (4*nnz*d) / HIP-event launch time; peak = 256 CUs / (h/72 + (1-h)/33.5) GB/s: "
-                            "MI355X_MICROARCH.md 'Indexed rows' per-CU gather rates from L2 and from the Infinity Cache, blended at the "
-                            "PMC-measured L2 hit rate h" + ("" if world == 1 else " of the 1-GPU schedule (not re-measured per partition)")}
+                    "traffic": traffic, "l2_hit_rate": pmc.get("l2_hit_rate"),
+                    "floor_ms": {"l2": 1e3 * t_l2, "infinity_cache": 1e3 * t_fabric},
+                    "what": "achieved = gathered neighbour-row bytes (4*nnz*d) / HIP-event launch time; peak = the same bytes / max(bytes / 34.5 TB/s "
+                            "L2 aggregate, PMC fabric bytes / 8.6 TB/s Infinity-Cache row-gather rate) — MI355X_MICROARCH.md 'L2', 'Indexed rows'"
+                            + ("" if world == 1 else "; fabric bytes of the 1-GPU launch scaled by this rank's share of the edges")}
         else:
             roof = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": algorithmic / HBM_PEAK_GBPS, "traffic": traffic,

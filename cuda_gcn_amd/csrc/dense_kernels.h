@@ -284,8 +284,38 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
 #pragma unroll
         for (int u = 0; u < VB; u++) acc[s][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int validA = a.n - colA, validB = a.p - colB;
-#pragma unroll 8
-    for (int k0 = r0; k0 < r1; k0 += 4) {
+    int k0 = r0;
+    // ATB_U K-steps (4 rows each) with their 2 * ATB_U row loads in flight together.  The `#pragma unroll 8` that used
+    // to stand here never applied (loads inside `if (row < r1)`): one K-step per round trip.  Needs whole steps inside the
+    // worker's range, no dropout, and rows padded to whole lane vectors (so a lane with fewer than VA / VB valid columns
+    // may read its full vector and zero the rest).
+    constexpr int ATB_U = 4;
+    if (!a.drop && a.lda >= (a.n + VA - 1) / VA * VA && a.ldb >= (a.p + VB - 1) / VB * VB) {
+        const float *pa = a.A + min(colA, max(a.n - 1, 0) / VA * VA), *pb = a.Bm + min(colB, max(a.p - 1, 0) / VB * VB);
+        for (; k0 + 4 * ATB_U <= r1; k0 += 4 * ATB_U) {
+            float av[ATB_U][VA], bv[ATB_U][VB];
+#pragma unroll
+            for (int q = 0; q < ATB_U; q++) {
+                const size_t row = (size_t)(k0 + 4 * q + kq);
+                load_vec<VA>(pa + row * a.lda, VA, av[q]);
+                load_vec<VB>(pb + row * a.ldb, VB, bv[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep the loads above: the scheduler otherwise sinks each to its use
+#pragma unroll
+            for (int q = 0; q < ATB_U; q++) {
+#pragma unroll
+                for (int s = 0; s < VA; s++) if (s >= validA) av[q][s] = 0.f;
+#pragma unroll
+                for (int u = 0; u < VB; u++) if (u >= validB) bv[q][u] = 0.f;
+#pragma unroll
+                for (int s = 0; s < VA; s++)
+#pragma unroll
+                    for (int u = 0; u < VB; u++)
+                        acc[s][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][s], bv[q][u], acc[s][u], 0, 0, 0);
+            }
+        }
+    }
+    for (; k0 < r1; k0 += 4) {
         const int row = k0 + kq;
         float av[VA], bv[VB];
 #pragma unroll
