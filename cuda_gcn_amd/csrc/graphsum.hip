@@ -30,6 +30,7 @@ struct GsArgs {
     const float *coef;
     const int4 *tasks;
     int n_tasks, n_rows, nnz;
+    size_t table_bytes;      // n_cols * ld_in * 4: decides the batch depth (cache-resident or HBM regime)
     const float *in;
     const uint16_t *in_bf;   // bf16 copy of the gathered table (opt-in storage format); row stride ld_in values
     float *out;
@@ -89,12 +90,10 @@ __device__ inline float4 relu_dropout4(float4 v, const GsArgs &a, int64_t r, int
     return make_float4(x[0], x[1], x[2], x[3]);
 }
 
-#ifndef GS_U
-#define GS_U 4
-#endif
+constexpr int GS_U = 4;        // row loads in flight per lane group when the table is cache resident (bf16 kernel: always)
 // One chunk of <= 64 edges whose (index, coef) pairs sit in the wave's lanes: acc += sum over the chunk, lane group g
 // taking edges g, g + G, ... in order (the order every form of the kernel keeps, so all of them agree bit for bit).
-template <int L>
+template <int L, int GS_U>
 __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in, int my_idx, float my_c, int cnt, int g, float4 acc) {
     constexpr int G = WAVE / L;
     const int iters = (cnt + G - 1) / G;
@@ -144,7 +143,7 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
 }
 
 // L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
-template <int L>
+template <int L, int U = GS_U>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
             my_c = a.coef[base + lane];                    // > 0 for every real edge
             if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
         }
-        acc = gather_chunk<L>(a, in, my_idx, my_c, cnt, g, acc);
+        acc = gather_chunk<L, U>(a, in, my_idx, my_c, cnt, g, acc);
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(256, 8) void graphsum_pipe_kernel(GsArgs a) {
         const int n_idx = a.indices[min(max(nbase + lane, 0), last_edge)];      // in flight while this chunk's rows are gathered
         float n_c = a.coef[min(max(nbase + lane, 0), last_edge)];
         // ---- this chunk
-        acc = gather_chunk<L>(a, in, my_idx, my_c, cnt, g, acc);
+        acc = gather_chunk<L, GS_U>(a, in, my_idx, my_c, cnt, g, acc);
         if (a.row_bits && !((a.row_bits[n_idx >> 5] >> (n_idx & 31)) & 1u)) n_c = 0.f;
         if (last) {
 #pragma unroll
@@ -652,7 +651,15 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
         graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
         return;
     }
-    graphsum_vec_kernel<L><<<dim3(max_blocks * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
+    // Batch depth by regime.  A table that fits the 256 MiB Infinity Cache is gathered with 4 row loads in flight per lane
+    // group (latency-bound otherwise: 1.08 -> 0.85 ms at Reddit scale).  Past it the kernel is HBM-bound and 2 is the
+    // optimum (R-MAT scale 21, 1 GiB table, d = 128: 5.33 / 5.16 / 5.51 ms with 1 / 2 / 4 in flight).
+    static const int force_u = getenv("GCNHIP_GS_U") ? atoi(getenv("GCNHIP_GS_U")) : 0;
+    const int u = force_u ? force_u : (a.table_bytes > ((size_t)256 << 20) ? 2 : 4);
+    const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
+    if (u >= 4) graphsum_vec_kernel<L, 4><<<grid, 256, 0, s>>>(a);
+    else if (u >= 2) graphsum_vec_kernel<L, 2><<<grid, 256, 0, s>>>(a);
+    else graphsum_vec_kernel<L, 1><<<grid, 256, 0, s>>>(a);
 }
 template <int L>
 static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
@@ -674,6 +681,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
     // a registered row subset brings its own compacted task list (same order, same segment slots)
     a.tasks = rs ? rs->tasks : g->tasks; a.n_tasks = rs ? rs->n_tasks : g->n_tasks; a.n_rows = g->n_rows; a.nnz = g->nnz;
+    a.table_bytes = (size_t)g->n_cols * ld_in * (in_bf ? 2 : 4);
     const int (*xb)[9] = rs ? rs->bounds : g->bounds;
     const int4 *split_rows = rs ? rs->split_rows : g->split_rows;
     const int n_split_rows = rs ? rs->n_split_rows : g->n_split_rows;
