@@ -193,12 +193,13 @@ def cpu_baseline(ds_full, hidden, budget_s=30.0):
 
 # ----------------------------------------------------------------------------------------------- HBM-regime leg
 def _pmc(files, kernel):
+    """PMC summary of the kernel whose name starts with `kernel` (template arguments after the first vary with the batch depth)"""
     for f in files:
         p = os.path.join(ROOT, "profiles", f)
         if os.path.exists(p):
-            k = json.load(open(p)).get(kernel)
-            if k:
-                return k, "profiles/" + f
+            for name, k in json.load(open(p)).items():
+                if name.startswith(kernel):
+                    return k, "profiles/" + f
     return None, None
 
 
@@ -242,7 +243,7 @@ def hbm_regime_leg(scale, dim, device, launches=10):
     x.free(); o.free(); g.free(); dev.close()
     bytes_per_launch = b_gs(N, nnz, dim)
     achieved = bytes_per_launch / avg_s / 1e9
-    k, src = _pmc(PMC_RMAT_FILES, "graphsum_vec_kernel<8>" if dim >= 64 and dim % 32 == 0 else "graphsum_vec_kernel<16>")
+    k, src = _pmc(PMC_RMAT_FILES, "graphsum_vec_kernel<8" if dim >= 64 and dim % 32 == 0 else "graphsum_vec_kernel<16")
     traffic = k.get("traffic_bytes_per_launch") if k else None
     return {"workload": f"GraphSum d={dim} on rmat-{scale} (N={N}, {nnz} stored edges, max degree {int(np.diff(gp).max())}); "
                         f"gathered table {N * ld * 4 / 2**20:.0f} MiB >> 256 MiB Infinity Cache; schedule dealt-256",
@@ -390,7 +391,7 @@ def main():
         # (FETCH_SIZE, WRITE_SIZE and the TCC hit counters need separate runs, so they cannot be collected live here)
         pmc, pmc_src = (None, None)
         if args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and not args.no_row_groups:
-            pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<8>")
+            pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<8")
         traffic = pmc.get("traffic_bytes_per_launch") if (pmc and world == 1) else None
         cache_resident = table_mb * 1e6 <= 256 * 2**20
         if cache_resident and pmc and "traffic_bytes_per_launch" in pmc:
