@@ -243,7 +243,7 @@ def hbm_regime_leg(scale, dim, device, launches=10):
     x.free(); o.free(); g.free(); dev.close()
     bytes_per_launch = b_gs(N, nnz, dim)
     achieved = bytes_per_launch / avg_s / 1e9
-    k, src = _pmc(PMC_RMAT_FILES, "graphsum_vec_kernel<8" if dim >= 64 and dim % 32 == 0 else "graphsum_vec_kernel<16")
+    k, src = _pmc(PMC_RMAT_FILES, "graphsum_vec_kernel<16")
     traffic = k.get("traffic_bytes_per_launch") if k else None
     return {"workload": f"GraphSum d={dim} on rmat-{scale} (N={N}, {nnz} stored edges, max degree {int(np.diff(gp).max())}); "
                         f"gathered table {N * ld * 4 / 2**20:.0f} MiB >> 256 MiB Infinity Cache; schedule dealt-256",
@@ -384,14 +384,14 @@ def main():
         avg_s = s_wide / max(n_wide, 1)
         algorithmic = bytes_per_launch / avg_s / 1e9
         gathered = ib * info["local_edges"] * d_eff / avg_s / 1e9
-        kernel = ("graphsum_bf16_kernel<8> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
-                  f"graphsum_vec_kernel<8>, XCD-sliced (GraphSum d={args.hidden})" if args.hidden > 64 else
+        kernel = ("graphsum_bf16_kernel<16> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
+                  f"graphsum_vec_kernel<16, 4>, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
                   f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)")
         # fabric traffic and L2 hit rate per launch of the same kernel from the committed rocprofv3 PMC passes
         # (FETCH_SIZE, WRITE_SIZE and the TCC hit counters need separate runs, so they cannot be collected live here)
         pmc, pmc_src = (None, None)
         if args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and not args.no_row_groups:
-            pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<8")
+            pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<16")
         traffic = pmc.get("traffic_bytes_per_launch") if (pmc and world == 1) else None
         cache_resident = table_mb * 1e6 <= 256 * 2**20
         if cache_resident and pmc and "traffic_bytes_per_launch" in pmc:

@@ -282,19 +282,20 @@ __global__ __launch_bounds__(256, 8) void graphsum_pipe_kernel(GsArgs a) {
 // The gathered matrix is dH1 = mask . (dZ0 . W2^T): three quarters of it are zeros whose positions are known
 // (ReLU and dropout of H1).  Its producer (gemm_rowstream, PACK) writes every 64-column half of a row as one
 // 128-byte slot — 64-bit mask + the masked-in values in column order — so an edge costs ONE line per half
-// instead of two, with the f32 values untouched.  Work split exactly as graphsum_vec_kernel<8>: 8 lane groups
-// of 8 lanes, edge k*8+g of a 64-edge chunk goes to group g, groups combined by the same xor tree — so every
-// output element sees the same non-zero terms in the same order and the result is bit-identical to the dense
-// gather (adding c * 0 never changes a sum that started at +0).
+// instead of two, with the f32 values untouched.  Edges are split as in graphsum_vec_kernel<16> (the dense gather
+// at widths that are multiples of 64): edge k*4+g of a 64-edge chunk goes to group g of FOUR, the four sums are
+// combined by the same xor tree — so every output element sees the same non-zero terms in the same order and the
+// result is bit-identical to the dense gather (adding c * 0 never changes a sum that started at +0).  A wave covers a
+// PAIR of halves: lane groups 0-3 (8 lanes each) take the even half, groups 4-7 the odd one.
 // A group loads its slot as 8 x 16 bytes (one request), parks it in the wave's LDS scratch, reads the mask back
 // (broadcast) and then each lane picks the values of its 8 columns: position = popcount of the mask below them.
 __global__ __launch_bounds__(256) void graphsum_packed_kernel(GsArgs a, const uint32_t *__restrict__ slots, int halves) {
     __shared__ uint4 stage[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int t, half;
+    int t, pair;
     {
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        half = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
+        pair = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
         const int g_id = xcd / a.n_slices;
         t = a.bounds[g_id] + q * 4 + wave;
         if (t >= a.bounds[g_id + 1]) return;               // wave-uniform
@@ -306,10 +307,12 @@ __global__ __launch_bounds__(256) void graphsum_packed_kernel(GsArgs a, const ui
     } else {
         row = t; e0 = a.indptr[t]; e1 = a.indptr[t + 1]; slot = -1;
     }
-    const int g = lane >> 3, l = lane & 7;
-    const uint32_t *sbase = slots + (size_t)half * 32 + l * 4;
+    const int g8 = lane >> 3, g = g8 & 3, l = lane & 7;
+    const int half = pair * 2 + (g8 >> 2);
+    const bool live = half < halves;                       // an odd number of halves: the last wave's upper groups idle
+    const uint32_t *sbase = slots + (size_t)(live ? half : 0) * 32 + l * 4;
     const size_t row_stride = (size_t)halves * 32;
-    const uint32_t *mine = reinterpret_cast<const uint32_t *>(&stage[wave][g * 8]);
+    const uint32_t *mine = reinterpret_cast<const uint32_t *>(&stage[wave][g8 * 8]);
     const uint32_t sh8 = 8u * (l & 3);                                            // this lane's byte inside its mask word
     const uint32_t below_lo = l < 4 ? (1u << (8 * l)) - 1u : 0xFFFFFFFFu;         // mask bits of the columns before this lane's
     const uint32_t below_hi = l < 4 ? 0u : (1u << (8 * (l - 4))) - 1u;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void graphsum_packed_kernel(GsArgs a, const ui
             my_idx = a.indices[base + lane];
             my_c = a.coef[base + lane];
         }
-        const int iters = (cnt + 7) >> 3;
+        const int iters = (cnt + 3) >> 2;
         // PACKED_U edges per lane group in flight: their slot loads are issued together, then each is parked in LDS and
         // decoded without branches (a branch per column serialises the loop: one load in flight per wave)
         constexpr int PACKED_U = 4;
@@ -334,10 +337,10 @@ __global__ __launch_bounds__(256) void graphsum_packed_kernel(GsArgs a, const ui
             float cc[PACKED_U];
 #pragma unroll
             for (int u = 0; u < PACKED_U; u++) {
-                const int src = (k0 + u) * 8 + g;              // >= 64 wraps in the shuffle; masked by `on`
+                const int src = (k0 + u) * 4 + g;              // >= 64 wraps in the shuffle; masked by `on`
                 jj[u] = __shfl(my_idx, src & 63, WAVE);
                 cc[u] = __shfl(my_c, src & 63, WAVE);
-                const bool on = src < cnt;
+                const bool on = src < cnt && live;
                 piece[u] = make_uint4(0u, 0u, 0u, 0u);         // empty mask: contributes nothing
                 if (on) piece[u] = *reinterpret_cast<const uint4 *>(sbase + (size_t)jj[u] * row_stride);
             }
@@ -372,8 +375,8 @@ __global__ __launch_bounds__(256) void graphsum_packed_kernel(GsArgs a, const ui
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int m = 8; m < WAVE; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
-    if (g == 0) {
+        for (int m = 8; m < 32; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
+    if (g == 0 && live) {
         const int col0 = half * 64 + 8 * l;
         float *o = slot >= 0 ? a.partials + (size_t)slot * a.part_ld + col0 : a.out + (size_t)row * a.ld_out + col0;
         *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -701,12 +704,14 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         if (d8 <= 1) launch_bf16<1>(a, xb, c->stream);
         else if (d8 <= 2) launch_bf16<2>(a, xb, c->stream);
         else if (d8 <= 4) launch_bf16<4>(a, xb, c->stream);
+        else if (d8 % 16 == 0) launch_bf16<16>(a, xb, c->stream);   // 128-column (two-line) slices as in the f32 kernel: 305 -> 322 epochs/s
         else launch_bf16<8>(a, xb, c->stream);               // 64-column (one line) slices, one per XCD group when 8 % slices == 0
-    } else if (vec && dim >= 64 && dim % 32 == 0 && 8 % (dim / 32) == 0) {
-        // rows of whole 128-byte lines: one 32-float column slice per XCD group (measured at
-        // Reddit scale, d = 128: 1.42 ms unsliced -> 1.26 ms; L2 hit rate of the gather rises
-        // because each XCD's L2 holds a quarter of the table)
-        launch_vec<8>(a, xb, c->stream);
+    } else if (vec && dim % 64 == 0 && 8 % (dim / 64) == 0) {
+        // rows of whole 128-byte lines: 64-float (two-line) column slices, one per XCD group, so each XCD's L2 holds
+        // 1/slices of the table and the (index, coef) stream is re-read only once per slice.  Measured at Reddit scale
+        // with 4 row loads in flight, 32- / 64- / 128-float slices: d = 64: 0.434 / 0.403 / - ms; d = 128: 0.843 / 0.760 /
+        // 0.874; d = 256: 2.36 / 1.77 / 1.78; R-MAT scale 21 (HBM regime), d = 128: 5.20 / 4.57 ms.
+        launch_vec<16>(a, xb, c->stream);
     } else if (vec) {
         if (d4 <= 1) launch_vec<1>(a, xb, c->stream);
         else if (d4 <= 2) launch_vec<2>(a, xb, c->stream);
@@ -804,14 +809,15 @@ int gcnhip_graphsum_packed(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_ro
     a.tasks = g->tasks; a.n_tasks = g->n_tasks; a.n_rows = g->n_rows; a.nnz = g->nnz;
     a.in = dense; a.out = out; a.partials = g->partials;
     a.ld_in = ld_dense; a.ld_out = ld_out; a.part_ld = g->part_ld; a.dim = p->cols;
-    const bool sliced = p->halves > 1 && 8 % p->halves == 0;
-    a.n_slices = sliced ? p->halves : 1;
+    const int pairs = (p->halves + 1) / 2;                  // a wave covers two halves
+    const bool sliced = pairs > 1 && 8 % pairs == 0;
+    a.n_slices = sliced ? pairs : 1;
     const int G = 8 / a.n_slices;
     const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
     int max_blocks = 1;
     for (int k = 0; k <= 8; k++) a.bounds[k] = g->bounds[lg][k];
     for (int k = 0; k < G; k++) max_blocks = std::max(max_blocks, ceil_div(a.bounds[k + 1] - a.bounds[k], 4));
-    graphsum_packed_kernel<<<dim3(max_blocks * 8, sliced ? 1 : p->halves), 256, 0, c->stream>>>(a, p->slots, p->halves);
+    graphsum_packed_kernel<<<dim3(max_blocks * 8, sliced ? 1 : pairs), 256, 0, c->stream>>>(a, p->slots, p->halves);
     GCNHIP_LAUNCH_CHECK();
     if (g->n_split_rows) {
         graphsum_finalize_kernel<<<g->n_split_rows, 256, 0, c->stream>>>(a, g->split_rows, g->n_split_rows);

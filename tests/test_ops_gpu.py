@@ -288,7 +288,7 @@ def bf16_round(x):
 def test_graphsum_bf16_table(dev, oracle, gname, dim, ld):
     """opt-in bf16 storage of the gathered table: the converter rounds to nearest even, and the
     aggregation differs from the f32 one ONLY by that rounding — against the oracle on the rounded
-    values it meets the f32 bound, at d = 128 (same lane grouping) it is bit-identical to the f32 kernel"""
+    values it meets the f32 bound, at d = 128 (same lane grouping: four groups of 16 lanes) it is bit-identical to the f32 kernel"""
     if gname == "cora":
         ds = datagen.make_dataset("cora-syn"); gp, gi = ds["g_indptr"], ds["g_indices"]
     else:

@@ -98,6 +98,8 @@ def main():
         gs_bf16(h, h); gs_bf16(Cc, 64); gs_bf16(Cc, 48)
         return
     gs(h, h)
+    if len(sys.argv) > 4 and sys.argv[4] == 'only_h':       # PMC passes: the hidden-width launches alone under their kernel name
+        return
     gs(Cc, (Cc + 3) // 4 * 4)
     gs(Cc, 48)
     gs(Cc, 64)
