@@ -385,7 +385,7 @@ def main():
         algorithmic = bytes_per_launch / avg_s / 1e9
         gathered = ib * info["local_edges"] * d_eff / avg_s / 1e9
         kernel = ("graphsum_bf16_kernel<16> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
-                  f"graphsum_vec_kernel<16, 4>, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
+                  f"graphsum_vec_kernel<16, 4, true>, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
                   f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)")
         # fabric traffic and L2 hit rate per launch of the same kernel from the committed rocprofv3 PMC passes
         # (FETCH_SIZE, WRITE_SIZE and the TCC hit counters need separate runs, so they cannot be collected live here)

@@ -143,7 +143,9 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
 }
 
 // L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
-template <int L, int U = GS_U>
+// SLICED: the launch binds one column slice to each XCD group (it only changes the block -> (tasks, columns) mapping; the
+// flag is a template argument so that profiles name the hidden-width launches apart from the class-width ones).
+template <int L, int U = GS_U, bool SLICED = false>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
@@ -155,12 +157,10 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     int t, cslice;
     {
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int groups = 8 / a.n_slices;                 // XCD groups per slice
-        cslice = a.n_slices > 1 ? xcd % a.n_slices : blockIdx.y;
-        const int g_id = xcd / a.n_slices;                 // which share of the tasks
+        cslice = SLICED ? xcd % a.n_slices : blockIdx.y;
+        const int g_id = SLICED ? xcd / a.n_slices : xcd;  // which share of the tasks
         t = a.bounds[g_id] + q * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (t >= a.bounds[g_id + 1]) return;               // wave-uniform
-        (void)groups;
     }
     int row, e0, e1, slot;
     if (a.n_tasks) {
@@ -660,9 +660,15 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     static const int force_u = getenv("GCNHIP_GS_U") ? atoi(getenv("GCNHIP_GS_U")) : 0;
     const int u = force_u ? force_u : (a.table_bytes > ((size_t)256 << 20) ? 2 : 4);
     const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
-    if (u >= 4) graphsum_vec_kernel<L, 4><<<grid, 256, 0, s>>>(a);
-    else if (u >= 2) graphsum_vec_kernel<L, 2><<<grid, 256, 0, s>>>(a);
-    else graphsum_vec_kernel<L, 1><<<grid, 256, 0, s>>>(a);
+    if (sliced) {
+        if (u >= 4) graphsum_vec_kernel<L, 4, true><<<grid, 256, 0, s>>>(a);
+        else if (u >= 2) graphsum_vec_kernel<L, 2, true><<<grid, 256, 0, s>>>(a);
+        else graphsum_vec_kernel<L, 1, true><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (u >= 4) graphsum_vec_kernel<L, 4><<<grid, 256, 0, s>>>(a);
+        else if (u >= 2) graphsum_vec_kernel<L, 2><<<grid, 256, 0, s>>>(a);
+        else graphsum_vec_kernel<L, 1><<<grid, 256, 0, s>>>(a);
+    }
 }
 template <int L>
 static void launch_scalar(const GsArgs &a, int nt, hipStream_t s) {
