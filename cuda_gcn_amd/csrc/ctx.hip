@@ -208,10 +208,10 @@ static int build_rowset(gcnhip_rowset *rs, const std::vector<int4> &tasks, const
 }
 
 // (Re)build the row schedule: tasks ordered by (key[row] ascending, degree descending); key == nullptr: degree only.
+static int build_tasks(gcnhip_graph *g, const std::vector<int> &order);
 static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
     const int n_rows = g->n_rows;
     const int *h_indptr = g->h_indptr->data();
-    const int SPLIT_EDGES = split_length(g->nnz);
     if (g->tasks) { GCNHIP_TRY(hipFree(g->tasks)); g->tasks = nullptr; }
     if (g->split_rows) { GCNHIP_TRY(hipFree(g->split_rows)); g->split_rows = nullptr; }
     // Task list: rows in descending degree order (heavy work first, similar rows together), group-major
@@ -223,6 +223,14 @@ static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
         if (h_row_group && h_row_group[a] != h_row_group[b]) return h_row_group[a] < h_row_group[b];
         return h_indptr[a + 1] - h_indptr[a] > h_indptr[b + 1] - h_indptr[b];
     });
+    return build_tasks(g, order);
+}
+
+// the task list of a given row order
+static int build_tasks(gcnhip_graph *g, const std::vector<int> &order) {
+    const int *h_indptr = g->h_indptr->data();
+    const int SPLIT_EDGES = split_length(g->nnz);
+    const int n_rows = g->n_rows;
     int n_slots = 0;
     std::vector<int4> tasks, srows;
     tasks.reserve((size_t)n_rows + 64);
@@ -336,6 +344,53 @@ static int graph_create_impl(gcnhip_ctx *c, gcnhip_graph *g, const int *h_indptr
 
     g->h_indptr = new std::vector<int>(h_indptr, h_indptr + n_rows + 1);
     return build_schedule(g, h_row_group);
+}
+
+int gcnhip_graph_create_restricted(gcnhip_ctx *c, gcnhip_graph **out, const gcnhip_graph *parent, const uint32_t *h_col_bits) {
+    if (!c || !out || !parent || !h_col_bits || !parent->h_indptr || !parent->h_tasks) return -1;
+    GCNHIP_TRY(hipSetDevice(c->device));
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
+    const int n_rows = parent->n_rows, nnz = parent->nnz;
+    // the parent's edges as it stores them (neighbours by descending degree) and ITS coefficients: degrees of the full graph
+    std::vector<int> idx((size_t)std::max(nnz, 1));
+    std::vector<float> cf((size_t)std::max(nnz, 1));
+    if (nnz) {
+        GCNHIP_TRY(hipMemcpy(idx.data(), parent->indices, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
+        GCNHIP_TRY(hipMemcpy(cf.data(), parent->coef, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    const int *pp = parent->h_indptr->data();
+    std::vector<int> ip((size_t)n_rows + 1);
+    size_t w = 0;
+    for (int r = 0; r < n_rows; r++) {
+        ip[r] = (int)w;
+        for (int e = pp[r]; e < pp[r + 1]; e++) {
+            const int j = idx[e];
+            if ((h_col_bits[j >> 5] >> (j & 31)) & 1u) { idx[w] = j; cf[w] = cf[e]; w++; }   // w <= e: in place
+        }
+    }
+    ip[n_rows] = (int)w;
+    gcnhip_graph *g = new gcnhip_graph();
+    memset(g, 0, sizeof *g);
+    auto fail = [&](int rc) { gcnhip_graph_destroy(c, g); return rc; };
+    g->n_rows = n_rows; g->n_cols = parent->n_cols; g->nnz = (int)w;
+    g->part_ld = parent->part_ld;
+    if (hipMalloc((void **)&g->indptr, (size_t)(n_rows + 1) * sizeof(int)) != hipSuccess) return fail(-2);
+    if (hipMalloc((void **)&g->indices, std::max(w, (size_t)1) * sizeof(int)) != hipSuccess) return fail(-2);
+    if (hipMalloc((void **)&g->coef, std::max(w, (size_t)1) * sizeof(float)) != hipSuccess) return fail(-2);
+    if (hipMemcpy(g->indptr, ip.data(), (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(-3);
+    if (w && hipMemcpy(g->indices, idx.data(), w * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(-3);
+    if (w && hipMemcpy(g->coef, cf.data(), w * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(-3);
+    g->h_indptr = new std::vector<int>(std::move(ip));
+    // the parent's current row order (a split row appears once per segment, consecutively)
+    std::vector<int> order;
+    order.reserve((size_t)n_rows);
+    for (const int4 &t : *parent->h_tasks)
+        if (order.empty() || order.back() != t.x) order.push_back(t.x);
+    if ((int)order.size() != n_rows) return fail(-1);
+    const int rc = build_tasks(g, order);
+    if (rc != 0) return fail(rc);
+    *out = g;
+    return 0;
 }
 
 int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {

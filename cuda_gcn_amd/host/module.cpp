@@ -157,7 +157,8 @@ void HipGraphSum::backward() {
     // same operator on the gradients (symmetric adjacency, module.cpp:103-119); out->grad is gathered,
     // unless every rank has already rebuilt all of it
     const int world = env->comm->size();
-    const uint32_t *row_bits = bwd_row_bits ? *bwd_row_bits : nullptr;
+    const uint32_t *row_bits = bwd_row_bits && !bwd_graph ? *bwd_row_bits : nullptr;
+    const gcnhip_graph *graph = bwd_graph ? bwd_graph : this->graph;
     if (env->bf16_tables) {
         uint16_t *tab = table();
         env->timers->start(TMR_GRAPHSUM_BW);

@@ -95,6 +95,8 @@ public:
     bool out_grad_complete = false;
     // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
     const uint32_t *const *bwd_row_bits = nullptr;
+    const gcnhip_graph *bwd_graph = nullptr;              // the operator without the edges that point at known-zero rows of out->grad
+                                                          // (gcnhip_graph_create_restricted); replaces the row mask when set
     // rows of `out` that the consumer reads in forward() (bit = 1); the others are not computed.  NULL: all rows.
     // The last aggregation sets it: loss and accuracy read only rows of the scored split (module.cpp:131-133).
     gcnhip_rowset *const *fwd_out_rows = nullptr;

@@ -463,6 +463,16 @@ class Graph:
         _ck(self.dev.lib, self.dev.lib.gcnhip_graph_add_rowset(self.dev.ctx, self.h, bits.ctypes.data, C.byref(h)), "gcnhip_graph_add_rowset")
         return h
 
+    def restricted(self, keep_cols):
+        """a second adjacency object without the edges whose source row is outside `keep_cols` (boolean per column)"""
+        bits = np.packbits(np.asarray(keep_cols, bool), bitorder="little")
+        bits = np.concatenate([bits, np.zeros((-bits.size) % 4 + 8, np.uint8)]).view(np.uint32)
+        h = C.c_void_p()
+        _ck(self.dev.lib, self.dev.lib.gcnhip_graph_create_restricted(self.dev.ctx, C.byref(h), self.h, bits.ctypes.data), "gcnhip_graph_create_restricted")
+        g = Graph.__new__(Graph)
+        g.dev, g.n_rows, g.n_cols, g.h = self.dev, self.n_rows, self.n_cols, h
+        return g
+
     def reserve(self, dim):
         """segment scratch for aggregations up to `dim` columns (256 are reserved when the object is built)"""
         if dim > 256:

@@ -50,6 +50,8 @@ enum {
                                            env HIPGCN_EXCHANGE=halo|allgather) */
     GCNHOST_PACKED_DH1 = 65536,       /* opt-in: dH1 travels to the hidden layer's backward gather as packed rows (bit-identical to the
                                          dense gather, measured slower on gfx950; env HIPGCN_PACKED_DH1=1 does the same) */
+    GCNHOST_MASKED_BWD = 131072,      /* the output layer's backward masks the rows of dZ outside the training split at every launch
+                                         (default: aggregates through gcnhip_graph_create_restricted's operator; env HIPGCN_MASKED_BWD=1) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
 };
 

@@ -331,6 +331,23 @@ def test_packed_dh1_is_bit_identical_to_dense(name, hidden):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,hidden", [("reddit-mini", 128), ("cora-syn", 16)])
+def test_restricted_backward_operator_matches_masked_launch(name, hidden):
+    """the output layer's backward through the operator that has lost the edges pointing outside the training split
+    (default) against masking those rows at every launch (MASKED_BWD): the same sums up to the order of their terms"""
+    from cuda_gcn_amd.model import HipGCNModel, MASKED_BWD
+    ds = datagen.make_dataset(name)
+    a = HipGCNModel(ds, seed=8, hidden_dim=hidden, dropout=0.5, epochs=12)
+    b = HipGCNModel(ds, seed=8, flags=MASKED_BWD, hidden_dim=hidden, dropout=0.5, epochs=12)
+    la, lb = a.train_epoch(), b.train_epoch()
+    assert la == lb                                            # the first forward does not depend on it
+    ga, gb = a.var(4, True), b.var(4, True)                    # dZ0 = A^ . dZ after one backward
+    assert np.allclose(ga, gb, rtol=1e-4, atol=1e-5 * float(np.abs(gb).max()))
+    ta, tb = a.run_epochs(10), b.run_epochs(10)
+    assert np.allclose(ta, tb, rtol=2e-4, atol=2e-5)
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""

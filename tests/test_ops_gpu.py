@@ -345,6 +345,40 @@ def test_graphsum_rowmask(dev, oracle, dim, ld):
     g.free()
 
 
+@pytest.mark.parametrize("gname", ["cora-syn", "hub"])
+@pytest.mark.parametrize("dim,ld", [(41, 48), (128, 128), (7, 7)])
+@pytest.mark.parametrize("share", [0.6, 0.0, 1.0])
+def test_restricted_operator(dev, oracle, gname, dim, ld, share):
+    """gcnhip_graph_create_restricted: the operator without the edges that point at rows promised to be zero gives the
+    oracle's result on the zeroed input even when those rows hold NaN on the device (they are never read), keeps the
+    parent's coefficients, and inherits the parent's row order (label-major here) — hub graph: split rows"""
+    if gname == "hub":
+        gp, gi = hub_graph(); labels = (np.arange(gp.size - 1) % 7).astype(np.int32)
+    else:
+        ds = datagen.make_dataset(gname); gp, gi, labels = ds["g_indptr"], ds["g_indices"], ds["label"]
+    n = gp.size - 1
+    rng = np.random.default_rng(dim + int(share * 10))
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    nz = rng.random(n) < share
+    if gname == "hub" and share == 0.6:
+        nz[0] = True                                          # the hub row stays a source
+    xz = np.where(nz[:, None], x, 0).astype(np.float32)
+    xn = np.where(nz[:, None], x, np.nan).astype(np.float32)
+    g = dev.graph(gp, gi, row_group=labels)
+    gr = g.restricted(nz)
+    got = dev.graphsum(gr, xn, ld_in=ld, ld_out=ld)
+    close_mag(got, oracle.graphsum(gp, gi, xz, dim), oracle.graphsum(gp, gi, np.abs(xz), dim))
+    if share == 1.0:                                          # nothing removed, same row order: the parent's bits
+        assert np.array_equal(got, dev.graphsum(g, x, ld_in=ld, ld_out=ld))
+    # every coefficient of the restricted object is one of the parent's (degrees of the FULL graph), edge count as expected
+    assert gr.coef().size == int(nz[gi].sum())
+    if share > 0:
+        full = np.sort(g.coef()); sub = gr.coef()
+        pos = np.searchsorted(full, sub)
+        assert np.array_equal(full[np.minimum(pos, full.size - 1)], sub)
+    gr.free(); g.free()
+
+
 def test_graphsum_nan_isolation(dev, oracle):
     """padding lanes must not read row 0: an Inf in row 0 may only reach its neighbours"""
     gp, gi = hub_graph(400, 50, 1)
