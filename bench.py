@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--bf16-tables", action="store_true",
                     help="opt-in, NOT the headline: GraphSum gathers bfloat16 copies of its inputs (f32 sums); reported as dtype f32+bf16-tables")
     ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
-                    help="validation forward on a second stream, overlapped with the next training epoch (auto = off)")
+                    help="validation forward on a second stream, overlapped with the next training epoch (auto: on with one GPU, off with several)")
     return ap.parse_args(argv)
 
 
@@ -303,9 +303,12 @@ def main():
         box = [nccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         nccl_id = box[0]
-    # auto = the plain one-stream schedule: the overlapped one (second stream + split communicator) is opt-in here
-    # until it has been measured on a multi-GPU node; the self-launching parent above tries both
-    lane_flag = {"auto": NO_EVAL_LANE, "on": EVAL_LANE, "off": NO_EVAL_LANE}[args.eval_lane]
+    # auto: one GPU — the validation forward runs on a second stream beside the next epoch's hidden-width aggregation
+    # (no communication involved; 277 -> 289 epochs/s).  Several GPUs — the plain one-stream schedule: the overlapped one
+    # (second stream + split communicator) is opt-in there until it has been measured on a multi-GPU node; the
+    # self-launching parent above tries both.
+    lane_on = args.eval_lane == "on" or (args.eval_lane == "auto" and world == 1)
+    lane_flag = EVAL_LANE if lane_on else NO_EVAL_LANE
     base_flags = lane_flag | (BF16_TABLES if args.bf16_tables else 0)
     n_epochs_total = args.warmup + args.steps * (2 + args.bursts) + 64
 
@@ -342,7 +345,8 @@ def main():
         log(f"timed: {args.steps / dt:.2f} epochs/s; bursts {['%.1f' % b for b in burst_eps]}")
 
     # ---- separate pass, same process and model: per-op HIP-event timers on (the epoch then runs eagerly, one
-    # event pair per op on the stream the op runs on).  The dominant kernel's launches are timed here.
+    # event pair per op on the stream the op runs on; on one GPU everything runs on ONE stream in this pass, so a launch
+    # is timed alone and not beside the validation lane's kernels).  The dominant kernel's launches are timed here.
     n_tm = min(args.steps, 20)
     model.set_timers(True)
     model.run_epochs(2, want_trace=False)
@@ -437,7 +441,7 @@ def main():
                                    "step = train_epoch + eval(val)",
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": schedule,
-                       "eval_lane": "on" if args.eval_lane == "on" else "off",
+                       "eval_lane": "on" if lane_on else "off",
                        "exchange": exchange,       # rank 0's view: all-gather of row blocks or halo lists, rows moved per exchange
                        "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
                                        "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",

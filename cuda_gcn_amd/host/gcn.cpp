@@ -784,7 +784,8 @@ void HipGCN::run_epochs(int n, float *trace) {
                 GCNHIP_CHECK(gcnhip_graph_launch(env.ctx, epoch_graph));
                 epochs_done++;
                 optimizer->note_replayed(1);
-            } else if (lane) {
+            } else if (lane && !(timers->enabled && env.comm->size() == 1)) {
+                // (one GPU with per-op timers on: one stream, so that every launch is timed alone — the branch below)
                 // validation of epoch i-1 zipped with training of epoch i; the chunk's last validation runs alone
                 if (i == 0) train_epoch_async(); else eval_then_train_zipped(2);
                 if (i == chunk - 1) eval_on_lane(2);
