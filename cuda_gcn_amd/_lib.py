@@ -101,6 +101,9 @@ GCNHIP_SYMBOLS = {
     "gcnhip_spmm_fwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
     "gcnhip_spmm_fwd_relu": (I, [P, P, P, P, I, P, I, I]),
     "gcnhip_spmm_bwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
+    "gcnhip_spmm_bwd_plan": (I, [P, P, I, C.POINTER(I), C.POINTER(I)]),
+    "gcnhip_spmm_bwd_part": (I, [P, P, P, P, I, I, F, U64, P, U64, P, I, I, I]),
+    "gcnhip_spmm_bwd_finish": (I, [P, P, P, I, I]),
     "gcnhip_matmul_fwd": (I, [P, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd_fused": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F]),

@@ -45,6 +45,7 @@ struct Tile128Args {
     const uint32_t *bits;             // NULL: no dropout
     float scale;
     int rows_per_split;               // bwd only
+    int split0;                       // bwd only: blockIdx.x == 0 is split number split0 (a launch may cover a range of splits)
     int relu;                         // fwd only: store max(x, 0)
 };
 
@@ -319,7 +320,8 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kq = lane >> 5;
     const int xc_base = blockIdx.y * 128, pc_base = blockIdx.z * 128;
-    const int r_begin = blockIdx.x * a.rows_per_split;
+    const int split = blockIdx.x + a.split0;
+    const int r_begin = split * a.rows_per_split;
     const int r_end = min(a.m, r_begin + a.rows_per_split);
     constexpr int LPR = 128 / VX;
     constexpr int A_PIECES = T_BK * 128 / (256 * VX);
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
         }
     }
     // partial [K x p] of this split
-    float *slab = a.out + (size_t)blockIdx.x * a.K * a.ldo;
+    float *slab = a.out + (size_t)split * a.K * a.ldo;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll

@@ -390,40 +390,93 @@ int gcnhip_spmm_fwd_relu(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
     return spmm_fwd_impl(c, f, vals, w, ld_w, out, ld_out, p, 0.f, 0, nullptr, 0, nullptr, 1);
 }
 
+// the split-K plan of the dense weight gradient: S row ranges of rps rows (a multiple of the K chunk) fill the chip twice
+static bool dense_bwd_plan(const gcnhip_ctx *c, const gcnhip_feat *f, int p, int *rps_out, int *S_out) {
+    if (!(f->dense && p > 64 && f->n_cols >= 64)) return false;
+    const int kt = ceil_div(f->n_cols, 128), pt = ceil_div(p, 128);
+    int S = (2 * c->n_cu) / (kt * pt);
+    if (S < 1) S = 1;
+    int rps = (ceil_div(f->n_rows, S) + T_BK - 1) / T_BK * T_BK;
+    if (rps < T_BK) rps = T_BK;
+    *rps_out = rps;
+    *S_out = ceil_div(f->n_rows, rps);
+    return true;
+}
+
+// splits [s0, s1) of the plan into their slabs
+static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,
+                          const DropSpec &d, int s0, int s1) {
+    int rps, S;
+    if (!dense_bwd_plan(c, f, p, &rps, &S) || s0 < 0 || s1 > S || s0 > s1) return -1;
+    if (s0 == s1) return 0;
+    const int kt = ceil_div(f->n_cols, 128), pt = ceil_div(p, 128);
+    const int p_ld = (p + 3) / 4 * 4;
+    const int rc = ensure_slab(c, (size_t)S * f->n_cols * p_ld * sizeof(float));
+    if (rc) return rc;
+    Tile128Args t;
+    t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
+    int vx = x_vec_width(f, vals);
+    if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }
+    t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps; t.relu = 0;
+    t.split0 = s0;
+    dim3 grid(s1 - s0, kt, pt);
+    const bool fast = vx == 4 && t.ldx % 4 == 0 && kt * 128 <= t.ldx && ld_dout % 4 == 0 && p % 128 == 0 && aligned16(dout);
+    if (fast) dense_bwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);   // (an eight-wave form measured the same: 0.3836 vs 0.3834 ms)
+    else if (vx == 4) dense_bwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
+    else if (vx == 2) dense_bwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
+    else dense_bwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// the ordered sum of all slabs
+static int dense_bwd_finish(gcnhip_ctx *c, const gcnhip_feat *f, float *dw, int ld_dw, int p) {
+    int rps, S;
+    if (!dense_bwd_plan(c, f, p, &rps, &S)) return -1;
+    const int p_ld = (p + 3) / 4 * 4;
+    if (!c->slab || c->slab_bytes < (size_t)S * f->n_cols * p_ld * sizeof(float)) return -1;   // no part has run on this context
+    int rb = ceil_div((int64_t)f->n_cols * p, 64);
+    if (rb > 4096) rb = 4096;
+    slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(c->slab, S, f->n_cols, p, p_ld, dw, ld_dw);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int gcnhip_spmm_bwd_plan(const gcnhip_ctx *c, const gcnhip_feat *f, int p, int *rows_per_split, int *n_splits) {
+    if (!c || !f || p <= 0 || !rows_per_split || !n_splits) return -1;
+    int rps = 0, S = 0;
+    if (!dense_bwd_plan(c, f, p, &rps, &S)) { rps = 0; S = 0; }
+    *rows_per_split = rps; *n_splits = S;
+    return 0;
+}
+
+int gcnhip_spmm_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,
+                         float p_drop, uint64_t seed, const uint32_t *d_epoch, uint64_t nnz_offset, const uint8_t *keep_mask,
+                         int split_begin, int split_end, int make_decisions) {
+    if (!c || !f || !vals || !dout || p <= 0 || ld_dout < p) return -1;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
+    const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
+    if (d.on && make_decisions) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
+    return dense_bwd_part(c, f, vals, dout, ld_dout, p, d, split_begin, split_end);
+}
+
+int gcnhip_spmm_bwd_finish(gcnhip_ctx *c, const gcnhip_feat *f, float *dw, int ld_dw, int p) {
+    if (!c || !f || !dw || p <= 0 || ld_dw < p) return -1;
+    return dense_bwd_finish(c, f, dw, ld_dw, p);
+}
+
 int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
                     float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
                     uint64_t nnz_offset, const uint8_t *keep_mask) {
     if (!c || !f || !vals || !dout || !dw || p <= 0 || ld_dout < p || ld_dw < p) return -1;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
-    if (f->dense && p > 64 && f->n_cols >= 64) {      // split-K 128 x 128 MFMA tiles + ordered slab sum
+    int rps, S;
+    if (dense_bwd_plan(c, f, p, &rps, &S)) {          // split-K 128 x 128 MFMA tiles + ordered slab sum
         if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
-        const int kt = ceil_div(f->n_cols, 128), pt = ceil_div(p, 128);
-        int S = (2 * c->n_cu) / (kt * pt);
-        if (S < 1) S = 1;
-        int rps = (ceil_div(f->n_rows, S) + T_BK - 1) / T_BK * T_BK;
-        if (rps < T_BK) rps = T_BK;
-        S = ceil_div(f->n_rows, rps);
-        const int p_ld = (p + 3) / 4 * 4;
-        const int rc = ensure_slab(c, (size_t)S * f->n_cols * p_ld * sizeof(float));
+        const int rc = dense_bwd_part(c, f, vals, dout, ld_dout, p, d, 0, S);
         if (rc) return rc;
-        Tile128Args t;
-        t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
-        int vx = x_vec_width(f, vals);
-        if (vals == f->values && f->values_pad) { t.x = f->values_pad; t.ldx = f->ld_pad; vx = 4; }
-        t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = rps; t.relu = 0;
-        dim3 grid(S, kt, pt);
-        const bool fast = vx == 4 && t.ldx % 4 == 0 && kt * 128 <= t.ldx && ld_dout % 4 == 0 && p % 128 == 0 && aligned16(dout);
-        if (fast) dense_bwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);   // (an eight-wave form measured the same: 0.3836 vs 0.3834 ms)
-        else if (vx == 4) dense_bwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
-        else if (vx == 2) dense_bwd_t128_kernel<2><<<grid, 256, 0, c->stream>>>(t);
-        else dense_bwd_t128_kernel<1><<<grid, 256, 0, c->stream>>>(t);
-        GCNHIP_LAUNCH_CHECK();
-        int rb = ceil_div((int64_t)f->n_cols * p, 64);
-        if (rb > 4096) rb = 4096;
-        slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(c->slab, S, f->n_cols, p, p_ld, dw, ld_dw);
-        GCNHIP_LAUNCH_CHECK();
-        return 0;
+        return dense_bwd_finish(c, f, dw, ld_dw, p);
     }
     if (f->dense) {                                   // narrow outputs (p <= 64)
         if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }     // not one Philox block per float4 in the GEMM

@@ -45,6 +45,8 @@ enum HipGCNFlags {
     HIPGCN_NO_AGG_FIRST_EVAL = 8192, // evaluation forwards keep the reference's order A^.(X.W1) instead of (A^.X).W1 with A^.X built once
     HIPGCN_EXCHANGE_ALLGATHER = 16384, // multi-GPU: always all-gather whole row blocks before an aggregation
     HIPGCN_EXCHANGE_HALO = 32768,      // ... or always exchange only the rows some local edge points at (default: decided per graph)
+    HIPGCN_BWD_PIPELINE = 262144,      // opt-in: the hidden layer's backward aggregation in row blocks, each block's share of the first
+                                       // layer's weight gradient on a second stream (same bits; measured slower)
     HIPGCN_MASKED_BWD = 131072,        // the output layer's backward masks the known-zero rows of dZ at every launch instead of
                                        // aggregating through an operator that has lost the edges pointing at them
     HIPGCN_PACKED_DH1 = 65536,         // opt-in: dH1 reaches the hidden layer's backward gather as packed rows (same bits; measured slower)
@@ -146,6 +148,9 @@ private:
     int32_t *d_result_i = nullptr;
     int32_t *d_truth[4] = {};                                  // per split code 1..3
     int32_t *cur_truth = nullptr;
+    std::unique_ptr<BackwardPipeline> bwd_pipe;                 // hidden-layer backward aggregation || dW1 product, in row blocks
+    void build_bwd_pipeline(HipSparseMatmul *sm, HipGraphSum *gs);
+    void destroy_bwd_pipeline();
     gcnhip_graph *graph_bwd_out = nullptr;                     // `graph` without the edges whose source is outside the training split
     std::vector<uint32_t> h_train_bits;
     uint32_t *d_train_bits = nullptr;                          // bit per (padded) node: in the training split

@@ -60,7 +60,23 @@ void HipSparseMatmul::forward(bool training) {
     env->timers->stop(TMR_SPMATMUL_FW);
 }
 
+void HipSparseMatmul::backward_part(int k) {
+    const float pd = last_training ? fused_dropout : 0.f;
+    GCNHIP_CHECK(gcnhip_spmm_bwd_part(pipe->side, sp, *vals, c->grad, c->ld, p, pd, env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch,
+                                      nnz_offset, pd > 0.f ? env->keep_input_bwd : nullptr, pipe->cuts[k], pipe->cuts[k + 1], k == 0));
+}
+
+void HipSparseMatmul::backward_finish() {
+    GCNHIP_CHECK(gcnhip_spmm_bwd_finish(pipe->side, sp, b->grad, b->ld, p));
+    GCNHIP_CHECK(gcnhip_event_record(pipe->side, pipe->ev_done));
+}
+
 void HipSparseMatmul::backward() {
+    if (pipe && pipe->armed) {                  // the producer of c->grad has already run this product on the second stream
+        GCNHIP_CHECK(gcnhip_stream_wait_event(env->ctx, pipe->ev_done));
+        pipe->armed = false;
+        return;
+    }
     env->timers->start(TMR_SPMATMUL_BW);
     const float pd = last_training ? fused_dropout : 0.f;     // the same X~ the forward saw (module.cpp:72)
     GCNHIP_CHECK(gcnhip_spmm_bwd(env->ctx, sp, *vals, c->grad, c->ld, b->grad, b->ld, p, pd,
@@ -187,7 +203,18 @@ void HipGraphSum::backward() {
     const float *src = out->full_grad ? out->full_grad : out->grad;
     env->timers->start(TMR_GRAPHSUM_BW);
     if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-    if (out_grad_pack)
+    if (pipe && pipe_consumer && !env->timers->enabled && !out_grad_pack && !row_bits && !bwd_graph) {
+        // (with per-op timers on, every launch runs alone on the main stream: the branches below)
+        const size_t nb = pipe->blocks.size();
+        for (size_t k = 0; k < nb; k++) {
+            GCNHIP_CHECK(gcnhip_graphsum_rowset(env->ctx, graph, pipe->blocks[k], src, out->ld, in->grad, in->ld, dim, nullptr));
+            GCNHIP_CHECK(gcnhip_event_record(env->ctx, pipe->ev_block[k]));
+            GCNHIP_CHECK(gcnhip_stream_wait_event(pipe->side, pipe->ev_block[k]));
+            pipe_consumer->backward_part((int)k);
+        }
+        pipe_consumer->backward_finish();
+        pipe->armed = true;
+    } else if (out_grad_pack)
         GCNHIP_CHECK(gcnhip_graphsum_packed(env->ctx, graph, out_grad_pack, src, out->ld, in->grad, in->ld));
     else if (row_bits)
         GCNHIP_CHECK(gcnhip_graphsum_rowmask(env->ctx, graph, src, out->ld, in->grad, in->ld, dim, row_bits));

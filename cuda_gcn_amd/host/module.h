@@ -10,6 +10,7 @@
 //  * fused (default): the input Dropout folds into SparseMatmul, ReLU+Dropout
 //    into GraphSum's store epilogue and into Matmul's backward epilogue.
 #pragma once
+#include <vector>
 #include <cstdint>
 #include "comm.h"
 #include "gcnhip.h"
@@ -32,6 +33,19 @@ struct HipEnv {
     const uint8_t *keep_hidden = nullptr;    // [local rows * hidden]
     // opt-in: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate); beyond the reference's f32 path
     bool bf16_tables = false;
+};
+
+// The hidden layer's backward aggregation hands dH0 to the weight gradient dW1 = X~^T . dH0 in row blocks: the
+// aggregation of block k+1 (gather-bound) runs beside the split-K product of block k (MFMA-bound) on a second stream.
+// Same kernels on the same rows and the same split ranges as the one-stream order: not a bit changes.  OPT-IN
+// (HIPGCN_BWD_PIPELINE): on one MI355X it measured slower than the one-stream order (gcn.cpp, build_modules).
+struct BackwardPipeline {
+    gcnhip_ctx *side = nullptr;              // the second stream (it owns the split-K slabs of the product)
+    std::vector<gcnhip_rowset *> blocks;     // row blocks, registered on the hidden layer's adjacency object
+    std::vector<int> cuts;                   // block k = splits [cuts[k], cuts[k+1]) of gcnhip_spmm_bwd_plan
+    std::vector<void *> ev_block;            // main stream: block k of dH0 is complete
+    void *ev_done = nullptr;                 // side stream: dW1 is complete
+    bool armed = false;                      // the backward in progress went through the pipeline
 };
 
 class Module {
@@ -73,6 +87,9 @@ public:
     gcnhip_feat *sp_full = nullptr;
     const float *const *vals_full = nullptr;
     bool relu_out = false;          // evaluation on A^.X: ReLU when the product is stored (forward(false) only)
+    BackwardPipeline *pipe = nullptr;       // set: the producer of c->grad may run backward_part/_finish block by block
+    void backward_part(int block);
+    void backward_finish();
     HipSparseMatmul(HipEnv *env, const float *const *vals, HipVariable *b, HipVariable *c, gcnhip_feat *sp,
                     int m, int n, int p, float fused_dropout, uint64_t nnz_offset);
     void forward(bool) override;
@@ -102,6 +119,9 @@ public:
     gcnhip_rowset *const *fwd_out_rows = nullptr;
     // backward(): out->grad arrives as packed rows (written by HipMatmul::backward into the same pack)
     gcnhip_rowpack *out_grad_pack = nullptr;              // a subset registered on `graph` (gcnhip_graph_add_rowset)
+    // backward(): in->grad is produced block by block and handed to this consumer's weight gradient (BackwardPipeline)
+    BackwardPipeline *pipe = nullptr;
+    HipSparseMatmul *pipe_consumer = nullptr;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
     ~HipGraphSum() override;

@@ -250,6 +250,25 @@ class Device:
                                                 nnz_offset, km.ptr if km else None), "gcnhip_spmm_bwd")
         return dw.download()[:, :p]
 
+    def spmm_bwd_plan(self, f: "Feat", p):
+        rps, ns = C.c_int(), C.c_int()
+        _ck(self.lib, self.lib.gcnhip_spmm_bwd_plan(self.ctx, f.h, p, C.byref(rps), C.byref(ns)), "gcnhip_spmm_bwd_plan")
+        return rps.value, ns.value
+
+    def spmm_bwd_parts(self, f: "Feat", dout, cuts, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, order=None):
+        """the weight gradient as gcnhip_spmm_bwd_part calls on the split ranges between `cuts` (in `order`), then _finish"""
+        dout = np.asarray(dout, np.float32)
+        p = dout.shape[1]
+        db = self.padded(dout, p)
+        dw = self.buf(np.full((f.n_cols, p), np.nan, np.float32))
+        ep = self.buf(np.array([epoch], np.uint32))
+        ranges = list(zip(cuts[:-1], cuts[1:]))
+        for k, i in enumerate(order if order is not None else range(len(ranges))):
+            _ck(self.lib, self.lib.gcnhip_spmm_bwd_part(self.ctx, f.h, f.values_ptr, db.ptr, p, p, p_drop, seed, ep.ptr, nnz_offset, None,
+                                                         ranges[i][0], ranges[i][1], 1 if k == 0 else 0), "gcnhip_spmm_bwd_part")
+        _ck(self.lib, self.lib.gcnhip_spmm_bwd_finish(self.ctx, f.h, dw.ptr, p, p), "gcnhip_spmm_bwd_finish")
+        return dw.download()
+
     def matmul_fwd(self, a, b, lda=None, ldb=None, ldc=None):
         a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
         m, n = a.shape

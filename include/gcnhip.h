@@ -197,6 +197,20 @@ int gcnhip_spmm_fwd_relu(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *val
 int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
                     float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
                     uint64_t nnz_offset, const uint8_t *keep_mask);
+/* The dense weight gradient (dense X, p > 64) is a split-K product: n_splits row ranges of rows_per_split rows each
+ * write a partial [n_cols x p] slab, and an ordered sum of the slabs gives dW (no atomics: the same bits every run).
+ * The three steps are also callable one by one, so that a caller whose dOut arrives in row blocks (the hidden layer's
+ * backward aggregation, computed block by block on another stream) can start on the first blocks while the rest is
+ * still being produced:  _plan reports the ranges (n_splits == 0: this shape does not take the split-K path, use
+ * gcnhip_spmm_bwd);  _part computes splits [split_begin, split_end) into the context's slabs — rows
+ * [split_begin * rows_per_split, min(n_rows, split_end * rows_per_split)) of X and dOut are all it reads;
+ * make_decisions != 0 (re)generates the input-dropout decisions first, once per backward;  _finish sums the slabs of
+ * the same context.  gcnhip_spmm_bwd is exactly _part(0, n_splits, 1) + _finish. */
+int gcnhip_spmm_bwd_plan(const gcnhip_ctx *ctx, const gcnhip_feat *f, int p, int *rows_per_split, int *n_splits);
+int gcnhip_spmm_bwd_part(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,
+                         float p_drop, uint64_t seed, const uint32_t *d_epoch, uint64_t nnz_offset, const uint8_t *keep_mask,
+                         int split_begin, int split_end, int make_decisions);
+int gcnhip_spmm_bwd_finish(gcnhip_ctx *ctx, const gcnhip_feat *f, float *dw, int ld_dw, int p);
 
 /* ---- opt-in storage format: bfloat16 gathered tables (beyond the reference) ----------
  * gcnhip_f32_to_bf16 rounds rows of f32 to bf16 (nearest even; NaN kept) into a table with row stride ld_dst

@@ -50,6 +50,9 @@ enum {
                                            env HIPGCN_EXCHANGE=halo|allgather) */
     GCNHOST_PACKED_DH1 = 65536,       /* opt-in: dH1 travels to the hidden layer's backward gather as packed rows (bit-identical to the
                                          dense gather, measured slower on gfx950; env HIPGCN_PACKED_DH1=1 does the same) */
+    GCNHOST_BWD_PIPELINE = 262144,    /* opt-in: hidden-layer backward aggregation in row blocks, each block's share of the first layer's
+                                         weight gradient on a second stream (bit-identical; measured slower on one MI355X; env
+                                         HIPGCN_BWD_PIPELINE=1; HIPGCN_BWD_CHUNKS sets the number of blocks, default 4) */
     GCNHOST_MASKED_BWD = 131072,      /* the output layer's backward masks the rows of dZ outside the training split at every launch
                                          (default: aggregates through gcnhip_graph_create_restricted's operator; env HIPGCN_MASKED_BWD=1) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */

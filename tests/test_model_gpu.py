@@ -348,6 +348,27 @@ def test_restricted_backward_operator_matches_masked_launch(name, hidden):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("extra", ["graph", "no_graph", "lane"])
+def test_backward_pipeline_is_bit_identical(extra, monkeypatch):
+    """opt-in BWD_PIPELINE: hidden-layer backward aggregation in row blocks with each block's share of dW1 on a second
+    stream against the one-stream order: same kernels, same rows, same split ranges — not a bit of any trace or
+    weight differs, replayed from a captured hipGraph, eagerly, or beside the validation lane"""
+    from cuda_gcn_amd.model import HipGCNModel, BWD_PIPELINE, NO_GRAPH, EVAL_LANE
+    monkeypatch.setenv("HIPGCN_BWD_CHUNKS", "3")
+    fl = {"graph": 0, "no_graph": NO_GRAPH, "lane": EVAL_LANE}[extra]
+    ds = datagen.make_dataset("reddit-mini")
+    a = HipGCNModel(ds, seed=8, flags=fl | BWD_PIPELINE, hidden_dim=128, dropout=0.5, epochs=16)
+    b = HipGCNModel(ds, seed=8, flags=fl, hidden_dim=128, dropout=0.5, epochs=16)
+    ta, tb = a.run_epochs(12), b.run_epochs(12)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert a.train_epoch() == b.train_epoch()
+    for v in (2, 5):
+        assert np.array_equal(a.var(v).view(np.uint32), b.var(v).view(np.uint32))
+        assert np.array_equal(a.var(v, True).view(np.uint32), b.var(v, True).view(np.uint32))
+    assert np.array_equal(a.var(1, True).view(np.uint32), b.var(1, True).view(np.uint32))       # dH0, block by block
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""

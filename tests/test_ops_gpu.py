@@ -217,6 +217,30 @@ def test_packed_rows_backward_is_bit_identical_to_dense(dev, gname, n, density):
     g.free()
 
 
+def test_spmm_bwd_in_parts_is_bit_identical(dev):
+    """gcnhip_spmm_bwd_plan/_part/_finish: the split ranges computed in several calls, in any order, with dropout, give
+    the bits of the one-call form"""
+    rng = np.random.default_rng(5)
+    n, F, p = 5000, 200, 128
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    fp = (np.arange(n + 1, dtype=np.int64) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), n)
+    f = dev.feat(fp, fi, x.reshape(-1), F)
+    assert f.dense
+    dout = rng.standard_normal((n, p)).astype(np.float32)
+    rps, ns = dev.spmm_bwd_plan(f, p)
+    assert rps % 32 == 0 and (ns - 1) * rps < n <= ns * rps and ns >= 8
+    for pd in (0.0, 0.5):
+        want = dev.spmm_bwd(f, dout, p_drop=pd, seed=11, epoch=3)
+        cuts = [0, ns // 4, ns // 4, ns // 2 + 1, ns]                    # an empty range among them
+        got = dev.spmm_bwd_parts(f, dout, cuts, p_drop=pd, seed=11, epoch=3)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        got = dev.spmm_bwd_parts(f, dout, cuts, p_drop=pd, seed=11, epoch=3, order=[3, 0, 2, 1])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert dev.spmm_bwd_plan(f, 41) == (0, 0)                               # narrow outputs do not take the split-K path
+    f.free()
+
+
 def test_edge_coef_bit_exact(dev):
     ds = datagen.make_dataset("cora-syn")
     gp, gi = ds["g_indptr"], ds["g_indices"]
