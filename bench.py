@@ -28,7 +28,8 @@ Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
     stream in a separate pass of the same process (timers ON), against the bound that binds it;
   * `roofline.hbm_regime`: the same kernel on an R-MAT graph whose table (1 GiB) is far beyond the
     Infinity Cache — the fraction of the HBM roofline proper;
-  * `value_no_row_groups`: the headline with the label-major aggregation schedule disabled.
+  * `value_no_label_hint`: the headline with the dataset's labels withheld from the aggregation's row schedule (row
+    groups are then found in the graph itself by label propagation); `value_no_row_groups`: no row groups at all.
 """
 import argparse
 import json
@@ -277,7 +278,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)    # control plane; data plane is RCCL in libgcnhost
 
     from cuda_gcn_amd import datagen
-    from cuda_gcn_amd.model import (HipGCNModel, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, NO_ROW_GROUPS, NO_AGG_FIRST_EVAL,
+    from cuda_gcn_amd.model import (HipGCNModel, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, NO_ROW_GROUPS, NO_LABEL_HINT, NO_AGG_FIRST_EVAL,
                                     ALL_ROWS, nccl_unique_id)
 
     def barrier():
@@ -457,8 +458,17 @@ def main():
         }
 
     extras = world == 1 and not args.no_extras
+    if extras and not args.no_row_groups and schedule == "label-major":
+        # the same headline with the labels withheld from the schedule: row groups found in the graph (host/cluster.h)
+        m2, _ = build(base_flags | NO_LABEL_HINT)
+        m2.run_epochs(args.warmup, want_trace=False)
+        d2, _tr = timed_region(m2, args.steps)
+        out["value_no_label_hint"] = args.steps / d2
+        out["config"]["aggregation_schedule_no_label_hint"] = m2.schedule()
+        m2.close()
+        log(f"no label hint: {args.steps / d2:.2f} epochs/s")
     if extras and not args.no_row_groups and schedule != "degree":
-        # the same headline without the label hint (structure-blind schedule: plain descending degree)
+        # ... and with no row groups of any kind (plain descending degree)
         m2, _ = build(base_flags | NO_ROW_GROUPS)
         m2.run_epochs(args.warmup, want_trace=False)
         d2, _tr = timed_region(m2, args.steps)

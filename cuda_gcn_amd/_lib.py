@@ -198,6 +198,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
     "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),
     "gcnhost_rmat_graph": (I, [I, I, U64, PP, PP, C.POINTER(I64)]),
+    "gcnhost_structure_groups": (I, [P, P, I, P, C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double), C.POINTER(I)]),
     "gcnhost_free_array": (None, [P]),
 }
 

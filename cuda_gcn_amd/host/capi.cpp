@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include "gcn.h"
+#include "cluster.h"
 #include "hip_check.h"
 #include "parser.h"
 
@@ -297,6 +298,19 @@ int gcnhost_plan_arrays(const gcnhost_plan *p, const int **recv_off, const int *
     return 0;
 }
 int gcnhost_plan_free(gcnhost_plan *p) { delete p; return 0; }
+
+int gcnhost_structure_groups(const int *g_indptr, const int *g_indices, int n_rows, int *group, int *n_groups, int *sweeps,
+                             double *largest_share, int *useful) {
+    if (!g_indptr || !g_indices || n_rows < 0 || !group) return -1;
+    API_TRY({
+        const StructureGroups sg = structure_groups(g_indptr, g_indices, n_rows);
+        if (n_rows) memcpy(group, sg.group.data(), (size_t)n_rows * sizeof(int));
+        if (n_groups) *n_groups = sg.n_groups;
+        if (sweeps) *sweeps = sg.sweeps;
+        if (largest_share) *largest_share = sg.largest_share;
+        if (useful) *useful = sg.useful ? 1 : 0;
+    })
+}
 
 int gcnhost_glorot(float *w, int size, int in_size, int out_size, long seed, int skip_draws) {
     HostRng rng;

@@ -1,4 +1,5 @@
 #include "gcn.h"
+#include "cluster.h"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -92,7 +93,14 @@ void HipGCN::init(const HipGCNOptions &opt) {
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
     n_local = r1 - r0;
     nnzA_local = (long)gp[r1] - gp[r0];
-    labels_assortative = !(flags & HIPGCN_NO_ROW_GROUPS) && labels_are_assortative(*data, N, C);
+    if (getenv("HIPGCN_NO_LABEL_HINT")) flags |= HIPGCN_NO_LABEL_HINT;
+    labels_assortative = !(flags & (HIPGCN_NO_ROW_GROUPS | HIPGCN_NO_LABEL_HINT)) && labels_are_assortative(*data, N, C);
+    // no usable labels: look for row groups in the graph itself (one pass over the edges per sweep, every rank the same
+    // result); whether they are used is decided by timing, like every other schedule (tune_schedule)
+    if (!(flags & HIPGCN_NO_ROW_GROUPS) && !labels_assortative && n_local >= 4096 && !getenv("HIPGCN_NO_STRUCTURE_GROUPS")) {
+        StructureGroups sg = structure_groups(gp.data(), gi.data(), N);
+        if (sg.useful) { structure_group = std::move(sg.group); structure_n_groups = sg.n_groups; }
+    }
     {
         int mode = (flags & HIPGCN_EXCHANGE_HALO) ? 2 : ((flags & HIPGCN_EXCHANGE_ALLGATHER) ? 1 : 0);
         if (const char *e = getenv("HIPGCN_EXCHANGE")) mode = !strcmp(e, "halo") ? 2 : (!strcmp(e, "allgather") ? 1 : mode);
@@ -273,12 +281,16 @@ void HipGCN::init(const HipGCNOptions &opt) {
 
 // Which rows the aggregation has in flight together decides its speed (what the XCD L2s hold; whether hub rows
 // overlap with the tail of short rows) and nothing else: every schedule gives the same bits.  Candidates:
-// descending degree; label-major when the labels are communities of this graph (Reddit: subreddits); degree rank
+// descending degree; label-major when the labels are communities of this graph (Reddit: subreddits), else group-major over
+// groups found in the graph by label propagation (cluster.h) when that finds any; degree rank
 // dealt into 256 equal-mix groups (graphs with a long tail of short rows, e.g. R-MAT).  Each is timed on the
 // hidden-width aggregation of this rank's rows and the fastest is kept for all of this rank's adjacency objects.
 void HipGCN::apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g) {
-    const int *labels = data->label.data() + part.start[env.comm->rank()];
-    GCNHIP_CHECK(gcnhip_graph_set_schedule(ctx, g, sched_mode, sched_mode == 1 ? labels : nullptr, sched_groups));
+    const int r0 = part.start[env.comm->rank()];
+    if (sched_mode == 3)                                      // groups found in the graph: the same group-major order as labels
+        GCNHIP_CHECK(gcnhip_graph_set_schedule(ctx, g, 1, structure_group.data() + r0, 0));
+    else
+        GCNHIP_CHECK(gcnhip_graph_set_schedule(ctx, g, sched_mode, sched_mode == 1 ? data->label.data() + r0 : nullptr, sched_groups));
 }
 
 void HipGCN::add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *out[4]) {
@@ -301,6 +313,7 @@ void HipGCN::tune_schedule() {
     struct Cand { int mode, groups; };
     std::vector<Cand> cands = {{0, 0}, {2, 256}};
     if (labels_assortative) cands.push_back({1, 0});
+    if (!structure_group.empty()) cands.push_back({3, structure_n_groups});
     void *e0, *e1;
     GCNHIP_CHECK(gcnhip_event_create(&e0));
     GCNHIP_CHECK(gcnhip_event_create(&e1));

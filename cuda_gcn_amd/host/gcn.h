@@ -47,6 +47,8 @@ enum HipGCNFlags {
     HIPGCN_EXCHANGE_HALO = 32768,      // ... or always exchange only the rows some local edge points at (default: decided per graph)
     HIPGCN_BWD_PIPELINE = 262144,      // opt-in: the hidden layer's backward aggregation in row blocks, each block's share of the first
                                        // layer's weight gradient on a second stream (same bits; measured slower)
+    HIPGCN_NO_LABEL_HINT = 524288,     // never use the dataset's labels as row groups of the aggregation's schedule (groups are then
+                                       // looked for in the graph itself, cluster.h)
     HIPGCN_MASKED_BWD = 131072,        // the output layer's backward masks the known-zero rows of dZ at every launch instead of
                                        // aggregating through an operator that has lost the edges pointing at them
     HIPGCN_PACKED_DH1 = 65536,         // opt-in: dH1 reaches the hidden layer's backward gather as packed rows (same bits; measured slower)
@@ -212,6 +214,8 @@ private:
     // row schedule of the aggregation (gcnhip_graph_set_schedule): candidates timed once, fastest kept
     int sched_mode = 0, sched_groups = 0;
     bool labels_assortative = false;
+    std::vector<int> structure_group;                          // per node: group found in the graph (cluster.h); empty: none useful
+    int structure_n_groups = 0;
     void tune_schedule();
     void apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g);
     void add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *out[4]);

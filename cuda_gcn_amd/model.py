@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO, PACKED_DH1, MASKED_BWD, BWD_PIPELINE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144
+MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO, PACKED_DH1, MASKED_BWD, BWD_PIPELINE, NO_LABEL_HINT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288
 TIMER_NAMES = ["train", "test", "matmul_fw", "matmul_bw", "spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw",
                "loss_fw", "relu_fw", "relu_bw", "dropout_fw", "dropout_bw", "adam", "comm", "graphsum_wide"]
 
@@ -117,10 +117,11 @@ class HipGCNModel:
         _ck(self.lib, self.lib.gcnhost_model_set_weights(self.h, w1.ctypes.data, w2.ctypes.data), "set_weights")
 
     def schedule(self):
-        """row schedule of the aggregation picked at construction: 'degree', 'label-major' or 'dealt-<G>'"""
+        """row schedule of the aggregation picked at construction: 'degree', 'label-major', 'dealt-<G>' or
+        'structure-major (<G> groups)' — groups found in the graph by label propagation"""
         m, g = C.c_int(), C.c_int()
         _ck(self.lib, self.lib.gcnhost_model_schedule(self.h, C.byref(m), C.byref(g)), "schedule")
-        return {0: "degree", 1: "label-major", 2: f"dealt-{g.value}"}[m.value]
+        return {0: "degree", 1: "label-major", 2: f"dealt-{g.value}", 3: f"structure-major ({g.value} groups)"}[m.value]
 
     def timer(self, name_or_id):
         i = TIMER_NAMES.index(name_or_id) if isinstance(name_or_id, str) else int(name_or_id)

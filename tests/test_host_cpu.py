@@ -223,3 +223,58 @@ def test_exchange_plans_are_consistent_across_ranks(name, world, mode, oracle):
         got = np.zeros((r1 - r0, 5), np.float64)
         np.add.at(got, src, coef[:, None].astype(np.float64) * table[ix].astype(np.float64))
         assert np.allclose(got, want[r0:r1], rtol=1e-5, atol=1e-5)
+
+
+def _structure_groups(gp, gi):
+    import ctypes as C
+    from cuda_gcn_amd import _lib
+    lib = _lib.gcnhost()
+    n = gp.size - 1
+    gp, gi = np.ascontiguousarray(gp, np.int32), np.ascontiguousarray(gi, np.int32)
+    grp = np.full(max(n, 1), -7, np.int32)
+    ng, sw, us, ls = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    assert lib.gcnhost_structure_groups(gp.ctypes.data, gi.ctypes.data, n, grp.ctypes.data, C.byref(ng), C.byref(sw), C.byref(ls), C.byref(us)) == 0
+    return grp[:n], ng.value, sw.value, ls.value, bool(us.value)
+
+
+def test_structure_groups_find_planted_communities():
+    """row groups for the aggregation's schedule from the graph alone (host/cluster.h, size-constrained label
+    propagation): on a planted partition the groups hold far more of the edges than chance, none exceeds the size
+    bound, nothing collapses into one group, and the result is deterministic"""
+    ds = datagen.make_dataset("reddit-mini")
+    gp, gi, lab = ds["g_indptr"], ds["g_indices"], ds["label"]
+    n = gp.size - 1
+    grp, ng, sweeps, largest, useful = _structure_groups(gp, gi)
+    assert useful and 4 <= ng <= n and 1 <= sweeps <= 8
+    assert grp.min() == 0 and grp.max() == ng - 1
+    sizes = np.bincount(grp, minlength=ng)
+    assert sizes[:-1].max() <= 4096 and np.all(np.diff(sizes[:-1]) <= 0)          # bounded, largest first (the last may be the rest)
+    assert abs(largest - sizes[0] / n) < 1e-12
+    src = np.repeat(np.arange(n), np.diff(gp))
+    nl = src != gi
+    inside = float((grp[src[nl]] == grp[gi[nl]]).mean())
+    chance = float(((sizes / n) ** 2).sum())
+    label_inside = float((lab[src[nl]] == lab[gi[nl]]).mean())
+    assert inside >= 4 * chance and inside >= 0.5 * label_inside, (inside, chance, label_inside)
+    again = _structure_groups(gp, gi)
+    assert np.array_equal(again[0], grp) and again[1:] == (ng, sweeps, largest, useful)
+
+
+def test_structure_groups_degenerate_inputs():
+    # no edges but the self loops: nothing merges -> not useful, every node in the one trailing group
+    n = 100
+    gp = np.arange(n + 1, dtype=np.int32); gi = np.arange(n, dtype=np.int32)
+    grp, ng, _, _, useful = _structure_groups(gp, gi)
+    assert not useful and ng == 1 and not grp.any()
+    # a clique below the size bound: one group -> not useful
+    m = 50
+    gp = (np.arange(m + 1) * m).astype(np.int32); gi = np.tile(np.arange(m, dtype=np.int32), m)
+    grp, ng, _, largest, useful = _structure_groups(gp, gi)
+    assert not useful and ng == 1 and largest == 1.0
+    # the empty graph
+    grp, ng, _, _, useful = _structure_groups(np.zeros(1, np.int32), np.zeros(0, np.int32))
+    assert grp.size == 0 and ng == 0 and not useful
+    # an R-MAT graph (no communities to find): valid groups, whatever their use
+    gp, gi = datagen.rmat_graph(12)
+    grp, ng, _, _, _ = _structure_groups(gp, gi)
+    assert grp.min() >= 0 and grp.max() == ng - 1

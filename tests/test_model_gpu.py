@@ -369,6 +369,21 @@ def test_backward_pipeline_is_bit_identical(extra, monkeypatch):
     a.close(); b.close()
 
 
+def test_structure_groups_schedule_is_bit_identical():
+    """labels withheld (NO_LABEL_HINT): the row groups come from the graph (label propagation) — another order of the
+    task list, the same bits"""
+    from cuda_gcn_amd.model import HipGCNModel, NO_LABEL_HINT
+    ds = datagen.make_dataset("reddit-mini")
+    a = HipGCNModel(ds, seed=6, flags=NO_LABEL_HINT, hidden_dim=32, dropout=0.5, epochs=4)
+    b = HipGCNModel(ds, seed=6, hidden_dim=32, dropout=0.5, epochs=4)
+    assert a.schedule() in ("degree", "dealt-256") or a.schedule().startswith("structure-major")
+    assert b.schedule() != a.schedule() or b.schedule() in ("degree", "dealt-256")
+    ta, tb = a.run_epochs(4), b.run_epochs(4)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert np.array_equal(a.var(2), b.var(2)) and np.array_equal(a.var(6), b.var(6))
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""
