@@ -5,6 +5,7 @@
 // Here: one wave64 per row (lane j holds logit j; C > 64 loops), wave-shuffle
 // max / sum, per-block partials reduced in block order (bitwise reproducible).
 #include "common.h"
+#include <stdlib.h>
 #pragma clang fp contract(off)
 
 struct XentArgs {
@@ -118,6 +119,77 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
     }
 }
 
+// ---- narrow logits (C <= 64, rows of whole float4 pieces): one LANE per row --------------------------------------
+// The wave-per-row form above walks ~19 rows per wave at Reddit scale, each a dependent chain rows[q] -> logits -> two
+// wave reductions, with 41 of 64 lanes busy: 62 us for 154 K rows of 41 classes, 1 TB/s.  Here a lane owns a row: its
+// NV4 float4 loads are independent and all in flight at once, max / sum run down the lane's registers IN THE REFERENCE'S
+// ORDER (module.cpp:135-143 sums exp left to right; the wave form used a shuffle tree), no shuffles until the block's
+// partials.  Same partial layout and finalize kernel as the wave form.
+template <int NV4>
+__global__ __launch_bounds__(256) void xent_lane_kernel(XentArgs a) {
+    __shared__ float sh_f[4];
+    __shared__ int sh_i[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float cnt = (float)(a.count > 0 ? a.count : (a.d_count ? *a.d_count : 0));
+    float loss = 0.f;
+    int correct = 0, total = 0;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < a.n_rows; q += gridDim.x * 256) {
+        const int r = a.rows ? a.rows[q] : q;
+        const int t = a.truth[r];
+        float *lg = a.logits + (size_t)r * a.ld;
+        float *gr = a.grad ? a.grad + (size_t)r * a.ld_grad : nullptr;
+        if (t < 0) {                                   // unlabelled: grad row stays 0 (module.cpp:129,132)
+            if (a.training && gr)
+#pragma unroll
+                for (int k = 0; k < NV4; k++) reinterpret_cast<float4 *>(gr)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        float v[4 * NV4];
+#pragma unroll
+        for (int k = 0; k < NV4; k++) {
+            const float4 x = reinterpret_cast<const float4 *>(lg)[k];
+            v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
+        }
+        total++;
+        float mx = -1e30f, tv = -INFINITY;             // module.cpp:135
+#pragma unroll
+        for (int j = 0; j < 4 * NV4; j++) {
+            if (j < a.C) mx = fmaxf(mx, v[j]);
+            tv = j == t ? v[j] : tv;
+        }
+        if (!(mx > tv)) correct++;                     // gcn.cpp:88-93: wrong iff some logit is strictly above the true one
+        if (a.acc_only) continue;
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4 * NV4; j++) {
+            v[j] -= mx;                                // module.cpp:140
+            if (a.shift && j < a.C) lg[j] = v[j];
+            v[j] = j < a.C ? expf(v[j]) : 0.f;
+            se += v[j];                                // left to right, as module.cpp:141-142
+        }
+        loss += logf(se) - (tv - mx);                  // module.cpp:143
+        if (a.training && gr) {
+#pragma unroll
+            for (int j = 0; j < 4 * NV4; j++) {
+                float p = v[j] / se;                   // module.cpp:147
+                if (j == t) p = (float)((double)p - 1.0);
+                v[j] = j < a.C ? p / cnt : 0.f;        // module.cpp:157; the padding columns stay zero
+            }
+#pragma unroll
+            for (int k = 0; k < NV4; k++)
+                reinterpret_cast<float4 *>(gr)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+    }
+    loss = wave_sum(loss); correct = wave_sum_i(correct); total = wave_sum_i(total);
+    if (lane == 0) { sh_f[wave] = loss; sh_i[wave * 2] = correct; sh_i[wave * 2 + 1] = total; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.part_f[blockIdx.x] = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
+        a.part_i[blockIdx.x * 2] = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
+        a.part_i[blockIdx.x * 2 + 1] = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
+    }
+}
+
 __global__ __launch_bounds__(256) void count_labelled_kernel(const int32_t *truth, int n, int32_t *part) {
     int c = 0;
     const int chunk = (n + gridDim.x - 1) / gridDim.x;
@@ -181,7 +253,22 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
         GCNHIP_LAUNCH_CHECK();
         a.d_count = c->red_i + 8192;
     }
-    xent_kernel<<<blocks, 256, 0, c->stream>>>(a);
+    // a lane per row when the rows are whole, aligned float4 pieces of at most 64 classes
+    const int nv4 = (a.C + 3) / 4;
+    static const bool force_wave = getenv("GCNHIP_XENT_WAVE") != nullptr;     // A/B aid
+    const bool lanes = !force_wave && a.C <= 64 && a.n_rows > 0 && a.ld % 4 == 0 && a.ld >= 4 * nv4 && aligned16(a.logits) &&
+                       (!a.grad || (a.ld_grad % 4 == 0 && a.ld_grad >= 4 * nv4 && aligned16(a.grad)));
+    if (lanes) {
+        blocks = ceil_div(a.n_rows, 256);
+        if (blocks > 2048) blocks = 2048;
+        switch (nv4) {
+#define XL(N) case N: xent_lane_kernel<N><<<blocks, 256, 0, c->stream>>>(a); break;
+            XL(1) XL(2) XL(3) XL(4) XL(5) XL(6) XL(7) XL(8) XL(9) XL(10) XL(11) XL(12) XL(13) XL(14) XL(15) XL(16)
+#undef XL
+        }
+    } else {
+        xent_kernel<<<blocks, 256, 0, c->stream>>>(a);
+    }
     GCNHIP_LAUNCH_CHECK();
     xent_finalize_kernel<<<1, 256, 0, c->stream>>>(a.part_f, a.part_i, blocks, d_result, d_result_i, a.acc_only);
     GCNHIP_LAUNCH_CHECK();
