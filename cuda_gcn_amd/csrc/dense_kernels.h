@@ -65,12 +65,29 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
     constexpr int NCLD = NT * 16 + 4;        // +4: the four k-groups of a wave hit disjoint banks
     const int Kp = (a.K + 15) / 16 * 16;
     const int c_base = blockIdx.y * NT * 16;
-    for (int idx = threadIdx.x; idx < Kp * NT * 16; idx += blockDim.x) {
-        const int k = idx / (NT * 16), c = idx % (NT * 16);
-        const int gc = c_base + c;
-        float v = 0.f;
-        if (k < a.K && gc < a.Nc) v = a.transB ? a.B[(size_t)gc * a.ldb + k] : a.B[(size_t)k * a.ldb + gc];
-        Bs[k * NCLD + c] = v;
+    // The small operand into LDS, 8 elements per thread in flight: unconditional loads from clamped addresses (element 0
+    // for the padding), zeroed by selects.  As a loop of one predicated load per iteration this prologue was 24 dependent
+    // round trips per workgroup (5 us of a 48 us launch at Reddit scale).
+    {
+        const int total = Kp * NT * 16;
+        for (int base = threadIdx.x; base < total; base += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = base + u * 256;
+                const int k = idx / (NT * 16), c = idx % (NT * 16);
+                const int gc = c_base + c;
+                const bool in = idx < total && k < a.K && gc < a.Nc;
+                const size_t off = in ? (a.transB ? (size_t)gc * a.ldb + k : (size_t)k * a.ldb + gc) : 0;
+                const float x = a.B[off];
+                v[u] = in ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = base + u * 256;
+                if (idx < total) Bs[(idx / (NT * 16)) * NCLD + idx % (NT * 16)] = v[u];
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,8 +116,26 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
         for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (KCH > 0) {
             float av[KCH > 0 ? KCH : 1][4];
+            if (VEC && a.lda >= KCH * 16) {
+                // Every float4 of the K extent lies inside the row's allocation (wave-uniform test): the KCH loads are
+                // issued UNCONDITIONALLY from a clamped row — a load inside a per-lane branch is waited for at the end
+                // of that branch, which kept ONE load in flight per wave here until round 2 (the same disease as
+                // GraphSum's; H1.W2 at Reddit scale: 55 -> 42 us with the K = 128 case batched).  Rows past m compute on a copy of the last row and are never stored;
+                // columns past K (row padding) are zeroed by selects.
+                const float *apc = a.A + (size_t)min(row, a.m - 1) * a.lda + 4 * kq;
+                float4 raw[KCH > 0 ? KCH : 1];
 #pragma unroll
-            for (int c = 0; c < KCH; c++) load4(ap, c * 16 + 4 * kq, valid, av[c]);
+                for (int c = 0; c < KCH; c++) raw[c] = *reinterpret_cast<const float4 *>(apc + c * 16);
+#pragma unroll
+                for (int c = 0; c < KCH; c++) {
+                    const int kk = c * 16 + 4 * kq;
+                    av[c][0] = kk + 0 < a.K ? raw[c].x : 0.f; av[c][1] = kk + 1 < a.K ? raw[c].y : 0.f;
+                    av[c][2] = kk + 2 < a.K ? raw[c].z : 0.f; av[c][3] = kk + 3 < a.K ? raw[c].w : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < KCH; c++) load4(ap, c * 16 + 4 * kq, valid, av[c]);
+            }
 #pragma unroll
             for (int c = 0; c < KCH; c++) {
                 const int kk = c * 16 + 4 * kq;
@@ -516,6 +551,7 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
             case 2: RS2(NT_, V_, F_, 2); break;                                                           \
             case 3: RS2(NT_, V_, F_, 3); break;                                                           \
             case 4: RS2(NT_, V_, F_, 4); break;                                                           \
+            case 8: if (V_ && lda >= 128) RS2(NT_, V_, F_, 8); else RS2(NT_, V_, F_, 0); break;           \
             default: RS2(NT_, V_, F_, 0); break;                                                          \
         }                                                                                                 \
     } while (0)
