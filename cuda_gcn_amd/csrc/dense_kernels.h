@@ -427,17 +427,20 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(AtbArgs a) {
             }
 }
 
-// out[nidx][pidx] = sum over workers.  Each output is summed by 4 threads over 4
-// contiguous worker ranges; the 4 partials are added in range order (fixed tree:
-// bitwise reproducible).
+// out[nidx][pidx] = sum over workers.  Each output is summed by CH = 256 / OPB threads over CH contiguous worker
+// ranges; the CH partials are added in range order (fixed order: bitwise reproducible).  OPB outputs per block: 64 when
+// there are many outputs (dW1: 77 K), fewer when there are few outputs and many workers (dW2: 5 K outputs, 503 slabs —
+// with 64 per block that was 82 blocks of threads walking 126 slabs each, 34 us; see launch_slab_reduce).
+template <int OPB>
 static __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *slab, int n_workers, int n, int p, int p_ld,
                                                                  float *out, int ld_out) {
-    __shared__ float part[4][64];
+    constexpr int CH = 256 / OPB;
+    __shared__ float part[CH][OPB];
     const int64_t total = (int64_t)n * p;
-    const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
-    const int per = (n_workers + 3) / 4;
+    const int lane = threadIdx.x % OPB, chunk = threadIdx.x / OPB;
+    const int per = (n_workers + CH - 1) / CH;
     const int w0 = chunk * per, w1 = min(n_workers, w0 + per);
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    for (int64_t base = (int64_t)blockIdx.x * OPB; base < total; base += (int64_t)gridDim.x * OPB) {
         const int64_t i = base + lane;
         float acc = 0.f;
         int r = 0, c = 0;
@@ -448,9 +451,22 @@ static __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *sl
         }
         part[chunk][lane] = acc;
         __syncthreads();
-        if (chunk == 0 && i < total) out[(size_t)r * ld_out + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (chunk == 0 && i < total) {
+            float v = part[0][lane];
+#pragma unroll
+            for (int k = 1; k < CH; k++) v += part[k][lane];
+            out[(size_t)r * ld_out + c] = v;
+        }
         __syncthreads();
     }
+}
+
+static inline void launch_slab_reduce(const float *slab, int n_workers, int n, int p, int p_ld, float *out, int ld_out, hipStream_t s) {
+    const int64_t total = (int64_t)n * p;
+    auto blocks = [&](int opb) { int64_t b = (total + opb - 1) / opb; return (int)(b > 4096 ? 4096 : b); };
+    if (total >= 64 * 512 || n_workers <= 16) slab_reduce_kernel<64><<<blocks(64), 256, 0, s>>>(slab, n_workers, n, p, p_ld, out, ld_out);
+    else if (total >= 16 * 512 || n_workers <= 64) slab_reduce_kernel<16><<<blocks(16), 256, 0, s>>>(slab, n_workers, n, p, p_ld, out, ld_out);
+    else slab_reduce_kernel<8><<<blocks(8), 256, 0, s>>>(slab, n_workers, n, p, p_ld, out, ld_out);
 }
 
 static inline int ensure_slab(gcnhip_ctx *c, size_t bytes) {
@@ -508,9 +524,7 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     else ATB(1, 1);
 #undef ATB
     GCNHIP_LAUNCH_CHECK();
-    int rb = ceil_div((int64_t)n * p, 64);
-    if (rb > 4096) rb = 4096;
-    slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(a.slab, n_slabs, n, p, a.p_ld, out, ld_out);
+    launch_slab_reduce(a.slab, n_slabs, n, p, a.p_ld, out, ld_out, c->stream);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

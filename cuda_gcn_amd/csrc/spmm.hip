@@ -435,9 +435,7 @@ static int dense_bwd_finish(gcnhip_ctx *c, const gcnhip_feat *f, float *dw, int 
     if (!dense_bwd_plan(c, f, p, &rps, &S)) return -1;
     const int p_ld = (p + 3) / 4 * 4;
     if (!c->slab || c->slab_bytes < (size_t)S * f->n_cols * p_ld * sizeof(float)) return -1;   // no part has run on this context
-    int rb = ceil_div((int64_t)f->n_cols * p, 64);
-    if (rb > 4096) rb = 4096;
-    slab_reduce_kernel<<<rb, 256, 0, c->stream>>>(c->slab, S, f->n_cols, p, p_ld, dw, ld_dw);
+    launch_slab_reduce(c->slab, S, f->n_cols, p, p_ld, dw, ld_dw, c->stream);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }
