@@ -44,6 +44,9 @@ HipSparseMatmul::HipSparseMatmul(HipEnv *env, const float *const *vals, HipVaria
 
 void HipSparseMatmul::forward(bool training) {
     last_training = training;
+    // a training forward through `sp` itself (not the replicated all-rows object) leaves this epoch's dropout decisions
+    // in sp's bit array; any other forward through sp (evaluation: no dropout) leaves them untouched
+    if (training) fwd_decisions_valid = fused_dropout > 0.f && !sp_full && !relu_out && gcnhip_feat_is_dense(sp);
     env->timers->start(TMR_SPMATMUL_FW);
     const float pd = training ? fused_dropout : 0.f;
     if (relu_out) {
@@ -79,9 +82,19 @@ void HipSparseMatmul::backward() {
     }
     env->timers->start(TMR_SPMATMUL_BW);
     const float pd = last_training ? fused_dropout : 0.f;     // the same X~ the forward saw (module.cpp:72)
-    GCNHIP_CHECK(gcnhip_spmm_bwd(env->ctx, sp, *vals, c->grad, c->ld, b->grad, b->ld, p, pd,
-                                 env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
-                                 pd > 0.f ? env->keep_input_bwd : nullptr));
+    int rps = 0, n_splits = 0;
+    GCNHIP_CHECK(gcnhip_spmm_bwd_plan(env->ctx, sp, p, &rps, &n_splits));
+    if (n_splits > 0 && pd > 0.f && fwd_decisions_valid) {
+        // the dropout decisions of this epoch's X~ are still in the object's bit array: this rank's forward wrote them
+        // (same object, same seed / epoch word / offset) and nothing has redrawn them since — no second generation pass
+        GCNHIP_CHECK(gcnhip_spmm_bwd_part(env->ctx, sp, *vals, c->grad, c->ld, p, pd, env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch,
+                                          nnz_offset, env->keep_input_bwd, 0, n_splits, 0));
+        GCNHIP_CHECK(gcnhip_spmm_bwd_finish(env->ctx, sp, b->grad, b->ld, p));
+    } else {
+        GCNHIP_CHECK(gcnhip_spmm_bwd(env->ctx, sp, *vals, c->grad, c->ld, b->grad, b->ld, p, pd,
+                                     env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
+                                     pd > 0.f ? env->keep_input_bwd : nullptr));
+    }
     env->timers->stop(TMR_SPMATMUL_BW);
 }
 

@@ -82,6 +82,7 @@ class HipSparseMatmul : public Module {
     float fused_dropout;            // > 0: input dropout applied on the fly (training only)
     uint64_t nnz_offset;            // global index of this rank's first stored value
     bool last_training = false;
+    bool fwd_decisions_valid = false;   // sp's keep-bit array holds the decisions of the last training forward
 public:
     // replicated forward (multi-GPU): X of ALL rows, so c->full is computed here and never gathered
     gcnhip_feat *sp_full = nullptr;
