@@ -286,12 +286,18 @@ __global__ __launch_bounds__(512) void dense_fwd_t128w8_kernel(Tile128Args a) {
         if (k0 + T_BK < a.K) fetch(k0 + T_BK);
         const float *Ap = &As[(wm * 32 + li) * T_ALD + kq];
         const float *Bp = &Bs[kq * T_BN + wn * 64 + li];
+        // operands of step kk+2 are read from LDS before the MFMAs of step kk are issued (the scheduler otherwise puts every
+        // read right in front of its use and the wave waits out the LDS latency once per MFMA pair)
+        float a0 = Ap[0], b0 = Bp[0], b1 = Bp[32];
 #pragma unroll
         for (int kk = 0; kk < T_BK; kk += 2) {
-            const float a0 = Ap[kk];
-            const float b0 = Bp[kk * T_BN], b1 = Bp[kk * T_BN + 32];
+            float an = 0.f, bn0 = 0.f, bn1 = 0.f;
+            if (kk + 2 < T_BK) { an = Ap[kk + 2]; bn0 = Bp[(kk + 2) * T_BN]; bn1 = Bp[(kk + 2) * T_BN + 32]; }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0] = MFMA32(a0, b0, acc[0]);
             acc[1] = MFMA32(a0, b1, acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = an; b0 = bn0; b1 = bn1;
         }
     }
 #pragma unroll
