@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
   * `roofline.hbm_regime`: the same kernel on an R-MAT graph whose table (1 GiB) is far beyond the
     Infinity Cache — the fraction of the HBM roofline proper;
   * `value_no_label_hint`: the headline with the dataset's labels withheld from the aggregation's row schedule (row
-    groups are then found in the graph itself by label propagation); `value_no_row_groups`: no row groups at all.
+    groups are then found in the graph itself by modularity local moving); `value_no_row_groups`: no row groups at all.
 """
 import argparse
 import json

@@ -3,16 +3,20 @@
 // an XCD's L2; rows that share neighbours should therefore be in flight together ("row schedule").
 // The reference has no counterpart: its GraphSum walks rows in file order (src/seq/module.cpp:85-101).
 //
-// Method: size-constrained label propagation (Raghavan, Albert, Kumara 2007; the size bound as in the coarsening of
-// Meyerhenke, Sanders, Schulz 2014), asynchronous, in a fixed pseudo-random node order — every node repeatedly joins the
-// group most of its neighbours are in among the groups that still have room, ties keep the current group.  The bound
-// (4096 nodes: 1 MiB of 256-byte row slices, a quarter of an XCD's L2) is what keeps plain label propagation from
-// flooding a graph with hubs into ONE group — measured: without it reddit-syn (56 % of the edges inside 41 planted
-// communities of 5.7 K nodes) collapses in three sweeps.  With the label hint withheld, reddit-syn on one MI355X:
-// bounds of 2048 / 4096 / 8192 / 16384 nodes -> 262 / 270 / 264 / 250 epochs/s (plain degree order: 193; the labels: 288).  One sweep costs one pass over the edges with a counter array (no hashing, no sorting).
-// Deterministic (fixed order, fixed tie rule), so every rank of a row-partitioned run finds the same groups.
-// The groups only ORDER the task list — any grouping, even a useless one, gives the same bits (tested); whether it is
-// used at all is decided by timing it against the other schedules (HipGCN::tune_schedule).
+// Method: the local-moving phase of the Louvain method (Blondel, Guillaume, Lambiotte, Lefebvre 2008) from singleton
+// groups, asynchronous, in a fixed pseudo-random node order: every node repeatedly joins the neighbouring group with the
+// largest modularity gain  k_i,c - tot_c * k_i / 2m  (k_i,c: its neighbours in c; tot_c: degree sum of c; ties and
+// non-positive gains keep the current group).  The degree-sum term is what plain label propagation lacks: that floods
+// a graph with hubs into ONE group — measured on reddit-syn (56 % of the edges inside 41 planted communities of 5.7 K
+// nodes): collapse in three sweeps; with a size bound instead of the term, 397 mixed groups holding 32 % of the edges;
+// with the term, the planted communities themselves (38-42 groups, 55-56 % of the edges) in 5 sweeps, 0.8 s.
+// A size bound stays (8192 nodes: 2 MiB of 256-byte row slices, half an XCD's L2): a group is a cache working set, so
+// merged communities beyond that size are of no use here.  One sweep costs one pass over the edges with a counter array
+// (no hashing, no sorting).  Deterministic (fixed order, fixed tie rule), so every rank of a row-partitioned run finds
+// the same groups.  The groups only ORDER the task list — any grouping, even a useless one, gives the same bits
+// (tested); whether it is used at all is decided by timing it against the other schedules (HipGCN::tune_schedule).
+// With the label hint withheld, reddit-syn on one MI355X: plain degree order 197 epochs/s, size-bounded label propagation
+// 279, this 297; the labels themselves 297.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -29,11 +33,18 @@ struct StructureGroups {
     bool useful = false;         // false: collapsed into one giant group, never left the singletons, or the groups hold few edges
 };
 
-inline StructureGroups structure_groups(const int *indptr, const int *indices, int n, int max_sweeps = 8, int max_group = 4096) {
+inline StructureGroups structure_groups(const int *indptr, const int *indices, int n, int max_sweeps = 10, int max_group = 8192) {
     StructureGroups out;
     if (n <= 0) return out;
-    std::vector<int> lab(n), order(n), cnt(n, 0), stamp(n, -1), size(n, 1);
-    for (int i = 0; i < n; i++) lab[i] = order[i] = i;
+    std::vector<int> lab(n), order(n), cnt(n, 0), stamp(n, -1), size(n, 1), seen;
+    std::vector<double> tot(n);                       // degree sum of each group (self loops of A + I left out)
+    double m2 = 0.0;                                  // 2m: sum of all degrees
+    for (int i = 0; i < n; i++) {
+        lab[i] = order[i] = i;
+        tot[i] = (double)(indptr[i + 1] - indptr[i] - 1);
+        m2 += tot[i];
+    }
+    if (m2 <= 0.0) m2 = 1.0;
     // fixed shuffle (xorshift64*): hubs must not all be visited first, nor in file order
     uint64_t s = 0x9E3779B97F4A7C15ull;
     for (int i = n - 1; i > 0; i--) {
@@ -45,18 +56,26 @@ inline StructureGroups structure_groups(const int *indptr, const int *indices, i
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
         long changed = 0, inside = 0, edges = 0;
         for (int k = 0; k < n; k++, visit++) {
-            const int i = order[k];
-            int best = lab[i], best_n = 0;
+            const int i = order[k], cur = lab[i];
+            const double ki = (double)(indptr[i + 1] - indptr[i] - 1);
+            seen.clear();
             for (int e = indptr[i]; e < indptr[i + 1]; e++) {
                 const int j = indices[e];
                 if (j == i) continue;                         // the self loop of A + I carries no information
                 const int l = lab[j];
-                if (stamp[l] != visit) { stamp[l] = visit; cnt[l] = 0; }
-                const int c = ++cnt[l];
-                if (l != lab[i] && size[l] >= max_group) continue;      // full: not a candidate (staying is always allowed)
-                if (c > best_n || (c == best_n && l == lab[i])) { best_n = c; best = l; }
+                if (stamp[l] != visit) { stamp[l] = visit; cnt[l] = 0; seen.push_back(l); }
+                cnt[l]++;
             }
-            if (best != lab[i]) { size[lab[i]]--; size[best]++; lab[i] = best; changed++; }
+            tot[cur] -= ki; size[cur]--;                      // i leaves; staying is one of the candidates below
+            int best = cur, best_n = stamp[cur] == visit ? cnt[cur] : 0;
+            double best_gain = (double)best_n - tot[cur] * ki / m2;
+            for (int l : seen) {                              // in order of first appearance: deterministic
+                if (l == cur || size[l] >= max_group) continue;
+                const double gain = (double)cnt[l] - tot[l] * ki / m2;
+                if (gain > best_gain) { best_gain = gain; best = l; best_n = cnt[l]; }
+            }
+            tot[best] += ki; size[best]++;
+            if (best != cur) { lab[i] = best; changed++; }
             inside += best_n;
             edges += indptr[i + 1] - indptr[i] - 1;
         }
@@ -64,7 +83,7 @@ inline StructureGroups structure_groups(const int *indptr, const int *indices, i
         out.inside_share = edges ? (double)inside / (double)edges : 0.0;
         if (getenv("HIPGCN_GROUPS_DEBUG")) fprintf(stderr, "sweep %d: changed %ld inside %.4f\n", sweep, changed, out.inside_share);
         // No structure to find: stop paying for sweeps.  After the first sweep a planted partition at Reddit's mixing has
-        // 12-14 % of every node's neighbours in its group, an R-MAT graph 3 % (final values: 32-49 % against 5 %).
+        // 18-25 % of every node's neighbours in its group, an R-MAT graph 3 % (final values: 49-56 % against 5 %).
         if (sweep == 0 && out.inside_share < 0.06) break;
         if (changed * 200 < n) break;                          // < 0.5 % of the nodes moved
         if (visit > (1 << 30)) break;                          // stamp values stay below 2^31

@@ -282,7 +282,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
 // Which rows the aggregation has in flight together decides its speed (what the XCD L2s hold; whether hub rows
 // overlap with the tail of short rows) and nothing else: every schedule gives the same bits.  Candidates:
 // descending degree; label-major when the labels are communities of this graph (Reddit: subreddits), else group-major over
-// groups found in the graph by label propagation (cluster.h) when that finds any; degree rank
+// groups found in the graph by modularity local moving (cluster.h) when that finds any; degree rank
 // dealt into 256 equal-mix groups (graphs with a long tail of short rows, e.g. R-MAT).  Each is timed on the
 // hidden-width aggregation of this rank's rows and the fastest is kept for all of this rank's adjacency objects.
 void HipGCN::apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g) {

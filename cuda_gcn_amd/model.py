@@ -118,7 +118,7 @@ class HipGCNModel:
 
     def schedule(self):
         """row schedule of the aggregation picked at construction: 'degree', 'label-major', 'dealt-<G>' or
-        'structure-major (<G> groups)' — groups found in the graph by label propagation"""
+        'structure-major (<G> groups)' — groups found in the graph by modularity local moving"""
         m, g = C.c_int(), C.c_int()
         _ck(self.lib, self.lib.gcnhost_model_schedule(self.h, C.byref(m), C.byref(g)), "schedule")
         return {0: "degree", 1: "label-major", 2: f"dealt-{g.value}", 3: f"structure-major ({g.value} groups)"}[m.value]

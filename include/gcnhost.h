@@ -54,7 +54,7 @@ enum {
                                          weight gradient on a second stream (bit-identical; measured slower on one MI355X; env
                                          HIPGCN_BWD_PIPELINE=1; HIPGCN_BWD_CHUNKS sets the number of blocks, default 4) */
     GCNHOST_NO_LABEL_HINT = 524288,   /* the labels are never used as row groups of the aggregation's schedule; groups are looked for in the
-                                         graph itself (label propagation) and used if they time faster (env HIPGCN_NO_LABEL_HINT=1) */
+                                         graph itself (modularity local moving) and used if they time faster (env HIPGCN_NO_LABEL_HINT=1) */
     GCNHOST_MASKED_BWD = 131072,      /* the output layer's backward masks the rows of dZ outside the training split at every launch
                                          (default: aggregates through gcnhip_graph_create_restricted's operator; env HIPGCN_MASKED_BWD=1) */
     GCNHOST_NULL_COMM = 1024      /* timing aid: rank r of world > 1 with no-op collectives (per-rank compute time; numbers meaningless) */
@@ -98,7 +98,7 @@ int gcnhost_model_sync(gcnhost_model *m);
 int gcnhost_model_exchange(gcnhost_model *m, int *halo, int64_t *recv_rows, int64_t *send_rows, int *table_rows, double *halo_share);
 int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges);
 /* the aggregation's row schedule this rank timed as fastest: 0 descending degree (also when not tuned), 1 label-major,
- * 2 degree rank dealt into n_groups groups, 3 group-major over n_groups groups found in the graph (label propagation) */
+ * 2 degree rank dealt into n_groups groups, 3 group-major over n_groups groups found in the graph (modularity local moving) */
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
 /* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
  * out == NULL: only report the shape. */
@@ -155,8 +155,8 @@ int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t ski
  * are malloc'ed here; release them with gcnhost_free_array.  Deterministic in (scale, edge_factor, seed). */
 int gcnhost_rmat_graph(int scale, int edge_factor, uint64_t seed, int **indptr, int **indices, int64_t *nnz);
 void gcnhost_free_array(void *p);
-/* Row groups for the aggregation's schedule found in the graph itself (asynchronous label propagation in a fixed node
- * order, host/cluster.h): group[i] in 0 .. *n_groups-1, largest group first.  *useful == 0: the graph has no such
+/* Row groups for the aggregation's schedule found in the graph itself (Louvain local moving from singletons with a size
+ * bound, asynchronous in a fixed node order, host/cluster.h): group[i] in 0 .. *n_groups-1, largest group first.  *useful == 0: the graph has no such
  * structure (everything collapsed into one group, or nothing merged) and HipGCN would not try the grouping.  What
  * HipGCN runs when the labels are not assortative on the graph (or GCNHOST_NO_LABEL_HINT is set); deterministic. */
 int gcnhost_structure_groups(const int *g_indptr, const int *g_indices, int n_rows, int *group, int *n_groups, int *sweeps,

@@ -238,24 +238,24 @@ def _structure_groups(gp, gi):
 
 
 def test_structure_groups_find_planted_communities():
-    """row groups for the aggregation's schedule from the graph alone (host/cluster.h, size-constrained label
-    propagation): on a planted partition the groups hold far more of the edges than chance, none exceeds the size
-    bound, nothing collapses into one group, and the result is deterministic"""
+    """row groups for the aggregation's schedule from the graph alone (host/cluster.h, modularity local moving with a
+    size bound): on a planted partition the groups hold as many of the edges as the planted labels do, none exceeds the
+    size bound, nothing collapses into one group, and the result is deterministic"""
     ds = datagen.make_dataset("reddit-mini")
     gp, gi, lab = ds["g_indptr"], ds["g_indices"], ds["label"]
     n = gp.size - 1
     grp, ng, sweeps, largest, useful = _structure_groups(gp, gi)
-    assert useful and 4 <= ng <= n and 1 <= sweeps <= 8
+    assert useful and 4 <= ng <= n and 1 <= sweeps <= 10
     assert grp.min() == 0 and grp.max() == ng - 1
     sizes = np.bincount(grp, minlength=ng)
-    assert sizes[:-1].max() <= 4096 and np.all(np.diff(sizes[:-1]) <= 0)          # bounded, largest first (the last may be the rest)
+    assert sizes[:-1].max() <= 8192 and np.all(np.diff(sizes[:-1]) <= 0)          # bounded, largest first (the last may be the rest)
     assert abs(largest - sizes[0] / n) < 1e-12
     src = np.repeat(np.arange(n), np.diff(gp))
     nl = src != gi
     inside = float((grp[src[nl]] == grp[gi[nl]]).mean())
     chance = float(((sizes / n) ** 2).sum())
     label_inside = float((lab[src[nl]] == lab[gi[nl]]).mean())
-    assert inside >= 4 * chance and inside >= 0.5 * label_inside, (inside, chance, label_inside)
+    assert inside >= 4 * chance and inside >= 0.95 * label_inside, (inside, chance, label_inside)
     again = _structure_groups(gp, gi)
     assert np.array_equal(again[0], grp) and again[1:] == (ng, sweeps, largest, useful)
 

@@ -370,7 +370,7 @@ def test_backward_pipeline_is_bit_identical(extra, monkeypatch):
 
 
 def test_structure_groups_schedule_is_bit_identical():
-    """labels withheld (NO_LABEL_HINT): the row groups come from the graph (label propagation) — another order of the
+    """labels withheld (NO_LABEL_HINT): the row groups come from the graph (modularity local moving) — another order of the
     task list, the same bits"""
     from cuda_gcn_amd.model import HipGCNModel, NO_LABEL_HINT
     ds = datagen.make_dataset("reddit-mini")
