@@ -429,14 +429,19 @@ __global__ __launch_bounds__(256) void dense_bwd_t128_kernel(Tile128Args a) {
         if (r0 + T_BK < r_end) fetch(r0 + T_BK);
         const float *Ap = &As[kq * 128 + wm * 64 + li];
         const float *Bp = &Bs[kq * 128 + wn * 64 + li];
+        // operands of step kk+2 are read from LDS before the MFMAs of step kk are issued (as in the forward tile)
+        float a0 = Ap[0], a1 = Ap[32], b0 = Bp[0], b1 = Bp[32];
 #pragma unroll
         for (int kk = 0; kk < T_BK; kk += 2) {
-            const float a0 = Ap[kk * 128], a1 = Ap[kk * 128 + 32];
-            const float b0 = Bp[kk * 128], b1 = Bp[kk * 128 + 32];
+            float an0 = 0.f, an1 = 0.f, bn0 = 0.f, bn1 = 0.f;
+            if (kk + 2 < T_BK) { an0 = Ap[(kk + 2) * 128]; an1 = Ap[(kk + 2) * 128 + 32]; bn0 = Bp[(kk + 2) * 128]; bn1 = Bp[(kk + 2) * 128 + 32]; }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = MFMA32(a0, b0, acc[0][0]);
             acc[0][1] = MFMA32(a0, b1, acc[0][1]);
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = an0; a1 = an1; b0 = bn0; b1 = bn1;
         }
     }
     // partial [K x p] of this split
