@@ -75,6 +75,24 @@ def test_bench_one_gpu_line():
 
 
 @pytest.mark.gpu
+def test_bench_extras_on_a_small_graph():
+    """the extra legs of the one-GPU line (label hint withheld, no row groups, reference operation order, the R-MAT leg of
+    the roofline — here at a small scale, so the code path and not the HBM regime is what is exercised)"""
+    p = run_bench(["--dataset", "reddit-mini", "--steps", 4, "--warmup", 1, "--bursts", 0, "--no-cpu-baseline", "--hbm-scale", 15])
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_lines(p.stdout)[0]
+    assert out["config"]["eval_lane"] == "on"                  # one GPU: validation forward on the second stream
+    assert out["value_reference_op_order_all_rows"] > 0
+    if out["config"]["aggregation_schedule"] == "label-major":
+        assert out["value_no_label_hint"] > 0 and "aggregation_schedule_no_label_hint" in out["config"]
+    if out["config"]["aggregation_schedule"] != "degree":
+        assert out["value_no_row_groups"] > 0
+    leg = out["roofline"]["hbm_regime"]
+    assert "error" not in leg, leg
+    assert leg["bound"] == "hbm" and leg["achieved"] > 0 and leg["launches"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_self_launched():
     p = run_bench(["--gpus", 2, "--dataset", "reddit-mini", "--steps", 3, "--warmup", 1, "--bursts", 0, "--no-cpu-baseline"],
                   env={"GCN_BENCH_TRANSPORT": "host", "GCN_BENCH_DEVICE": "0", "GCN_BENCH_TIMEOUT": "600"})
