@@ -99,5 +99,22 @@ def test_c_abi_rejects_bad_arguments():
         dev.matmul_fwd(np.ones((3, 800), np.float32), np.ones((800, 40), np.float32))   # inner dim above the LDS panel limit
     out = dev.graphsum(g, x)
     assert np.isfinite(out).all()
-    g.free()
+    # round-2 entry points: NULL operands, split ranges outside the plan, a finish without parts
+    import ctypes as C
+    lib = dev.lib
+    h = C.c_void_p()
+    assert lib.gcnhip_graph_create_restricted(dev.ctx, C.byref(h), None, None) == -1
+    assert lib.gcnhip_graph_create_restricted(dev.ctx, C.byref(h), g.h, None) == -1
+    n, F, p = 300, 128, 128
+    xs = np.ones((n, F), np.float32)
+    f = dev.feat((np.arange(n + 1) * F).astype(np.int32), np.tile(np.arange(F, dtype=np.int32), n), xs.reshape(-1), F)
+    rps, ns = dev.spmm_bwd_plan(f, p)
+    assert ns >= 1 and rps >= 32
+    d = dev.buf(np.ones((n, p), np.float32)); dw = dev.buf(np.zeros((F, p), np.float32))
+    part = lambda s0, s1: lib.gcnhip_spmm_bwd_part(dev.ctx, f.h, f.values_ptr, d.ptr, p, p, 0.0, 0, None, 0, None, s0, s1, 0)
+    assert part(0, ns + 1) == -1 and part(-1, 1) == -1 and part(2, 1) == -1
+    assert lib.gcnhip_spmm_bwd_part(dev.ctx, f.h, f.values_ptr, d.ptr, p, 41, 0.0, 0, None, 0, None, 0, 1, 0) == -1   # no split-K plan at 41 columns
+    assert part(0, ns) == 0 and lib.gcnhip_spmm_bwd_finish(dev.ctx, f.h, dw.ptr, p, p) == 0
+    assert np.allclose(dw.download(), n)                      # X^T . 1 with X = 1: every entry is the row count
+    f.free(); g.free()
     dev.close()
