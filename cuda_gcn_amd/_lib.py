@@ -139,6 +139,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graph_launch": (I, [P, P]),
     "gcnhip_graph_exec_destroy": (I, [P]),
     "gcnhip_event_create": (I, [C.POINTER(P)]),
+    "gcnhip_event_create_sync": (I, [C.POINTER(P)]),
     "gcnhip_event_destroy": (I, [P]),
     "gcnhip_event_record": (I, [P, P]),
     "gcnhip_stream_wait_event": (I, [P, P]),

@@ -122,6 +122,7 @@ int gcnhip_graph_exec_destroy(void *graph_exec) {
 }
 
 int gcnhip_event_create(void **ev) { GCNHIP_TRY(hipEventCreate((hipEvent_t *)ev)); return 0; }
+int gcnhip_event_create_sync(void **ev) { GCNHIP_TRY(hipEventCreateWithFlags((hipEvent_t *)ev, hipEventDisableTiming)); return 0; }
 int gcnhip_event_destroy(void *ev) { GCNHIP_TRY(hipEventDestroy((hipEvent_t)ev)); return 0; }
 int gcnhip_event_record(gcnhip_ctx *c, void *ev) { GCNHIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream)); return 0; }
 int gcnhip_stream_wait_event(gcnhip_ctx *c, void *ev) {

@@ -54,7 +54,7 @@ namespace {
 struct Turnstile {
     void *ev = nullptr;
     bool armed = false;
-    Turnstile() { GCNHIP_CHECK(gcnhip_event_create(&ev)); }
+    Turnstile() { GCNHIP_CHECK(gcnhip_event_create_sync(&ev)); }
     ~Turnstile() { gcnhip_event_destroy(ev); }
 };
 

@@ -408,7 +408,7 @@ void HipGCN::build_bwd_pipeline(HipSparseMatmul *sm, HipGraphSum *gs) {
     bwd_pipe.reset(new BackwardPipeline());
     BackwardPipeline &P = *bwd_pipe;
     GCNHIP_CHECK(gcnhip_ctx_create(&P.side, device_, nullptr));
-    GCNHIP_CHECK(gcnhip_event_create(&P.ev_done));
+    GCNHIP_CHECK(gcnhip_event_create_sync(&P.ev_done));
     for (int k = 0; k <= chunks; k++) P.cuts.push_back((int)((int64_t)n_splits * k / chunks));
     for (int k = 0; k < chunks; k++) {
         const int r_lo = std::min(n_local, P.cuts[k] * rps), r_hi = std::min(n_local, P.cuts[k + 1] * rps);
@@ -418,7 +418,7 @@ void HipGCN::build_bwd_pipeline(HipSparseMatmul *sm, HipGraphSum *gs) {
         GCNHIP_CHECK(gcnhip_graph_add_rowset(env.ctx, graph, bits.data(), &rs));
         P.blocks.push_back(rs);
         void *ev = nullptr;
-        GCNHIP_CHECK(gcnhip_event_create(&ev));
+        GCNHIP_CHECK(gcnhip_event_create_sync(&ev));
         P.ev_block.push_back(ev);
     }
     sm->pipe = &P;
@@ -548,9 +548,9 @@ void HipGCN::build_eval_lane() {
         ce->rows_list = &L.rows; ce->rows_n = &L.rows_n;
         L.modules.push_back(ce);
     }
-    GCNHIP_CHECK(gcnhip_event_create(&L.ev_weights));
-    GCNHIP_CHECK(gcnhip_event_create(&L.ev_done));
-    GCNHIP_CHECK(gcnhip_event_create(&L.ev_fork));
+    GCNHIP_CHECK(gcnhip_event_create_sync(&L.ev_weights));
+    GCNHIP_CHECK(gcnhip_event_create_sync(&L.ev_done));
+    GCNHIP_CHECK(gcnhip_event_create_sync(&L.ev_fork));
     GCNHIP_CHECK(gcnhip_ctx_sync(L.env.ctx));
 }
 

@@ -381,6 +381,9 @@ int gcnhip_graph_exec_destroy(void *graph_exec);
 /* ---- timing (replaces the host chrono timers that the CUDA path leaves
  *      unsynchronised) ---------------------------------------------- */
 int gcnhip_event_create(void **ev);
+/* an event used only to order streams (gcnhip_event_record + gcnhip_stream_wait_event): no timestamp is taken, so
+ * gcnhip_event_elapsed_ms must not be asked of it */
+int gcnhip_event_create_sync(void **ev);
 int gcnhip_event_destroy(void *ev);
 int gcnhip_event_record(gcnhip_ctx *ctx, void *ev);
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
