@@ -16,9 +16,11 @@ RANK / WORLD_SIZE are then set), or this file does: a parent that has not
 touched the GPU (no torch import, no native library) starts the N ranks with
 torch.distributed.run as CHILD processes, relays rank 0's JSON line and exits
 with their return code (a hung child group is killed after GCN_BENCH_TIMEOUT
-seconds).  It runs the plain one-stream schedule first, then tries the
-schedule with the validation forward overlapped on a second stream as fresh
-children, and prints the faster valid line.
+seconds).  It first runs the RCCL self-test (all-gather, all-reduce, halo
+send/receive, split communicator) as a throw-away group of ranks, then the plain
+one-stream schedule, then tries the two overlapped schedules (exchanges on their
+own stream beside the locally owned columns' aggregation; validation forward on
+a second stream) as fresh children, and prints the fastest valid line.
 
 Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
   * `value` / `ms_per_step`: exactly K epochs, barrier + synchronize on both sides, max over ranks,
@@ -48,8 +50,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
 L2_AGG_GBPS = 34500.0         # "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
 MALL_GATHER_GBPS = 8600.0     # "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache: 33.5 GB/s per CU = 8.6 TB/s
-PMC_FILES = ["r02_graphsum_pmc.json"]           # newest first (profiles/)
-PMC_RMAT_FILES = ["r02_graphsum_pmc_rmat.json"]
+PMC_FILES = ["r03_graphsum_pmc.json", "r02_graphsum_pmc.json"]           # newest first (profiles/)
+PMC_RMAT_FILES = ["r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
+GS_KERNEL = "graphsum_vec_kernel<16, 4, true>"       # the hidden-width launch on a cache-resident table (graphsum.hip, launch_vec)
+GS_KERNEL_HBM = "graphsum_vec_kernel<16, 2, true>"   # ... past the Infinity Cache (two row loads in flight)
 
 
 def log(*a):
@@ -78,6 +82,9 @@ def parse_args(argv=None):
                     help="opt-in, NOT the headline: GraphSum gathers bfloat16 copies of its inputs (f32 sums); reported as dtype f32+bf16-tables")
     ap.add_argument("--eval-lane", choices=["auto", "on", "off"], default="auto",
                     help="validation forward on a second stream, overlapped with the next training epoch (auto: on with one GPU, off with several)")
+    ap.add_argument("--overlap", choices=["on", "off"], default="off",
+                    help="several GPUs: exchanges on their own stream beside the aggregation of the locally owned columns (HIPGCN_OVERLAP_EXCHANGE)")
+    ap.add_argument("--selftest", action="store_true", help="several GPUs: run gcnhost_rccl_selftest_world on every rank and exit")
     return ap.parse_args(argv)
 
 
@@ -90,12 +97,12 @@ def _free_port():
     return p
 
 
-def _run_ranks(n_gpus, extra, timeout):
+def _run_ranks(n_gpus, extra, timeout, env=None):
     """one group of N rank processes (children of this GPU-free parent); returns (rc, JSON line or None)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
-    log("starting", n_gpus, "ranks:", " ".join(cmd[1:]))
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    log("starting", n_gpus, "ranks:", " ".join(cmd[1:]), "" if not env else f"env {env}")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True, env=dict(os.environ, **(env or {})))
     try:
         out, _ = p.communicate(timeout=timeout)
         rc = p.returncode
@@ -109,7 +116,7 @@ def _run_ranks(n_gpus, extra, timeout):
         rc = 124
     line = None
     for ln in (out or "").splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
+        if ln.startswith("{") and ('"metric"' in ln or '"selftest"' in ln):
             line = ln
         else:
             print(ln, file=sys.stderr)
@@ -122,33 +129,54 @@ def launch_ranks(n_gpus, argv):
     """Parent of an N-rank run.  Runs before torch or any native library is imported: this process never
     initialises the GPU, it only starts children, so nothing here is an exec from a GPU process.
 
-    The row-partitioned epoch exists in two schedules: everything on one stream (`--eval-lane off`: the plain,
-    conservative one) and the validation forward on a second stream / communicator overlapped with the next
-    training epoch (`on`).  Unless the caller chose one, the plain schedule runs first — its line is the safe
-    result — then the overlapped one is tried as fresh children with a short deadline, and the faster valid
-    line is printed (its `config.eval_lane` says which; the other value is kept as `other_schedule`)."""
+    Order (each step a fresh group of children, so that a hang or failure of a later, less proven step cannot take an
+    earlier result with it):
+      0. the RCCL self-test (gcnhost_rccl_selftest_world: all-gather, all-reduce, the halo exchange by grouped
+         ncclSend/ncclRecv, the split communicator) with a short deadline.  Passed: the model runs may pick the exchange
+         per graph (HIPGCN_EXCHANGE=auto).  Failed or hung: they are pinned to the in-place all-gather.
+      1. the plain schedule: everything on one stream.  Its line is the safe result.  If it fails with a per-graph
+         exchange it is retried once pinned to the all-gather.
+      2. unless the caller chose a schedule: `--overlap on` (exchanges on their own stream beside the aggregation of the
+         locally owned columns), then `--eval-lane on` (validation forward on a second stream and communicator).
+    The fastest valid line is printed; `config.schedule` says which, the others are kept in `other_schedules`."""
     timeout = float(os.environ.get("GCN_BENCH_TIMEOUT", "600"))
-    if "--eval-lane" in argv:
-        rc, line = _run_ranks(n_gpus, list(argv), timeout)
-        if rc == 0:
-            print(line, flush=True)
-        return rc
-    rc, line = _run_ranks(n_gpus, list(argv) + ["--eval-lane", "off"], timeout)
+    t_try = float(os.environ.get("GCN_BENCH_LANE_TIMEOUT", "300"))
+    argv = list(argv)
+    env = {}
+    if "HIPGCN_EXCHANGE" not in os.environ and os.environ.get("GCN_BENCH_TRANSPORT") != "host":
+        rc0, line0 = _run_ranks(n_gpus, ["--gpus", str(n_gpus), "--selftest"], float(os.environ.get("GCN_BENCH_SELFTEST_TIMEOUT", "180")))
+        selftest_ok = rc0 == 0
+        env["HIPGCN_EXCHANGE"] = "auto" if selftest_ok else "allgather"
+        log("RCCL self-test", "passed: exchange decided per graph" if selftest_ok else f"FAILED (rc {rc0}): every exchange pinned to the all-gather")
+    chosen = "--eval-lane" in argv or "--overlap" in argv
+    base = argv if chosen else argv + ["--eval-lane", "off", "--overlap", "off"]
+    rc, line = _run_ranks(n_gpus, base, timeout, env)
+    if rc != 0 and env.get("HIPGCN_EXCHANGE") == "auto":
+        log(f"run failed (rc {rc}) with a per-graph exchange: retrying pinned to the all-gather")
+        env["HIPGCN_EXCHANGE"] = "allgather"
+        rc, line = _run_ranks(n_gpus, base, timeout, env)
     if rc != 0:
         log(f"plain schedule failed (rc {rc})")
         return rc
-    first = json.loads(line)
-    t_try = float(os.environ.get("GCN_BENCH_LANE_TIMEOUT", "240"))
-    rc2, line2 = _run_ranks(n_gpus, list(argv) + ["--eval-lane", "on"], t_try)
-    best = first
-    if rc2 == 0:
-        second = json.loads(line2)
-        lo, hi = sorted((first, second), key=lambda d: d["value"])
-        best = hi
-        best["other_schedule"] = {"eval_lane": lo["config"].get("eval_lane"), "value": lo["value"], "ms_per_step": lo["ms_per_step"]}
-    else:
-        log(f"overlapped schedule failed or timed out (rc {rc2}); keeping the plain schedule's line")
-        best["other_schedule"] = {"eval_lane": "on", "value": None, "failed_rc": rc2}
+    if chosen:
+        print(line, flush=True)
+        return 0
+    lines = [json.loads(line)]
+    others = []
+    for extra in (["--eval-lane", "off", "--overlap", "on"], ["--eval-lane", "on", "--overlap", "off"]):
+        rc2, line2 = _run_ranks(n_gpus, argv + extra + ["--no-cpu-baseline"], t_try, env)
+        if rc2 == 0:
+            lines.append(json.loads(line2))
+        else:
+            log(f"schedule {extra} failed or timed out (rc {rc2}); keeping what has been measured")
+            others.append({"schedule": " ".join(extra), "value": None, "failed_rc": rc2})
+    best = max(lines, key=lambda d: d["value"])
+    for d in lines:
+        if d is not best:
+            others.append({"schedule": d["config"].get("schedule"), "value": d["value"], "ms_per_step": d["ms_per_step"]})
+    if best.get("cpu_baseline") is None:
+        best["cpu_baseline"] = lines[0].get("cpu_baseline")      # timed once, in the first group (same box, same workload)
+    best["other_schedules"] = others
     print(json.dumps(best), flush=True)
     return 0
 
@@ -193,15 +221,29 @@ def cpu_baseline(ds_full, hidden, budget_s=30.0):
 
 
 # ----------------------------------------------------------------------------------------------- HBM-regime leg
-def _pmc(files, kernel):
-    """PMC summary of the kernel whose name starts with `kernel` (template arguments after the first vary with the batch depth)"""
+def _pmc(files, kernel, avg_launch_ms=None, tol=0.10):
+    """PMC summary of exactly `kernel` (full name with template arguments) from the newest committed profile that has it,
+    accepted only when it describes the launch that was just timed: the profile records the kernel's median duration under
+    the profiler, and a file whose duration differs from the HIP-event average of this run by more than `tol` is refused
+    (a kernel change would otherwise leave the roofline computed from stale fabric bytes).  Returns (entry, source, why_not)."""
+    why = "no committed PMC profile names this kernel"
     for f in files:
         p = os.path.join(ROOT, "profiles", f)
-        if os.path.exists(p):
-            for name, k in json.load(open(p)).items():
-                if name.startswith(kernel):
-                    return k, "profiles/" + f
-    return None, None
+        if not os.path.exists(p):
+            continue
+        doc = json.load(open(p))
+        k = doc.get(kernel)
+        if k is None:
+            continue
+        ref_us = k.get("median_duration_us_under_pmc")
+        if avg_launch_ms is not None and ref_us:
+            dev = abs(1e3 * avg_launch_ms - ref_us) / ref_us
+            if dev > tol:
+                why = f"profiles/{f}: {kernel} took {ref_us:.0f} us under the profiler, {1e3 * avg_launch_ms:.0f} us here ({100 * dev:.0f} % apart): refused"
+                continue
+        k = dict(k, commit=doc.get("_meta", {}).get("commit"), duration_checked=bool(avg_launch_ms is not None and ref_us))
+        return k, "profiles/" + f, None
+    return None, None, why
 
 
 def hbm_regime_leg(scale, dim, device, launches=10):
@@ -244,13 +286,13 @@ def hbm_regime_leg(scale, dim, device, launches=10):
     x.free(); o.free(); g.free(); dev.close()
     bytes_per_launch = b_gs(N, nnz, dim)
     achieved = bytes_per_launch / avg_s / 1e9
-    k, src = _pmc(PMC_RMAT_FILES, "graphsum_vec_kernel<16")
+    k, src, why_not = _pmc(PMC_RMAT_FILES, GS_KERNEL_HBM if N * ld * 4 > 256 * 2**20 else GS_KERNEL, 1e3 * avg_s, tol=0.15)
     traffic = k.get("traffic_bytes_per_launch") if k else None
     return {"workload": f"GraphSum d={dim} on rmat-{scale} (N={N}, {nnz} stored edges, max degree {int(np.diff(gp).max())}); "
                         f"gathered table {N * ld * 4 / 2**20:.0f} MiB >> 256 MiB Infinity Cache; schedule dealt-256",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s, "launches": launches,
-            "traffic": traffic, "traffic_source": src,
+            "traffic": traffic, "traffic_source": src if k else why_not,
             "traffic_frac_of_peak": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBPS,
             "setup_s": {"generate": round(t_gen, 2), "graph_create_and_schedule": round(t_prep, 2)}}
 
@@ -279,7 +321,24 @@ def main():
 
     from cuda_gcn_amd import datagen
     from cuda_gcn_amd.model import (HipGCNModel, EVAL_LANE, NO_EVAL_LANE, BF16_TABLES, NO_ROW_GROUPS, NO_LABEL_HINT, NO_AGG_FIRST_EVAL,
-                                    ALL_ROWS, nccl_unique_id)
+                                    ALL_ROWS, OVERLAP_EXCHANGE, nccl_unique_id)
+
+    if args.selftest:
+        # every RCCL primitive the row-partitioned epoch uses, against real peers, before a model depends on them
+        from cuda_gcn_amd import _lib
+        if world < 2:
+            sys.exit("bench.py --selftest needs more than one rank")
+        box = [nccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        lib = _lib.gcnhost()
+        rc = lib.gcnhost_rccl_selftest_world(device, rank, world, box[0])
+        if rc != 0:
+            sys.exit(f"rank {rank}: gcnhost_rccl_selftest_world failed: {rc}: {lib.gcnhost_last_error().decode()}")
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": "ok", "n_gpus": world}), flush=True)
+        dist.destroy_process_group()
+        return
 
     def barrier():
         if world > 1:
@@ -310,7 +369,8 @@ def main():
     # self-launching parent above tries both.
     lane_on = args.eval_lane == "on" or (args.eval_lane == "auto" and world == 1)
     lane_flag = EVAL_LANE if lane_on else NO_EVAL_LANE
-    base_flags = lane_flag | (BF16_TABLES if args.bf16_tables else 0)
+    overlap_on = args.overlap == "on" and world > 1
+    base_flags = lane_flag | (BF16_TABLES if args.bf16_tables else 0) | (OVERLAP_EXCHANGE if overlap_on else 0)
     n_epochs_total = args.warmup + args.steps * (2 + args.bursts) + 64
 
     def build(flags):
@@ -390,47 +450,60 @@ def main():
         algorithmic = bytes_per_launch / avg_s / 1e9
         gathered = ib * info["local_edges"] * d_eff / avg_s / 1e9
         kernel = ("graphsum_bf16_kernel<16> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
-                  f"graphsum_vec_kernel<16, 4, true>, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
+                  f"{GS_KERNEL}, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
                   f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)")
+        if overlap_on and args.hidden > 64:
+            kernel += "; --overlap on: a launch pair per aggregation (own-column edges, then the rest), timed together incl. any exposed wait for the exchange"
         # fabric traffic and L2 hit rate per launch of the same kernel from the committed rocprofv3 PMC passes
-        # (FETCH_SIZE, WRITE_SIZE and the TCC hit counters need separate runs, so they cannot be collected live here)
-        pmc, pmc_src = (None, None)
-        if args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and not args.no_row_groups:
-            pmc, pmc_src = _pmc(PMC_FILES, "graphsum_vec_kernel<16")
-        traffic = pmc.get("traffic_bytes_per_launch") if (pmc and world == 1) else None
+        # (FETCH_SIZE, WRITE_SIZE and the TCC hit counters need separate runs, so they cannot be collected live here);
+        # a profile is accepted only for exactly this kernel at (within 10 %) the duration timed in this run
+        pmc, pmc_src, pmc_why = (None, None, "no PMC profile is committed for this configuration")
+        if args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and not args.no_row_groups and world == 1:
+            pmc, pmc_src, pmc_why = _pmc(PMC_FILES, GS_KERNEL, 1e3 * avg_s)
+        traffic = pmc.get("traffic_bytes_per_launch") if pmc else None
         cache_resident = table_mb * 1e6 <= 256 * 2**20
         if cache_resident and pmc and "traffic_bytes_per_launch" in pmc:
             # The gathered table sits in the Infinity Cache: HBM is not what bounds the kernel (B_gs / t exceeds the HBM
             # peak).  Two resources do: every gathered byte crosses an XCD's L2 (34.5 TB/s aggregate, MI355X_MICROARCH.md
             # "L2"), and the bytes that miss L2 (PMC: 2*FETCH_SIZE + WRITE_SIZE per launch) come from the Infinity Cache,
-            # for which the highest row-gather rate the guide reports is 8.6 TB/s ("Indexed rows", 38 MB table).  The
+            # for which the highest row-gather rate the guide RECORDS is 8.6 TB/s ("Indexed rows", 38 MB table; the guide
+            # labels its per-CU rates lower bounds, so this is the best gather rate on record, not a hardware limit).  The
             # launch cannot be shorter than the longer of the two transfers; peak = gathered bytes / that floor.
-            # (Round 1-2's blend of the guide's PER-CU row-gather rates, 72 and 33.5 GB/s, gave 12.7 TB/s; the guide calls
-            # those lower bounds, and with four row loads in flight per lane group the kernel now gathers faster than that.)
             gathered_bytes = ib * info["local_edges"] * d_eff
-            fabric = pmc["traffic_bytes_per_launch"] * (info["local_edges"] / ds["g_indices"].size)   # this rank's share
+            fabric = pmc["traffic_bytes_per_launch"]
             t_l2, t_fabric = gathered_bytes / (L2_AGG_GBPS * 1e9), fabric / (MALL_GATHER_GBPS * 1e9)
             t_floor = max(t_l2, t_fabric)
             peak = gathered_bytes / t_floor / 1e9
             roof = {"bound": "cache-gather", "kernel": kernel, "achieved": gathered, "peak": peak, "unit": "GB/s", "frac": gathered / peak,
                     "traffic": traffic, "l2_hit_rate": pmc.get("l2_hit_rate"),
-                    "floor_ms": {"l2": 1e3 * t_l2, "infinity_cache": 1e3 * t_fabric},
+                    "floor_ms_l2": 1e3 * t_l2, "floor_ms_infinity_cache": 1e3 * t_fabric,
                     "what": "achieved = gathered neighbour-row bytes (4*nnz*d) / HIP-event launch time; peak = the same bytes / max(bytes / 34.5 TB/s "
-                            "L2 aggregate, PMC fabric bytes / 8.6 TB/s Infinity-Cache row-gather rate) — MI355X_MICROARCH.md 'L2', 'Indexed rows'"
-                            + ("" if world == 1 else "; fabric bytes of the 1-GPU launch scaled by this rank's share of the edges")}
+                            "L2 aggregate, PMC fabric bytes / 8.6 TB/s) - 8.6 TB/s is the best Infinity-Cache row-gather rate MI355X_MICROARCH.md records "
+                            "('Indexed rows', per-CU rates labelled lower bounds): a fraction of the best rate on record, not of a hardware limit"}
         else:
             roof = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": algorithmic / HBM_PEAK_GBPS, "traffic": traffic,
                     "what": "B_gs(d) / HIP-event launch time against the HBM peak" +
-                            ("; the table is Infinity-Cache resident and no PMC hit rate is committed for this configuration, so this may exceed 1"
-                             if cache_resident else "")}
-        roof.update({"traffic_source": pmc_src, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s, "launches": n_wide,
+                            ("; the table is Infinity-Cache resident, so this may exceed 1 (cache-served); no PMC profile accepted for the "
+                             "two-resource cache bound: " + str(pmc_why) if cache_resident else "")}
+        roof.update({"traffic_source": pmc_src if pmc else pmc_why, "traffic_commit": pmc.get("commit") if pmc else None,
+                     "traffic_profile_duration_us": pmc.get("median_duration_us_under_pmc") if pmc else None,
+                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s, "launches": n_wide,
                      "table_MB": round(table_mb, 1),
-                     "hbm_algorithmic": {"achieved": algorithmic, "peak": HBM_PEAK_GBPS, "frac": algorithmic / HBM_PEAK_GBPS,
-                                         "what": "SURVEY §8(d) contract figure B_gs(d)/t; > 1 means cache-served"},
-                     "hbm_traffic": None if traffic is None else {"achieved": traffic / avg_s / 1e9, "peak": HBM_PEAK_GBPS,
-                                                                  "frac": traffic / avg_s / 1e9 / HBM_PEAK_GBPS,
-                                                                  "what": "PMC fabric bytes (2*FETCH_SIZE + WRITE_SIZE) per launch / launch time"}})
+                     "breakdown_schedule": "one-stream (per-op timers on: every launch timed alone; the headline runs the validation forward "
+                                           "on a second stream, so the breakdown does not add up to ms_per_step)" if (world == 1 and lane_on) else "as timed",
+                     # SURVEY 8(d) contract figure B_gs(d)/t against the HBM peak; > 1 means cache-served
+                     "hbm_algorithmic_achieved": algorithmic, "hbm_algorithmic_frac": algorithmic / HBM_PEAK_GBPS,
+                     # PMC fabric bytes (2*FETCH_SIZE + WRITE_SIZE) per launch / launch time
+                     "hbm_traffic_achieved": None if traffic is None else traffic / avg_s / 1e9,
+                     "hbm_traffic_frac": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBPS})
+        if world > 1:
+            # the exchange's share: device time of the collectives per epoch (HIP events on the stream they run on) and the
+            # bytes this rank receives per epoch; with --overlap on the exchanges run beside the aggregations, so their
+            # device time is not all exposed
+            comm_ms = breakdown.get("comm", 0.0)
+            roof.update({"comm_ms_per_epoch": comm_ms, "comm_share_of_timers_pass": comm_ms / max(1e3 * dt_tm / n_tm, 1e-9),
+                         "per_rank": "rank 0's launches on its row block"})
         n_lab = int((ds["split"] == 1).sum())
         out = {
             "metric": "epochs_per_sec", "value": args.steps / dt, "unit": "epochs/s",
@@ -443,6 +516,9 @@ def main():
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": schedule,
                        "eval_lane": "on" if lane_on else "off",
+                       "overlap_exchange": "on" if overlap_on else "off",
+                       "schedule": ("plain one-stream" if not (lane_on or overlap_on) else
+                                    " + ".join(x for x in ["exchange overlap" if overlap_on else "", "validation lane" if lane_on else ""] if x)),
                        "exchange": exchange,       # rank 0's view: all-gather of row blocks or halo lists, rows moved per exchange
                        "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
                                        "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",
@@ -486,16 +562,19 @@ def main():
         log(f"reference op order, all rows: {args.steps / d3:.2f} epochs/s")
     if extras:
         try:
-            out["roofline"]["hbm_regime"] = hbm_regime_leg(args.hbm_scale, args.hidden if args.hidden > 64 else 128, device)
-            log("hbm regime leg:", "%.0f GB/s" % out["roofline"]["hbm_regime"]["achieved"])
+            leg = hbm_regime_leg(args.hbm_scale, args.hidden if args.hidden > 64 else 128, device)
+            out["roofline"]["hbm_regime"] = leg
+            # the same as scalars, so that a reader that keeps only the first level of `roofline` keeps the HBM-roofline numbers
+            out["roofline"].update({"hbm_regime_achieved": leg["achieved"], "hbm_regime_frac": leg["frac"],
+                                    "hbm_regime_avg_launch_ms": leg["avg_launch_ms"],
+                                    "hbm_regime_traffic_frac_of_peak": leg["traffic_frac_of_peak"]})
+            log("hbm regime leg:", "%.0f GB/s" % leg["achieved"])
         except Exception as e:          # the leg is an extra: report its failure, keep the headline
             out["roofline"]["hbm_regime"] = {"error": repr(e)}
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ds, args.hidden)
-        else:
-            out["cpu_baseline"] = None
+        # rank 0, any N: the CPU path on this box's host cores (the other ranks wait at the barrier below)
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(ds, args.hidden)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -71,6 +71,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_ctx_sync": (I, [P]),
     "gcnhip_ctx_stream": (P, [P]),
     "gcnhip_error_string": (C.c_char_p, [I]),
+    "gcnhip_last_error": (C.c_char_p, []),
     "gcnhip_version": (C.c_char_p, []),
     "gcnhip_malloc": (I, [P, C.POINTER(P), C.c_size_t]),
     "gcnhip_free": (I, [P, P]),
@@ -92,6 +93,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_rowset_size": (I, [P, C.POINTER(I)]),
     "gcnhip_graphsum_rowset": (I, [P, P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
+    "gcnhip_graphsum_part": (I, [P, P, P, P, I, P, I, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
     "gcnhip_feat_create_aggregated": (I, [P, C.POINTER(P), P, P]),
     "gcnhip_feat_destroy": (I, [P, P]),
@@ -188,6 +190,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_dataset_free": (I, [P]),
     "gcnhost_rccl_selftest": (I, [I]),
     "gcnhost_rccl_selftest_world": (I, [I, I, I, C.c_char_p]),
+    "gcnhost_halo_selftest_host": (I, [I, I, I, ALLGATHER_FN, ALLREDUCE_FN, P]),
     "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
     "gcnhost_local_graph": (I, [P, P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "gcnhost_plan_create": (I, [PP, P, P, I, I, I, I]),

@@ -17,6 +17,9 @@
 
 constexpr int WAVE = 64;
 
+// detail text for a -1 return (gcnhip_last_error); returns -1 so that a check can `return gcnhip_fail("...")`
+int gcnhip_fail(const char *detail);
+
 struct gcnhip_ctx {
     int device;
     hipStream_t stream;
@@ -34,7 +37,9 @@ constexpr int RED_SLOTS = 4096;
 
 // a registered subset of the rows of an adjacency object: its own compacted task list, in the order of the
 // object's current row schedule (rebuilt whenever that changes).  Segment slots are the full schedule's.
+struct gcnhip_graph;
 struct gcnhip_rowset {
+    const gcnhip_graph *owner;    // the adjacency object the subset was registered on (its task lists and segment slots)
     std::vector<uint32_t> bits;   // host copy: bit r = row r is in the subset
     int n_tasks;
     int4 *tasks;

@@ -8,7 +8,15 @@
 #include <vector>
 #include <algorithm>
 
+static thread_local char g_detail[256] = "";
+int gcnhip_fail(const char *detail) {
+    snprintf(g_detail, sizeof g_detail, "%s", detail ? detail : "");
+    return -1;
+}
+
 extern "C" {
+
+const char *gcnhip_last_error(void) { return g_detail; }
 
 int gcnhip_device_count(int *count) {
     GCNHIP_TRY(hipGetDeviceCount(count));
@@ -444,7 +452,9 @@ int gcnhip_graph_add_rowset(gcnhip_ctx *c, gcnhip_graph *g, const uint32_t *h_ro
     gcnhip_rowset *rs = new gcnhip_rowset();
     rs->n_tasks = rs->n_split_rows = 0;
     rs->tasks = rs->split_rows = nullptr;
-    rs->bits.assign(h_row_bits, h_row_bits + (size_t)g->n_rows / 32 + 1);
+    rs->owner = g;
+    rs->bits.assign(h_row_bits, h_row_bits + ((size_t)g->n_rows + 31) / 32);   // exactly the n_rows bits the header documents
+    rs->bits.push_back(0u);                                                       // (+ a zero word: row ids index it as r >> 5 with r < n_rows)
     const int rc = build_rowset(rs, *g->h_tasks, *g->h_srows);
     if (rc != 0) {
         if (rs->tasks) hipFree(rs->tasks);

@@ -6,17 +6,20 @@
 //  * one wave64 per row task; the wave reads 64 (index, coef) pairs with one
 //    coalesced load each and hands them to its lane groups by cross-lane
 //    shuffle, so the only per-edge memory instruction is the feature-row load;
-//  * a feature row is read with 16-byte lane loads: L = dim/4 lanes per row,
-//    64/L rows per wave instruction (d=128: 2 rows / 1 KiB per instruction),
-//    unrolled so 8 row loads per lane group are in flight;
+//  * a feature row is read with 16-byte lane loads: L lanes per row slice,
+//    64/L rows per wave instruction (d=128: 16 lanes per 64-float slice, 4 rows /
+//    1 KiB per instruction); gather_chunk issues GS_U (4; 2 past the Infinity
+//    Cache) row loads per lane group before the first is used, from a
+//    wave-uniform loop so that no load sits inside a per-lane branch;
 //  * partial sums of the lane groups are combined with wave shuffles (no LDS,
 //    no atomics) — results are bitwise reproducible run to run;
 //  * rows longer than SPLIT_EDGES are cut into segments processed by separate
 //    waves (heavy segments dispatched first) and summed in segment order by a
 //    small second kernel, so a hub row does not serialise the tail;
-//  * XCD-aware launch for wide rows: the columns are cut into 128-byte slices and
-//    each slice is bound to the workgroups of one XCD group (blockIdx % 8), so every
-//    XCD's private 4 MiB L2 caches 1/4 of the table instead of all of it;
+//  * XCD-aware launch for rows of whole 256-byte pieces: the columns are cut into
+//    64-float (256-byte) slices and each slice is bound to the workgroups of one XCD
+//    group (blockIdx % 8), so every XCD's private 4 MiB L2 caches 1/slices of the
+//    table (d=128: half of it) and the (index, coef) stream is re-read once per slice;
 //  * the ReLU + dropout of the first layer is an optional store epilogue.
 // The reference launches one block per row with `dim` threads and does a
 // global read-modify-write per edge (cuda_kernel.cu:126-143).
@@ -46,6 +49,8 @@ struct GsArgs {
     const uint8_t *keep_mask;
     const uint32_t *row_bits;   // optional: bit j == 0 -> row j of `in` is all zero and is not read
     const uint32_t *out_bits;   // optional: bit r == 0 -> nobody reads row r of `out`: it is not computed (left untouched)
+    int accumulate;             // 1: out[r,:] = out[r,:] + sum (the second of two operators that share the rows of `out`:
+                                // the remote-column part of a row-partitioned aggregation, gcnhip_graphsum_part)
 };
 
 __device__ inline bool row_wanted(const GsArgs &a, int row) {
@@ -192,8 +197,17 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         if (slot >= 0) {
             *reinterpret_cast<float4 *>(a.partials + (size_t)slot * a.part_ld + col0) = acc;
         } else {
-            if (a.fuse) acc = relu_dropout4(acc, a, row, col0);
             float *o = a.out + (size_t)row * a.ld_out + col0;
+            if (a.accumulate) {                            // what the first operator left in this row, then this one's terms
+                if (col0 + 4 <= a.dim) {
+                    acc = f4_add(*reinterpret_cast<const float4 *>(o), acc);
+                } else {
+                    float x[4] = {acc.x, acc.y, acc.z, acc.w};
+                    for (int i = 0; col0 + i < a.dim; i++) x[i] = o[i] + x[i];
+                    acc = make_float4(x[0], x[1], x[2], x[3]);
+                }
+            }
+            if (a.fuse) acc = relu_dropout4(acc, a, row, col0);
             if (col0 + 4 <= a.dim) {
                 *reinterpret_cast<float4 *>(o) = acc;
             } else {                                       // ragged tail: dim % 4 != 0
@@ -596,6 +610,7 @@ __global__ __launch_bounds__(256) void graphsum_scalar_kernel(GsArgs a) {
                 if (slot >= 0) {
                     a.partials[(size_t)slot * a.part_ld + col] = v;
                 } else {
+                    if (a.accumulate) v = a.out[(size_t)row * a.ld_out + col] + v;
                     if (a.fuse) {
                         v = v > 0.f ? v : 0.f;
                         if (a.training) {
@@ -620,7 +635,7 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
     const int row = sr.x, first = sr.y, ns = sr.z;
     if (!row_wanted(a, row)) return;
     for (int col = threadIdx.x; col < a.dim; col += blockDim.x) {
-        float v = 0.f;
+        float v = a.accumulate ? a.out[(size_t)row * a.ld_out + col] : 0.f;
         for (int k = 0; k < ns; k++) v += a.partials[(size_t)(first + k) * a.part_ld + col];
         if (a.fuse) {
             v = v > 0.f ? v : 0.f;
@@ -649,7 +664,7 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     // than a wave per task once the row loads are batched (1.15 vs 0.85 ms at Reddit scale): fresh waves arriving in
     // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
     static const bool pipe = getenv("GCNHIP_GS_PIPE") != nullptr;
-    if (pipe && a.n_tasks && !a.out_bits) {
+    if (pipe && a.n_tasks && !a.out_bits && !a.accumulate) {
         const int per_xcd = std::min(max_blocks, 32 * 8);
         graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
         return;
@@ -679,13 +694,18 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
                          const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr,
-                         const gcnhip_rowset *rs = nullptr) {
+                         const gcnhip_rowset *rs = nullptr, int accumulate = 0) {
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
+    if (accumulate && in_bf) return -1;                     // the bf16 kernel has no accumulating store
+    if (rs && rs->owner != g)                                // a subset brings task lists and segment slots of ITS adjacency object
+        return gcnhip_fail("gcnhip_graphsum*: the row subset was registered on another adjacency object");
     if (in_bf && (ld_in % 8 != 0 || !aligned16(in_bf))) return -1;
     if (g->n_rows == 0 || (rs && rs->n_tasks == 0)) return 0;
     // the segment scratch of split rows is sized when the object is built (256 columns) or by
     // gcnhip_graph_reserve_width; a launch never allocates, synchronises or touches the object
-    if (g->n_slots && g->part_ld < (dim + 7) / 8 * 8) return -1;
+    if (g->n_slots && g->part_ld < (dim + 7) / 8 * 8)
+        return gcnhip_fail("gcnhip_graphsum*: dim is wider than the split-row scratch of this adjacency object; call "
+                           "gcnhip_graph_reserve_width(ctx, g, dim) once before the first launch (restricted objects: on them too)");
     GsArgs a;
     a.indptr = g->indptr; a.indices = g->indices; a.coef = g->coef;
     // a registered row subset brings its own compacted task list (same order, same segment slots)
@@ -701,6 +721,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.seed = seed; a.elem_offset = elem_offset; a.d_epoch = d_epoch; a.keep_mask = keep_mask;
     a.row_bits = row_bits;
     a.out_bits = out_bits;
+    a.accumulate = accumulate;
     const int nt = a.n_tasks ? a.n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     const int d4 = (dim + 3) / 4;
@@ -772,6 +793,15 @@ int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const flo
                                  const uint8_t *keep_mask) {
     if (training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 1, training, p, seed, d_epoch, elem_offset, keep_mask);
+}
+
+int gcnhip_graphsum_part(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_rowset *rows, const float *in, int ld_in,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, int accumulate,
+                         int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
+                         uint64_t elem_offset, const uint8_t *keep_mask) {
+    if (relu_dropout && training && !(p >= 0.f && p < 1.f)) return -1;
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, relu_dropout ? 1 : 0, relu_dropout ? training : 0, relu_dropout ? p : 0.f,
+                         seed, d_epoch, elem_offset, keep_mask, in_row_bits, nullptr, nullptr, rows, accumulate ? 1 : 0);
 }
 
 int gcnhip_rowpack_create(gcnhip_ctx *c, gcnhip_rowpack **out, int rows, int cols) {

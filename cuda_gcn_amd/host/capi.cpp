@@ -163,9 +163,48 @@ int gcnhost_dataset_save_binary(gcnhost_dataset *d, const gcnhost_params *p, con
 }
 int gcnhost_dataset_free(gcnhost_dataset *d) { delete d; return 0; }
 
+// The HALO exchange (RCCL: grouped ncclSend/ncclRecv straight into the table segments) on a small synthetic graph:
+// node i points at i+1, i+3, i-1 and i + N/2 (mod N), so every rank needs rows of its neighbour ranks and of the rank
+// half-way round; every table row must come back holding its global id.  Any transport.
+static void halo_round_trip(gcnhip_ctx *ctx, Comm *comm, int rank, int world) {
+    const int N = world * 96, ld = 8;
+    std::vector<int> gp(N + 1), gi;
+    for (int i = 0; i < N; i++) {
+        gp[i] = (int)gi.size();
+        gi.push_back(i);
+        for (int off : {1, 3, N / 2, N - 1}) gi.push_back((i + off) % N);
+    }
+    gp[N] = (int)gi.size();
+    const RowPartition part = make_partition(gp.data(), N, world);
+    const ExchangePlan plan = make_exchange_plan(gp.data(), gi.data(), N, part, rank, /*HALO*/ 2);
+    ExchangeBuffers xb;
+    exchange_buffers_create(ctx, plan, ld, &xb);
+    std::vector<float> tab((size_t)plan.table_rows * ld, -1.f);
+    for (int r = 0; r < plan.n_local; r++)
+        for (int k = 0; k < ld; k++) tab[(size_t)r * ld + k] = (float)(part.start[rank] + r) + 0.125f * k;
+    void *dt = nullptr;
+    try {
+        GCNHIP_CHECK(gcnhip_malloc(ctx, &dt, tab.size() * sizeof(float)));
+        GCNHIP_CHECK(gcnhip_h2d(ctx, dt, tab.data(), tab.size() * sizeof(float)));
+        for (int it = 0; it < 3; it++) comm->exchange_rows(plan, xb, (float *)dt, ld);
+        GCNHIP_CHECK(gcnhip_d2h(ctx, tab.data(), dt, tab.size() * sizeof(float)));
+    } catch (...) {
+        gcnhip_free(ctx, dt);
+        exchange_buffers_destroy(&xb);
+        throw;
+    }
+    gcnhip_free(ctx, dt);
+    exchange_buffers_destroy(&xb);
+    for (int t = 0; t < plan.table_rows; t++)
+        for (int k = 0; k < ld; k++)
+            if (tab[(size_t)t * ld + k] != (float)plan.table_global[t] + 0.125f * k)
+                throw GcnHipFailure(-1, "halo exchange self-test: a table row came back with the wrong content");
+}
+
 // RCCL round trip with `world` ranks (one per process; world == 1: a single-rank communicator): communicator
-// init from the shared unique id, in-place all-gather of distinct blocks, all-reduce, the validation lane's
-// split communicator on a second stream, and collectives alternating between the two (turnstile order).
+// init from the shared unique id, in-place all-gather of distinct blocks, all-reduce, the halo exchange (grouped
+// ncclSend/ncclRecv through an ExchangePlan's send lists, world > 1), the validation lane's split communicator on a
+// second stream, and collectives alternating between the two (turnstile order).
 int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *nccl_id) {
     if (world < 1 || rank < 0 || rank >= world || !nccl_id) { g_err = "bad rank/world/id"; return -1; }
     API_TRY({
@@ -191,6 +230,7 @@ int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *ncc
             for (size_t i = 0; i < B; i++)
                 if (back[i] != (float)world * ((float)i * 0.5f)) throw GcnHipFailure(-1, "RCCL self-test: all-reduce mismatch");
             gcnhip_free(ctx, d);
+            if (world > 1) halo_round_trip(ctx, comm.get(), rank, world);
             void *sa;
             GCNHIP_CHECK(gcnhip_malloc(ctx, &sa, 256 * world * sizeof(float)));
             GCNHIP_CHECK(gcnhip_memset_async(ctx, sa, 0, 256 * world * sizeof(float)));
@@ -223,6 +263,23 @@ int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *ncc
             }
             gcnhip_ctx_destroy(ctx2);
             gcnhip_free(ctx, sa);
+        }
+        gcnhip_ctx_destroy(ctx);
+    })
+}
+
+// the same halo round trip through the host-staged transport (tests: ranks as threads or gloo processes sharing a GPU)
+int gcnhost_halo_selftest_host(int device, int rank, int world, gcnhost_allgather_fn ag, gcnhost_allreduce_fn ar, void *user) {
+    if (world < 2 || rank < 0 || rank >= world || !ag || !ar) { g_err = "bad rank/world/callbacks"; return -1; }
+    API_TRY({
+        gcnhip_ctx *ctx = nullptr;
+        GCNHIP_CHECK(gcnhip_ctx_create(&ctx, device, nullptr));
+        try {
+            std::unique_ptr<Comm> comm(make_host_comm(ctx, rank, world, ag, ar, user));
+            halo_round_trip(ctx, comm.get(), rank, world);
+        } catch (...) {
+            gcnhip_ctx_destroy(ctx);
+            throw;
         }
         gcnhip_ctx_destroy(ctx);
     })

@@ -44,6 +44,57 @@ void exchange_buffers_destroy(ExchangeBuffers *b) {
     *b = ExchangeBuffers();
 }
 
+ExchangeLane::ExchangeLane(gcnhip_ctx *main_ctx, int device, Comm *parent, const ExchangePlan &plan, int max_ld_words, bool timers_on)
+    : main(main_ctx) {
+    GCNHIP_CHECK(gcnhip_ctx_create(&ctx, device, nullptr));
+    try {
+        comm.reset(parent->clone_for(ctx));
+        exchange_buffers_create(ctx, plan, max_ld_words, &xbuf);
+        timers.reset(new DeviceTimers(ctx));
+        timers->enabled = timers_on;
+        for (int i = 0; i < 32; i++) {
+            void *e = nullptr;
+            GCNHIP_CHECK(gcnhip_event_create_sync(&e));
+            events.push_back(e);
+        }
+    } catch (...) {
+        for (void *e : events) gcnhip_event_destroy(e);
+        timers.reset();
+        exchange_buffers_destroy(&xbuf);
+        comm.reset();
+        gcnhip_ctx_destroy(ctx);
+        throw;
+    }
+}
+
+ExchangeLane::~ExchangeLane() {
+    gcnhip_ctx_sync(ctx);
+    for (void *e : events) gcnhip_event_destroy(e);
+    timers.reset();
+    exchange_buffers_destroy(&xbuf);
+    comm.reset();
+    gcnhip_ctx_destroy(ctx);
+}
+
+void *ExchangeLane::next_event() {
+    void *e = events[next];
+    next = (next + 1) % events.size();
+    return e;
+}
+
+void *ExchangeLane::begin(const ExchangePlan &plan, float *table, int ld_words) {
+    void *ev_in = next_event(), *ev_done = next_event();
+    GCNHIP_CHECK(gcnhip_event_record(main, ev_in));          // this rank's block of the table is complete behind this point
+    GCNHIP_CHECK(gcnhip_stream_wait_event(ctx, ev_in));
+    timers->start(TMR_COMM);
+    comm->exchange_rows(plan, xbuf, table, ld_words);
+    timers->stop(TMR_COMM);
+    GCNHIP_CHECK(gcnhip_event_record(ctx, ev_done));
+    return ev_done;
+}
+
+void ExchangeLane::wait(void *ev) { GCNHIP_CHECK(gcnhip_stream_wait_event(main, ev)); }
+
 namespace {
 
 // Two communicators of one process (training lane + validation lane) must never have collectives in

@@ -7,8 +7,11 @@
 // Both are enqueued on the context's stream: no host synchronisation.
 #pragma once
 #include <cstddef>
+#include <memory>
+#include <vector>
 #include "gcnhip.h"
 #include "partition.h"
+#include "timer.h"
 
 // device-side companions of an ExchangePlan for ONE context / stream (each lane has its own, so the lanes'
 // exchanges never share a send buffer): the send lists and a packing buffer.  Empty for ALLGATHER plans.
@@ -35,6 +38,30 @@ struct Comm {
     // a second communicator over the same ranks whose collectives run on another context's stream
     // (the validation lane); every rank must call it at the same point
     virtual Comm *clone_for(gcnhip_ctx *ctx) = 0;
+};
+
+// Asynchronous exchanges (HIPGCN_OVERLAP_EXCHANGE, SURVEY §8e "overlap local-block SpMM with arrival of remote blocks"):
+// a second stream of this rank with its own communicator (clone_for) and packing buffers.  begin() makes that stream
+// wait for everything enqueued so far on the main stream (the producer of the rows this rank contributes), enqueues the
+// exchange there and returns an event; the main stream goes on with work that needs only this rank's own rows and
+// waits for the event (wait()) in front of the first kernel that reads a row of another rank.  Every rank runs the same
+// host program, so the collectives of the two communicators are enqueued in the same order everywhere (and, under RCCL,
+// executed in that order: the turnstile of comm.cpp).
+struct ExchangeLane {
+    gcnhip_ctx *main = nullptr;           // the stream whose work the exchange follows and feeds (not owned)
+    gcnhip_ctx *ctx = nullptr;            // the exchange stream (owned)
+    std::unique_ptr<Comm> comm;
+    ExchangeBuffers xbuf;
+    std::unique_ptr<DeviceTimers> timers; // TMR_COMM on the exchange stream
+    std::vector<void *> events;           // a ring: an event is reused long after its last waiter was enqueued
+    size_t next = 0;
+    ExchangeLane(gcnhip_ctx *main_ctx, int device, Comm *parent, const ExchangePlan &plan, int max_ld_words, bool timers_on);
+    ~ExchangeLane();
+    ExchangeLane(const ExchangeLane &) = delete;
+    void *begin(const ExchangePlan &plan, float *table, int ld_words);
+    void wait(void *ev);
+private:
+    void *next_event();
 };
 
 // world == 1: nothing to exchange

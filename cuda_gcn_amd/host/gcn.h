@@ -35,11 +35,12 @@ enum HipGCNFlags {
     HIPGCN_HOST_MASKS = 2,    // parity mode: dropout decisions from the reference's host RNG stream
     HIPGCN_TIMERS = 4,        // record device-event timers per op
     HIPGCN_NO_GRAPH = 8,      // never replay epochs from a captured hipGraph
-    HIPGCN_EVAL_LANE = 16,    // validation forward on a second stream, overlapped with the next training epoch
-    HIPGCN_NO_EVAL_LANE = 32, // never (default: on when world > 1, where it hides the all-gathers)
+    HIPGCN_EVAL_LANE = 16,    // validation forward on a second stream, overlapped with the next training epoch (opt-in; with
+                              // several GPUs it adds a second communicator: not the default until measured on such a node)
+    HIPGCN_NO_EVAL_LANE = 32, // never
     HIPGCN_NO_REPLICATE_L1 = 64, // multi-GPU: all-gather H0 instead of computing X.W1 for all rows on every rank
     HIPGCN_REPLICATE_L1 = 128,   // ... or force the replication (default: 2-4 GPUs replicate, 8 gather)
-    HIPGCN_GATHER_DH1 = 256,
+    HIPGCN_GATHER_DH1 = 256,     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
     HIPGCN_BF16_TABLES = 2048,   // opt-in, beyond the reference: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate)
     HIPGCN_ALL_ROWS = 4096,      // compute every row of the logits (default: only rows of the scored split, which is all the loss and accuracy read)
     HIPGCN_NO_AGG_FIRST_EVAL = 8192, // evaluation forwards keep the reference's order A^.(X.W1) instead of (A^.X).W1 with A^.X built once
@@ -53,7 +54,13 @@ enum HipGCNFlags {
                                        // aggregating through an operator that has lost the edges pointing at them
     HIPGCN_PACKED_DH1 = 65536,         // opt-in: dH1 reaches the hidden layer's backward gather as packed rows (same bits; measured slower)
     HIPGCN_NULL_COMM = 1024,     // world > 1 without transport: collectives are no-ops (per-rank compute timing only)
-    HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)     // multi-GPU: all-gather dH1 (128 wide) instead of dZ0 (48 wide) + 1 bit per element of H1
+    HIPGCN_NO_ROW_GROUPS = 512,  // keep the aggregation's plain descending-degree row schedule (no timing of alternatives)
+    HIPGCN_OVERLAP_EXCHANGE = 1048576,  // multi-GPU: exchanges on their own stream; each aggregation starts on the edges that point at
+                                        // this rank's own rows while the other ranks' rows arrive, then adds the rest (the order of a
+                                        // row's sum then depends on the partition: float tolerance, not bit-identity, across P)
+    HIPGCN_STRUCTURE_PARTITION = 2097152, // multi-GPU: rank blocks formed from groups found in the graph (cluster.h) instead of
+                                          // contiguous id ranges, when that shrinks the neediest rank's halo (default: decided per graph)
+    HIPGCN_ID_PARTITION = 4194304,        // ... never
 };
 
 struct HipGCNOptions {
@@ -154,6 +161,14 @@ private:
     void build_bwd_pipeline(HipSparseMatmul *sm, HipGraphSum *gs);
     void destroy_bwd_pipeline();
     gcnhip_graph *graph_bwd_out = nullptr;                     // `graph` without the edges whose source is outside the training split
+    // HIPGCN_OVERLAP_EXCHANGE: `graph` and `graph_bwd_out` cut by column owner (own rows / other ranks' rows), the split
+    // subsets of the last aggregation on both halves, and the exchange stream
+    gcnhip_graph *graph_loc = nullptr, *graph_rem = nullptr, *graph_bwd_loc = nullptr, *graph_bwd_rem = nullptr;
+    gcnhip_rowset *split_rows_loc[4] = {}, *split_rows_rem[4] = {};
+    gcnhip_rowset *cur_out_rows_loc = nullptr, *cur_out_rows_rem = nullptr;
+    std::unique_ptr<ExchangeLane> xlane;
+    void build_overlap();
+    void wire_overlap(HipGraphSum *gs, bool output_layer);
     std::vector<uint32_t> h_train_bits;
     uint32_t *d_train_bits = nullptr;                          // bit per (padded) node: in the training split
     const uint32_t *bwd_bits = nullptr;

@@ -14,7 +14,20 @@ void HipMatmul::forward(bool) {
 
 void HipMatmul::backward() {
     env->timers->start(TMR_MATMUL_BW);
-    if (pos_bits_full) {
+    if (pos_bits_full && env->xlane) {
+        // the exchange of dc runs on the exchange stream beside everything that needs only this rank's rows: db, and da
+        // of the own block; da of the other ranks' rows follows when their dc (and their mask bits, in flight since the
+        // forward) have arrived
+        void *ev = env->xlane->begin(*env->plan, c->full_grad, c->ld);
+        GCNHIP_CHECK(gcnhip_matmul_bwd(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
+                                       nullptr, a->ld, b->grad, b->ld, m, n, p));
+        const int own = env->plan->own_offset;
+        rebuild_da(own, m);
+        env->xlane->wait(ev);
+        if (env->pos_bits_ready) { env->xlane->wait(env->pos_bits_ready); env->pos_bits_ready = nullptr; }
+        rebuild_da(0, own);
+        rebuild_da(own + m, all_rows - own - m);
+    } else if (pos_bits_full) {
         // db from this rank's rows; da for every row of every rank from the gathered dc and mask bits
         GCNHIP_CHECK(gcnhip_matmul_bwd(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                        nullptr, a->ld, b->grad, b->ld, m, n, p));
@@ -23,8 +36,7 @@ void HipMatmul::backward() {
         env->comm->exchange_rows(*env->plan, *env->xbuf, c->full_grad, c->ld);
         env->timers->stop(TMR_COMM);
         env->timers->start(TMR_MATMUL_BW);
-        GCNHIP_CHECK(gcnhip_matmul_bwd_da_bits(env->ctx, b->data, b->ld, c->full_grad, c->ld, a->full_grad, a->ld,
-                                               all_rows, n, p, pos_bits_full, wpr, fused_bwd_scale));
+        rebuild_da(0, all_rows);
     } else if (fused_bwd_scale > 0.f && da_pack)
         GCNHIP_CHECK(gcnhip_matmul_bwd_packed(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                               a->grad, a->ld, da_pack, b->grad, b->ld, m, n, p, fused_bwd_scale));
@@ -35,6 +47,13 @@ void HipMatmul::backward() {
         GCNHIP_CHECK(gcnhip_matmul_bwd(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                        a->grad, a->ld, b->grad, b->ld, m, n, p));
     env->timers->stop(TMR_MATMUL_BW);
+}
+
+void HipMatmul::rebuild_da(int first, int rows) {
+    if (rows <= 0) return;
+    GCNHIP_CHECK(gcnhip_matmul_bwd_da_bits(env->ctx, b->data, b->ld, c->full_grad + (size_t)first * c->ld, c->ld,
+                                           a->full_grad + (size_t)first * a->ld, a->ld, rows, n, p,
+                                           pos_bits_full + (size_t)first * wpr, wpr, fused_bwd_scale));
 }
 
 // ------------------------------------------------------------- SparseMatmul
@@ -153,6 +172,21 @@ void HipGraphSum::forward(bool training) {
                                           training ? env->keep_hidden : nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_FW);
+    } else if (env->xlane && split_loc && !replicated && world > 1) {
+        // exchange on its own stream; meanwhile the edges that point at this rank's own rows, then the others on top
+        void *ev = env->xlane->begin(*env->plan, in->full, in->ld);
+        const gcnhip_rowset *rows_loc = fwd_out_rows_loc ? *fwd_out_rows_loc : nullptr, *rows_rem = fwd_out_rows_rem ? *fwd_out_rows_rem : nullptr;
+        const bool fused = fused_relu_dropout >= 0.f;
+        env->timers->start(TMR_GRAPHSUM_FW);
+        if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_loc, rows_loc, in->full, in->ld, out->data, out->ld, dim, nullptr, 0,
+                                          0, 0, 0.f, 0, nullptr, 0, nullptr));
+        env->xlane->wait(ev);
+        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_rem, rows_rem, in->full, in->ld, out->data, out->ld, dim, nullptr, 1,
+                                          fused ? 1 : 0, training ? 1 : 0, fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT,
+                                          env->d_epoch, elem_offset, training ? env->keep_hidden : nullptr));
+        if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+        env->timers->stop(TMR_GRAPHSUM_FW);
     } else {
         if (!replicated && world > 1) {
             env->timers->start(TMR_COMM);
@@ -176,9 +210,15 @@ void HipGraphSum::forward(bool training) {
     if (pos_bits_full && training) {
         uint32_t *mine = pos_bits_full + (size_t)env->plan->own_offset * wpr;
         GCNHIP_CHECK(gcnhip_pack_positive(env->ctx, out->data, out->ld, out->rows, dim, mine, wpr));
-        env->timers->start(TMR_COMM);
-        env->comm->exchange_rows(*env->plan, *env->xbuf, reinterpret_cast<float *>(pos_bits_full), wpr);   // bytes are moved, not interpreted
-        env->timers->stop(TMR_COMM);
+        if (env->xlane) {
+            // nobody reads the other ranks' bits before the Matmul backward: the exchange stream delivers them meanwhile
+            if (env->pos_bits_ready) env->xlane->wait(env->pos_bits_ready);        // (a forward whose backward never ran)
+            env->pos_bits_ready = env->xlane->begin(*env->plan, reinterpret_cast<float *>(pos_bits_full), wpr);
+        } else {
+            env->timers->start(TMR_COMM);
+            env->comm->exchange_rows(*env->plan, *env->xbuf, reinterpret_cast<float *>(pos_bits_full), wpr);   // bytes are moved, not interpreted
+            env->timers->stop(TMR_COMM);
+        }
     }
 }
 
@@ -204,6 +244,19 @@ void HipGraphSum::backward() {
         }
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
         GCNHIP_CHECK(gcnhip_graphsum_bf16(env->ctx, graph, tab, ld_bf, in->grad, in->ld, dim, row_bits, nullptr, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
+        env->timers->stop(TMR_GRAPHSUM_BW);
+        return;
+    }
+    if (world > 1 && !out_grad_complete && env->xlane && split_loc) {
+        const gcnhip_graph *loc = bwd_split_loc ? bwd_split_loc : split_loc, *rem = bwd_split_rem ? bwd_split_rem : split_rem;
+        const uint32_t *bits = bwd_split_loc ? nullptr : row_bits;      // the restricted operators have lost the known-zero rows already
+        void *ev = env->xlane->begin(*env->plan, out->full_grad, out->ld);
+        env->timers->start(TMR_GRAPHSUM_BW);
+        if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
+        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, loc, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 0, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        env->xlane->wait(ev);
+        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, rem, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 1, 0, 0, 0.f, 0, nullptr, 0, nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_BW);
         return;

@@ -33,6 +33,10 @@ struct HipEnv {
     const uint8_t *keep_hidden = nullptr;    // [local rows * hidden]
     // opt-in: GraphSum gathers bfloat16 copies of its inputs (f32 accumulate); beyond the reference's f32 path
     bool bf16_tables = false;
+    // HIPGCN_OVERLAP_EXCHANGE: exchanges run on their own stream (comm.h, ExchangeLane) while this stream works on the
+    // edges that point at this rank's own rows
+    ExchangeLane *xlane = nullptr;
+    void *pos_bits_ready = nullptr;          // event of the in-flight exchange of the H1 > 0 bits (forward -> Matmul backward)
 };
 
 // The hidden layer's backward aggregation hands dH0 to the weight gradient dW1 = X~^T . dH0 in row blocks: the
@@ -69,6 +73,9 @@ public:
     // that do not fit a slot.  The consumer is the GraphSum that owns the same pack.
     gcnhip_rowpack *da_pack = nullptr;
     HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
+private:
+    void rebuild_da(int first_row, int n_rows);     // da rows [first_row, first_row + n_rows) of the table from dc + mask bits
+public:
     void forward(bool) override;
     void backward() override;
 };
@@ -120,6 +127,13 @@ public:
     gcnhip_rowset *const *fwd_out_rows = nullptr;
     // backward(): out->grad arrives as packed rows (written by HipMatmul::backward into the same pack)
     gcnhip_rowpack *out_grad_pack = nullptr;              // a subset registered on `graph` (gcnhip_graph_add_rowset)
+    // HIPGCN_OVERLAP_EXCHANGE: `graph` cut in two by the owner of the column (gcnhip_graph_create_restricted, twice): the
+    // edges that point at this rank's own rows, and the rest.  forward()/backward() then start the exchange on the
+    // exchange stream, aggregate through `loc` meanwhile, wait, and add the terms of `rem` (gcnhip_graphsum_part).
+    // bwd_split_*: the same cut of bwd_graph.  The row subsets of the last aggregation exist per operator.
+    const gcnhip_graph *split_loc = nullptr, *split_rem = nullptr;
+    const gcnhip_graph *bwd_split_loc = nullptr, *bwd_split_rem = nullptr;
+    gcnhip_rowset *const *fwd_out_rows_loc = nullptr, *const *fwd_out_rows_rem = nullptr;
     // backward(): in->grad is produced block by block and handed to this consumer's weight gradient (BackwardPipeline)
     BackwardPipeline *pipe = nullptr;
     HipSparseMatmul *pipe_consumer = nullptr;

@@ -57,6 +57,8 @@ int  gcnhip_ctx_destroy(gcnhip_ctx *ctx);
 int  gcnhip_ctx_sync(gcnhip_ctx *ctx);                 /* synchronises the stream */
 void *gcnhip_ctx_stream(gcnhip_ctx *ctx);
 const char *gcnhip_error_string(int code);
+/* detail of the calling thread's most recent -1 (argument error) where the library has one to give, else "" */
+const char *gcnhip_last_error(void);
 const char *gcnhip_version(void);
 
 /* ---- memory (CUDAVariable ctor/dtor/zero: src/cuda/cuda_variable.cu:3-31) ---- */
@@ -96,7 +98,10 @@ int gcnhip_graph_create_grouped(gcnhip_ctx *ctx, gcnhip_graph **g, const int *h_
 int gcnhip_graph_set_schedule(gcnhip_ctx *ctx, gcnhip_graph *g, int mode, const int *h_row_group, int n_groups);
 /* Widest aggregation (columns) this object will be asked for.  Rows cut into segments need a scratch row per
  * segment; it is sized for 256 columns when the object is built and grown HERE (synchronises the context) —
- * never inside gcnhip_graphsum*, which return -1 for a wider call.  So a launch allocates nothing, may be
+ * never inside gcnhip_graphsum*, which return -1 for a wider call on an object that has split rows (and leave a
+ * message naming this function in gcnhip_last_error()).  Objects made by gcnhip_graph_create_restricted copy the
+ * parent's width when they are created: call this on the parent FIRST, or on each restricted object as well.
+ * So a launch allocates nothing, may be
  * captured into a hipGraph at any time, and treats the object as read-only apart from that scratch: two streams
  * may share one object only if their aggregations never overlap in time (HipGCN gives each lane its own). */
 int gcnhip_graph_reserve_width(gcnhip_ctx *ctx, gcnhip_graph *g, int max_dim);
@@ -130,7 +135,8 @@ int gcnhip_graphsum_masked(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *
  * compacted task list for the rows with bit r set in h_row_bits (host, n_rows bits) out of the object's row schedule
  * — no wave is launched for a row outside it (the device mask above launches every wave and retires the unwanted ones:
  * at 10 % wanted rows that is 4x slower than the compacted list).  The subset belongs to the object: it follows
- * gcnhip_graph_set_schedule and is freed by gcnhip_graph_destroy.  Results as gcnhip_graphsum_masked. */
+ * gcnhip_graph_set_schedule and is freed by gcnhip_graph_destroy; passing it with any other adjacency object is an
+ * argument error (-1).  Results as gcnhip_graphsum_masked. */
 int gcnhip_graph_add_rowset(gcnhip_ctx *ctx, gcnhip_graph *g, const uint32_t *h_row_bits, gcnhip_rowset **rows);
 int gcnhip_rowset_size(const gcnhip_rowset *rows, int *n_tasks);
 int gcnhip_graphsum_rowset(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_rowset *rows, const float *in, int ld_in,
@@ -145,6 +151,20 @@ int gcnhip_graphsum_rowset(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_
  * scale the masked class-width backward takes 0.39 ms, the restricted operator 0.27 ms (a third of the edges gone and
  * no predicate on the loads).  The object is independent of the parent: destroy it with gcnhip_graph_destroy. */
 int gcnhip_graph_create_restricted(gcnhip_ctx *ctx, gcnhip_graph **out, const gcnhip_graph *parent, const uint32_t *h_col_bits);
+/* One PART of an aggregation whose edges were split over two operators with the same rows (both made by
+ * gcnhip_graph_create_restricted from one parent with complementary column sets).  The row-partitioned epoch uses it
+ * to start on the edges that point at this rank's own rows while the rows of the other ranks are still in flight on the
+ * exchange stream, then adds the remaining edges (xGMI note):
+ *     accumulate == 0:  out[r,:]  = sum over the operator's edges            (the first part)
+ *     accumulate != 0:  out[r,:]  = out[r,:] + that sum                      (the second part; rows with no edge keep their value)
+ * with every option of the other entry points: rows (NULL or a subset registered on THIS g), in_row_bits (NULL or as in
+ * gcnhip_graphsum_rowmask), and relu_dropout != 0 = the epilogue of gcnhip_graphsum_relu_dropout applied AFTER the
+ * addition, i.e. by the last part only.  The sum of a row is then (terms of part 1) + (terms of part 2): the same real
+ * number as gcnhip_graphsum on the parent, associated differently — within the f32 bound of the tests, not bit-identical. */
+int gcnhip_graphsum_part(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_rowset *rows, const float *in, int ld_in,
+                         float *out, int ld_out, int dim, const uint32_t *in_row_bits, int accumulate,
+                         int relu_dropout, int training, float p, uint64_t seed, const uint32_t *d_epoch,
+                         uint64_t elem_offset, const uint8_t *keep_mask);
 /* Fused epilogue used by the first layer: GraphSum, then ReLU
  * (module.cpp:175-185), then Dropout (module.cpp:207-221) on the same rows.
  * training == 0: ReLU only.  The dropout decision for element (r, c) is

@@ -125,8 +125,12 @@ int gcnhost_dataset_free(gcnhost_dataset *d);
  * destroy): checks that the RCCL this process loaded works before a multi-GPU job relies on it */
 int gcnhost_rccl_selftest(int device);
 /* the same with `world` ranks, one process per rank, all given the id rank 0 got from gcnhost_nccl_unique_id:
- * in-place all-gather of distinct blocks, all-reduce, split communicator, alternating lanes — values checked */
+ * in-place all-gather of distinct blocks, all-reduce, the halo exchange (an ExchangePlan's send lists moved by grouped
+ * ncclSend/ncclRecv, every table row checked), split communicator, alternating lanes — values checked */
 int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *nccl_id);
+/* the halo round trip of that self-test through the host-staged transport (the callbacks of gcnhost_model_create) */
+int gcnhost_halo_selftest_host(int device, int rank, int world, gcnhost_allgather_fn host_allgather,
+                               gcnhost_allreduce_fn host_allreduce, void *host_user);
 
 /* host-only helpers, callable without a GPU (CPU tests) */
 int gcnhost_partition(const int *g_indptr, int n_rows, int world, int *start /* [world+1] */, int *rows_max);

@@ -117,6 +117,93 @@ def test_two_ranks_one_gpu_match_single_gpu(name, world, dropout, run_async, fla
     m.close()
 
 
+# HIPGCN_OVERLAP_EXCHANGE (1048576): every exchange on its own stream, each aggregation cut into the edges that point at
+# the rank's own rows (run meanwhile) and the rest (added when the rows have arrived).  A row's sum is then associated
+# as (own-column terms) + (other terms), which depends on the partition: compared at the stated float tolerance, not bit for bit.
+OVERLAP = 1048576
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,dropout,run_async,flags", [
+    ("cora-syn", 2, 0.5, 0, OVERLAP), ("cora-syn", 3, 0.5, 1, OVERLAP), ("cora-syn", 8, 0.5, 0, OVERLAP),
+    ("cora-syn", 8, 0.0, 1, 0),                             # eight logical ranks without the overlap: the plain schedule
+    ("cora-syn", 3, 0.5, 0, OVERLAP | 32768),               # halo plan: own rows first in the table
+    ("cora-syn", 8, 0.5, 1, OVERLAP | 32768),
+    ("cora-syn", 2, 0.5, 0, OVERLAP | 2),                   # HOST_MASKS
+    ("cora-syn", 3, 0.5, 0, OVERLAP | 64),                  # NO_REPLICATE_L1: the hidden-width exchange overlapped too
+    ("cora-syn", 2, 0.5, 0, OVERLAP | 256),                 # GATHER_DH1: the hidden layer's backward exchange overlapped
+    ("cora-syn", 2, 0.5, 0, OVERLAP | 131072),              # MASKED_BWD: the cut of the full operator + the row mask
+    ("cora-syn", 3, 0.5, 0, OVERLAP | 4096),                # ALL_ROWS
+    ("cora-syn", 2, 0.5, 0, OVERLAP | 1),                   # MODULAR: one module per reference module
+    ("cora-syn", 2, 0.5, 1, OVERLAP | 16),                  # + the validation lane (three communicators' worth of streams)
+    ("reddit-mini", 2, 0.5, 1, OVERLAP), ("reddit-mini", 3, 0.5, 0, OVERLAP | 64), ("reddit-mini", 8, 0.5, 1, OVERLAP | 64),
+    ("rmat-12-32", 3, 0.5, 1, OVERLAP), ("rmat-12-32", 8, 0.5, 0, OVERLAP),
+])
+def test_logical_ranks_as_threads_match_single_gpu(name, world, dropout, run_async, flags):
+    """2, 3 and 8 logical ranks (threads of this process, host-staged transport) against the single-GPU trace"""
+    from cuda_gcn_amd import datagen
+    from cuda_gcn_amd.model import HipGCNModel
+    from tests.mr_threads import run_ranks
+    epochs = 10
+    hidden = 128 if name.startswith("reddit") else 16
+    ds = datagen.make_dataset(name)
+    got = run_ranks(ds, world, flags, epochs, hidden, dropout, run_async=bool(run_async))
+    for tr in got["traces"][1:]:
+        assert np.array_equal(tr, got["traces"][0])          # every rank reads the same all-reduced scalars
+    m = HipGCNModel(ds, seed=4, flags=flags & (1 | 2), hidden_dim=hidden, dropout=dropout, epochs=epochs)
+    want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
+    wtest = m.eval(3)
+    tol = 2e-4                                                # SURVEY §8(d): |dloss| <= 2e-4 for epochs 1-10
+    assert np.abs(got["trace"][:, [0, 2]] - want[:, [0, 2]]).max() <= tol, np.abs(got["trace"] - want).max(axis=0)
+    n_scored = max(1, int((ds["split"] == 2).sum()))
+    assert np.abs(got["trace"][:, [1, 3]] - want[:, [1, 3]]).max() <= max(0.005, 2.0 / n_scored)
+    assert np.abs(got["test"] - np.array(wtest, np.float32)).max() <= tol
+    dh = np.abs(got["h1"] - m.var(3))
+    assert np.median(dh) <= 1e-5 and np.quantile(dh, 0.999) <= 1e-3 * max(1.0, float(np.abs(m.var(3)).max())), (np.median(dh), dh.max())
+    m.close()
+
+
+@pytest.mark.gpu
+def test_overlap_exchange_vs_oracle_cora():
+    """the overlapped schedule against the CPU oracle itself (reference RNG stream replayed on every rank)"""
+    from cuda_gcn_amd import datagen
+    from oracle.pyoracle import Oracle
+    from tests.mr_threads import run_ranks
+    ds = datagen.make_dataset("cora-syn")
+    epochs = 10
+    got = run_ranks(ds, 3, OVERLAP | 2, epochs, 16, 0.5, seed=1)
+    o = Oracle().model(ds, seed_time=1, hidden_dim=16, dropout=0.5)
+    want = np.array([o.train_epoch() + o.eval(2) for _ in range(epochs)], np.float32)
+    o.close()
+    assert np.abs(got["trace"][:, [0, 2]] - want[:, [0, 2]]).max() <= 2e-4, np.abs(got["trace"] - want).max(axis=0)
+    assert np.abs(got["trace"][:, [1, 3]] - want[:, [1, 3]]).max() <= 0.005
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_halo_round_trip_selftest_host_transport(world):
+    """the halo part of gcnhost_rccl_selftest_world (synthetic plan, pack kernel, per-peer segments, every table row
+    checked) through the host-staged transport: what the RCCL ranks run first on a multi-GPU node"""
+    import threading
+    from cuda_gcn_amd import _lib
+    from tests.mr_threads import ThreadWorld
+    lib = _lib.gcnhost()
+    tw = ThreadWorld(world)
+    rcs = [None] * world
+
+    def body(rank):
+        ag, ar = tw.callbacks(rank)
+        cag, car = _lib.ALLGATHER_FN(ag), _lib.ALLREDUCE_FN(ar)
+        rcs[rank] = lib.gcnhost_halo_selftest_host(0, rank, world, cag, car, None)
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert rcs == [0] * world, (rcs, lib.gcnhost_last_error())
+
+
 def _gpu_count():
     from cuda_gcn_amd import _lib
     import ctypes as C

@@ -12,5 +12,5 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr " " "_")
   timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/$N" -- python3 "$R/tools/bench_ops.py" $DS $H graphsum $EXTRA > "$OUT/$N.log" 2>&1 || echo "FAILED $N"
 done
-python3 "$R/tools/pmc_summary.py" "$OUT" > "$OUT/summary.json"
+python3 "$R/tools/pmc_summary.py" "$OUT" "${GCN_COMMIT:-unknown}" "tools/bench_ops.py $DS $H graphsum $EXTRA" > "$OUT/summary.json"
 cat "$OUT/summary.json"
