@@ -179,6 +179,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_model_sync": (I, [P]),
     "gcnhost_model_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "gcnhost_model_schedule": (I, [P, C.POINTER(I), C.POINTER(I)]),
+    "gcnhost_model_row_ids": (I, [P, P, C.POINTER(I)]),
     "gcnhost_model_get_var": (I, [P, I, I, P, C.POINTER(I), C.POINTER(I)]),
     "gcnhost_model_set_weights": (I, [P, P, P]),
     "gcnhost_model_timer": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
@@ -202,6 +203,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_glorot": (I, [P, I, I, I, C.c_long, I]),
     "gcnhost_host_masks": (I, [P, I64, F, C.c_long, I64]),
     "gcnhost_rmat_graph": (I, [I, I, U64, PP, PP, C.POINTER(I64)]),
+    "gcnhost_choose_node_order": (I, [P, P, I, I, I, P, C.POINTER(I), C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(I64)]),
     "gcnhost_structure_groups": (I, [P, P, I, P, C.POINTER(I), C.POINTER(I), C.POINTER(C.c_double), C.POINTER(I)]),
     "gcnhost_free_array": (None, [P]),
 }

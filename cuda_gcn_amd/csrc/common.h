@@ -32,7 +32,13 @@ struct gcnhip_ctx {
     // split-K slabs for the dense weight-gradient GEMMs
     float *slab;
     size_t slab_bytes;
+    int slab_n;         // partial slabs the last dense weight-gradient product left there (split ranges, or workgroups of the persistent form)
+    // packed weight image of the persistent forward GEMM (dense_persist.h), sized once at creation
+    float *wpack;
+    size_t wpack_bytes;
+    int corun;          // gcnhip_ctx_set_corun: this stream's kernels are meant to share the chip with another stream's
 };
+constexpr size_t WPACK_BYTES = (size_t)2 << 20;    // K <= 4096 at p = 128
 constexpr int RED_SLOTS = 4096;
 
 // a registered subset of the rows of an adjacency object: its own compacted task list, in the order of the

@@ -52,6 +52,8 @@ int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
         GCNHIP_TRY(hipMalloc((void **)&c->red_i, RED_SLOTS * 4 * sizeof(int32_t)));
         GCNHIP_TRY(hipMalloc((void **)&c->ticket, 64 * sizeof(uint32_t)));
         GCNHIP_TRY(hipMemset(c->ticket, 0, 64 * sizeof(uint32_t)));
+        GCNHIP_TRY(hipMalloc((void **)&c->wpack, WPACK_BYTES));
+        c->wpack_bytes = WPACK_BYTES;
         return 0;
     };
     const int rc = fill();
@@ -68,8 +70,15 @@ int gcnhip_ctx_destroy(gcnhip_ctx *c) {
     if (c->red_i) hipFree(c->red_i);
     if (c->ticket) hipFree(c->ticket);
     if (c->slab) hipFree(c->slab);
+    if (c->wpack) hipFree(c->wpack);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
+    return 0;
+}
+
+int gcnhip_ctx_set_corun(gcnhip_ctx *c, int on) {
+    if (!c) return -1;
+    c->corun = on ? 1 : 0;
     return 0;
 }
 

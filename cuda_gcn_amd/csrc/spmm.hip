@@ -13,6 +13,7 @@
 //    (72 GB) through L2 instead of 0.56 GB from HBM.
 #include "dense_kernels.h"
 #include "dense_tile128.h"
+#include "dense_persist.h"
 
 struct DropSpec {
     int on, thr;
@@ -331,6 +332,26 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         t.m = f->n_rows; t.K = f->n_cols; t.p = p; t.bits = d.on ? f->keep_bits : nullptr; t.scale = d.scale; t.rows_per_split = 0; t.relu = relu;
         dim3 grid(ceil_div(f->n_rows, T_BM), ceil_div(p, T_BN));
         const bool fast = vx == 4 && t.ldx % 4 == 0 && (t.K + 31) / 32 * 32 <= t.ldx && ld_w % 4 == 0 && p % T_BN == 0 && aligned16(w);
+        // p = 128: the persistent LDS-DMA form (dense_persist.h) — one workgroup per CU for the whole launch, rows dealt in
+        // 32-row blocks, three-stage ring.  GCNHIP_GEMM_TILES keeps the tile kernels below for A/B runs.
+        static const bool tiles_only = getenv("GCNHIP_GEMM_TILES") != nullptr;
+        const int n_chunks = (t.K + PG_BK - 1) / PG_BK;
+        if (fast && p == 128 && !tiles_only && aligned16(t.x) && aligned16(out) &&
+            (uint64_t)(t.m + PG_ROWS) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 4096 * sizeof(float) <= c->wpack_bytes) {
+            pg_pack_w_kernel<<<ceil_div(n_chunks * 4 * 256, 256), 256, 0, c->stream>>>(w, ld_w, t.K, n_chunks * 4, c->wpack, t.bits ? t.scale : 1.f);
+            GCNHIP_LAUNCH_CHECK();
+            PersistFwdArgs pa;
+            pa.x = t.x; pa.ldx = t.ldx; pa.wp = c->wpack; pa.out = out; pa.ldo = ld_out;
+            pa.m = t.m; pa.K = t.K; pa.n_chunks = n_chunks; pa.n_rb = ceil_div(t.m, 32);
+            pa.bits = t.bits; pa.relu = relu;
+            static const bool dbg_linear = getenv("GCNHIP_DBG_LINEAR") != nullptr;
+            pa.dbg_linear = dbg_linear ? 1 : 0;
+            const int wgs = std::max(1, std::min(c->n_cu, pa.n_rb));
+            if (pa.bits) dense_fwd_persist_kernel<true><<<wgs, 512, 0, c->stream>>>(pa);
+            else dense_fwd_persist_kernel<false><<<wgs, 512, 0, c->stream>>>(pa);
+            GCNHIP_LAUNCH_CHECK();
+            return 0;
+        }
         // eight waves per tile: same bits, 4 % faster than the four-wave form (0.383 -> 0.367 ms at Reddit scale);
         // GCNHIP_GEMM_W4 selects the four-wave kernel for A/B runs
         static const bool w4 = getenv("GCNHIP_GEMM_W4") != nullptr;
@@ -403,12 +424,45 @@ static bool dense_bwd_plan(const gcnhip_ctx *c, const gcnhip_feat *f, int p, int
     return true;
 }
 
+// The whole product by the persistent form (dense_persist.h): one workgroup per CU, each with a contiguous share of the rows
+// and ALL of dW in its accumulators; one slab per workgroup.  Returns 1 when the shape is not its (then the split tiles run).
+static int dense_bwd_persist(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p, const DropSpec &d) {
+    // EXPERIMENT, opt-in (GCNHIP_GEMM_PERSIST_BWD): measured SLOWER than the split tiles at Reddit scale (0.50 ms without,
+    // 0.61 ms with dropout against 0.387 ms; profiles/r03_gemm_pmc.json: the pipes 41-53 % busy, 37 % of the wave cycles
+    // parked) — ten k-major A reads + ten keep-word pairs per k step and wave make the VALU/LDS side as long as the MFMAs
+    static const bool persist_bwd = getenv("GCNHIP_GEMM_PERSIST_BWD") != nullptr;
+    if (!persist_bwd || p != 128 || f->n_rows < 1) return 1;
+    const float *x = vals; int ldx = f->n_cols;
+    if (vals == f->values && f->values_pad) { x = f->values_pad; ldx = f->ld_pad; }
+    const int n_xb = ceil_div(f->n_cols, 32);
+    if (ldx % 16 != 0 || ldx > PB_MAX_LDX || n_xb * 32 > ldx || n_xb > 2 * PB_NACC || !aligned16(x) || ld_dout % 4 != 0 || !aligned16(dout)) return 1;
+    const int G = std::max(1, std::min(c->n_cu, ceil_div(f->n_rows, PB_ROWS)));
+    const int p_ld = 128;
+    const int rc = ensure_slab(c, (size_t)G * f->n_cols * p_ld * sizeof(float));
+    if (rc) return rc;
+    PersistBwdArgs a;
+    a.x = x; a.ldx = ldx; a.dout = dout; a.ldd = ld_dout; a.slab = c->slab; a.lds = p_ld;
+    a.m = f->n_rows; a.K = f->n_cols; a.n_xb = n_xb;
+    a.rows_per_wg = ceil_div(f->n_rows, G);
+    a.bits = d.on ? f->keep_bits : nullptr; a.scale = d.scale;
+    if (a.bits) dense_bwd_persist_kernel<true><<<G, 512, 0, c->stream>>>(a);
+    else dense_bwd_persist_kernel<false><<<G, 512, 0, c->stream>>>(a);
+    GCNHIP_LAUNCH_CHECK();
+    c->slab_n = G;
+    return 0;
+}
+
 // splits [s0, s1) of the plan into their slabs
 static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,
                           const DropSpec &d, int s0, int s1) {
     int rps, S;
     if (!dense_bwd_plan(c, f, p, &rps, &S) || s0 < 0 || s1 > S || s0 > s1) return -1;
     if (s0 == s1) return 0;
+    if (s0 == 0 && s1 == S) {                    // every split at once: the persistent form when the shape is its
+        const int rc = dense_bwd_persist(c, f, vals, dout, ld_dout, p, d);
+        if (rc <= 0) return rc;
+    }
+    c->slab_n = S;
     const int kt = ceil_div(f->n_cols, 128), pt = ceil_div(p, 128);
     const int p_ld = (p + 3) / 4 * 4;
     const int rc = ensure_slab(c, (size_t)S * f->n_cols * p_ld * sizeof(float));
@@ -434,8 +488,9 @@ static int dense_bwd_finish(gcnhip_ctx *c, const gcnhip_feat *f, float *dw, int 
     int rps, S;
     if (!dense_bwd_plan(c, f, p, &rps, &S)) return -1;
     const int p_ld = (p + 3) / 4 * 4;
-    if (!c->slab || c->slab_bytes < (size_t)S * f->n_cols * p_ld * sizeof(float)) return -1;   // no part has run on this context
-    launch_slab_reduce(c->slab, S, f->n_cols, p, p_ld, dw, ld_dw, c->stream);
+    const int n_slabs = c->slab_n > 0 ? c->slab_n : S;
+    if (!c->slab || c->slab_bytes < (size_t)n_slabs * f->n_cols * p_ld * sizeof(float)) return -1;   // no part has run on this context
+    launch_slab_reduce(c->slab, n_slabs, f->n_cols, p, p_ld, dw, ld_dw, c->stream);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

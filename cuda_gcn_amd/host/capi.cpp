@@ -110,6 +110,15 @@ int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, 
         if (local_edges) *local_edges = m->gcn->n_edges_local();
     })
 }
+int gcnhost_model_row_ids(gcnhost_model *m, int *ids, int *renumbered) {
+    API_TRY({
+        const std::vector<int> &order = m->gcn->node_order();
+        const int r0 = m->gcn->row_start(), n = m->gcn->local_rows();
+        if (renumbered) *renumbered = order.empty() ? 0 : 1;
+        if (ids)
+            for (int r = 0; r < n; r++) ids[r] = order.empty() ? r0 + r : order[(size_t)r0 + r];
+    })
+}
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups) {
     API_TRY({
         if (mode) *mode = m->gcn->schedule_mode();
@@ -355,6 +364,25 @@ int gcnhost_plan_arrays(const gcnhost_plan *p, const int **recv_off, const int *
     return 0;
 }
 int gcnhost_plan_free(gcnhost_plan *p) { delete p; return 0; }
+
+int gcnhost_choose_node_order(const int *g_indptr, const int *g_indices, int n_rows, int world, int force, int *order, int *renumbered,
+                              double *ids_share, int64_t *ids_recv_rows, double *new_share, int64_t *new_recv_rows, int64_t *allgather_rows) {
+    if (!g_indptr || !g_indices || n_rows < 0 || world < 1) return -1;
+    API_TRY({
+        StructureGroups sg;
+        const OrderCost ids = exchange_cost(g_indptr, g_indices, n_rows, world);
+        if ((force || ids.halo_share > 0.5) && n_rows >= 4096) sg = structure_groups(g_indptr, g_indices, n_rows);
+        const NodeOrderChoice ch = choose_node_order(g_indptr, g_indices, n_rows, world, sg.useful ? sg.group.data() : nullptr, force != 0);
+        if (renumbered) *renumbered = ch.order.empty() ? 0 : 1;
+        if (order)
+            for (int k = 0; k < n_rows; k++) order[k] = ch.order.empty() ? k : ch.order[k];
+        if (ids_share) *ids_share = ch.ids.halo_share;
+        if (ids_recv_rows) *ids_recv_rows = ch.ids.recv_rows_max;
+        if (new_share) *new_share = ch.chosen.halo_share;
+        if (new_recv_rows) *new_recv_rows = ch.chosen.recv_rows_max;
+        if (allgather_rows) *allgather_rows = (int64_t)(world - 1) * ch.ids.rows_max;
+    })
+}
 
 int gcnhost_structure_groups(const int *g_indptr, const int *g_indices, int n_rows, int *group, int *n_groups, int *sweeps,
                              double *largest_share, int *useful) {

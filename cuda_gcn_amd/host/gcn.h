@@ -101,6 +101,10 @@ public:
     int local_rows() const { return n_local; }
     int row_start() const { return part.start[env.comm->rank()]; }
     const RowPartition &partition() const { return part; }
+    // multi-GPU: the model may renumber the nodes before it partitions them (partition.h, choose_node_order): row r of
+    // this rank is then node node_order()[row_start() + r] of the dataset it was given.  Empty: the ids were kept.
+    const std::vector<int> &node_order() const { return node_order_; }
+    const char *node_order_name() const { return node_order_name_; }
     const ExchangePlan &exchange_plan() const { return xplan; }
     // variable k as in gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z); rows x cols floats, this rank's rows
     void get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols);
@@ -115,6 +119,10 @@ public:
 
 private:
     GCNData *data;
+    std::unique_ptr<GCNData> renumbered;                       // the dataset in node_order_ (owned), when the ids were not kept
+    std::vector<int> node_order_;
+    const char *node_order_name_ = "ids";
+    void renumber_nodes(int world);
     HipEnv env;
     std::unique_ptr<Comm> owned_comm;
     std::unique_ptr<DeviceTimers> timers;

@@ -176,3 +176,97 @@ inline LocalGraph build_table_graph(const int *gp, const int *gi, int n_rows, co
     for (long e = 0; e < nnz; e++) lg.indices[e] = pos[gi[gp[r0] + e]];   // never -1: the plan covers every column of the block
     return lg;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rank blocks by STRUCTURE when the node ids carry no locality.  Rank blocks are contiguous ranges of the node order, so
+// which rows a rank must fetch depends on that order: R-MAT ids from the generator put the hubs first and give the other
+// blocks few distinct neighbours (38 % of the remote rows at 8 ranks), the same graph with shuffled ids needs far more.
+// An order is a permutation `order[new] = old`; the model is renumbered with it once, before anything is partitioned
+// (the model is permutation-invariant; only which element gets which dropout decision changes with the numbering).
+// Candidates, each a function of the graph alone (every rank computes the same):
+//   * descending degree — recovers the hub-first layout of a scale-free graph whatever its ids are;
+//   * group-major over groups found in the graph (cluster.h: modularity local moving), descending degree inside a group —
+//     for graphs made of communities.
+// exchange_cost() prices an order at `world` ranks by the rows the neediest rank receives per exchange (what a HALO plan
+// moves; an ALLGATHER plan moves (world - 1) * rows_max).
+struct OrderCost {
+    double halo_share = 1.0;       // max over ranks: needed remote rows / remote rows
+    long recv_rows_max = 0;        // ... needed remote rows of the neediest rank
+    long rows_max = 0;
+};
+
+// the CSR renumbered with order[new] = old (self loop first in every row, the other neighbours in their old order)
+inline void permute_csr(const int *gp, const int *gi, int n, const std::vector<int> &order, std::vector<int> &np_, std::vector<int> &ni_) {
+    std::vector<int> inv((size_t)n);
+    for (int k = 0; k < n; k++) inv[order[k]] = k;
+    np_.assign((size_t)n + 1, 0);
+    for (int k = 0; k < n; k++) np_[k + 1] = np_[k] + (gp[order[k] + 1] - gp[order[k]]);
+    ni_.resize((size_t)np_[n]);
+    for (int k = 0; k < n; k++) {
+        const int o = order[k];
+        int w = np_[k];
+        for (int e = gp[o]; e < gp[o + 1]; e++) ni_[w++] = inv[gi[e]];
+    }
+}
+
+inline OrderCost exchange_cost(const int *gp, const int *gi, int n, int world) {
+    OrderCost c;
+    const RowPartition part = make_partition(gp, n, world);
+    c.rows_max = part.rows_max;
+    std::vector<uint8_t> mark((size_t)n);
+    c.halo_share = 0.0;
+    for (int p = 0; p < world && world > 1; p++) {
+        std::fill(mark.begin(), mark.end(), 0);
+        const int a = part.start[p], b = part.start[p + 1];
+        for (long e = gp[a]; e < gp[b]; e++) mark[gi[e]] = 1;
+        long cnt = 0;
+        for (int j = 0; j < n; j++) cnt += mark[j] && (j < a || j >= b);
+        const long remote = (long)n - (b - a);
+        if (remote > 0) c.halo_share = std::max(c.halo_share, (double)cnt / (double)remote);
+        c.recv_rows_max = std::max(c.recv_rows_max, cnt);
+    }
+    return c;
+}
+
+inline std::vector<int> degree_order(const int *gp, int n, const int *group = nullptr) {
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (group && group[a] != group[b]) return group[a] < group[b];
+        return gp[a + 1] - gp[a] > gp[b + 1] - gp[b];
+    });
+    return order;
+}
+
+// The order to renumber with, or empty: keep the ids.  Tried only when the id order is expensive (its neediest rank reads
+// more than `try_above` of the remote rows); an alternative is kept when the neediest rank then receives at least
+// `gain` fewer rows per exchange than the cheaper of {halo list, padded all-gather} under the id order.
+struct NodeOrderChoice {
+    std::vector<int> order;        // empty: ids kept
+    const char *name = "ids";
+    OrderCost ids, chosen;
+};
+inline NodeOrderChoice choose_node_order(const int *gp, const int *gi, int n, int world, const int *group /* cluster.h, or NULL */,
+                                         bool force, double try_above = 0.5, double gain = 0.15) {
+    NodeOrderChoice out;
+    if (world < 2 || n < 2) return out;
+    out.ids = out.chosen = exchange_cost(gp, gi, n, world);
+    if (!force && out.ids.halo_share <= try_above) return out;
+    auto price = [&](const OrderCost &c) { return std::min(c.recv_rows_max, (long)(world - 1) * c.rows_max); };
+    long best = price(out.ids);
+    std::vector<int> np_, ni_;
+    for (int cand = 0; cand < 2; cand++) {
+        if (cand == 1 && !group) continue;
+        std::vector<int> order = degree_order(gp, n, cand == 1 ? group : nullptr);
+        permute_csr(gp, gi, n, order, np_, ni_);
+        const OrderCost c = exchange_cost(np_.data(), ni_.data(), n, world);
+        const bool better = price(c) < best && (force ? true : (double)price(c) <= (1.0 - gain) * (double)price(out.ids));
+        if (better || (force && out.order.empty())) {
+            best = price(c);
+            out.order = std::move(order);
+            out.name = cand == 1 ? "group-major (groups found in the graph), descending degree inside" : "descending degree";
+            out.chosen = c;
+        }
+    }
+    return out;
+}

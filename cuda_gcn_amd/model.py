@@ -98,6 +98,14 @@ class HipGCNModel:
         _ck(self.lib, self.lib.gcnhost_model_info(self.h, C.byref(r), C.byref(w), C.byref(s), C.byref(n), C.byref(e)), "info")
         return dict(rank=r.value, world=w.value, row_start=s.value, local_rows=n.value, local_edges=e.value)
 
+    def row_ids(self):
+        """(node of the caller's dataset for every local row of this rank, whether the model renumbered the nodes)"""
+        n = self.info()["local_rows"]
+        ids = np.zeros(n, np.int32)
+        ren = C.c_int()
+        _ck(self.lib, self.lib.gcnhost_model_row_ids(self.h, ids.ctypes.data, C.byref(ren)), "row_ids")
+        return ids, bool(ren.value)
+
     def exchange(self):
         h, t = C.c_int(), C.c_int()
         r, sn = C.c_int64(), C.c_int64()
@@ -235,6 +243,24 @@ def exchange_plan(g_indptr, g_indices, world, rank, mode=0):
                col_deg=arr(ptr[7], max(tr.value, 1)))
     lib.gcnhost_plan_free(h)
     return out
+
+
+def choose_node_order(g_indptr, g_indices, world, force=False):
+    """what a `world`-rank model does with the node ids of this graph (host only): dict(order, renumbered, ids_share, ids_recv_rows,
+    new_share, new_recv_rows, allgather_rows)"""
+    lib = _lib.gcnhost()
+    gp, gi = _i32(g_indptr), _i32(g_indices)
+    n = gp.size - 1
+    order = np.zeros(n, np.int32)
+    ren = C.c_int()
+    s0, s1 = C.c_double(), C.c_double()
+    r0, r1, ag = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib.gcnhost_choose_node_order(gp.ctypes.data, gi.ctypes.data, n, world, int(force), order.ctypes.data, C.byref(ren),
+                                       C.byref(s0), C.byref(r0), C.byref(s1), C.byref(r1), C.byref(ag))
+    if rc != 0:
+        raise GcnHostError("choose_node_order failed")
+    return dict(order=order, renumbered=bool(ren.value), ids_share=s0.value, ids_recv_rows=r0.value, new_share=s1.value,
+                new_recv_rows=r1.value, allgather_rows=ag.value)
 
 
 def glorot(size, in_size, out_size, seed, skip_draws=0):

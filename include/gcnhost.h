@@ -99,6 +99,10 @@ int gcnhost_model_exchange(gcnhost_model *m, int *halo, int64_t *recv_rows, int6
 int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, int *local_rows, int64_t *local_edges);
 /* the aggregation's row schedule this rank timed as fastest: 0 descending degree (also when not tuned), 1 label-major,
  * 2 degree rank dealt into n_groups groups, 3 group-major over n_groups groups found in the graph (modularity local moving) */
+/* Several GPUs: the model may renumber the nodes by structure before partitioning them (rank blocks are contiguous in the
+ * node order; HIPGCN_ID_PARTITION keeps the ids, HIPGCN_STRUCTURE_PARTITION forces the renumbering).  ids[r] (local_rows
+ * entries) = the node of the caller's dataset that local row r of this rank is; *renumbered = 0 when the ids were kept. */
+int gcnhost_model_row_ids(gcnhost_model *m, int *ids, int *renumbered);
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
 /* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
  * out == NULL: only report the shape. */
@@ -159,6 +163,11 @@ int gcnhost_host_masks(uint8_t *keep, int64_t n, float p, long seed, int64_t ski
  * are malloc'ed here; release them with gcnhost_free_array.  Deterministic in (scale, edge_factor, seed). */
 int gcnhost_rmat_graph(int scale, int edge_factor, uint64_t seed, int **indptr, int **indices, int64_t *nnz);
 void gcnhost_free_array(void *p);
+/* The node order a `world`-rank model would renumber the dataset with (host/partition.h, choose_node_order): order[new] =
+ * old (identity when the ids are kept), and the rows the neediest rank receives per exchange under the ids and under the
+ * chosen order, next to what the padded all-gather moves.  Host only. */
+int gcnhost_choose_node_order(const int *g_indptr, const int *g_indices, int n_rows, int world, int force, int *order, int *renumbered,
+                              double *ids_share, int64_t *ids_recv_rows, double *new_share, int64_t *new_recv_rows, int64_t *allgather_rows);
 /* Row groups for the aggregation's schedule found in the graph itself (Louvain local moving from singletons with a size
  * bound, asynchronous in a fixed node order, host/cluster.h): group[i] in 0 .. *n_groups-1, largest group first.  *useful == 0: the graph has no such
  * structure (everything collapsed into one group, or nothing merged) and HipGCN would not try the grouping.  What

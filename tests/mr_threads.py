@@ -60,8 +60,9 @@ def run_ranks(ds, world, flags, epochs, hidden, dropout, seed=4, run_async=False
             else:
                 tr = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
             test = m.eval(3)
+            ids, renumbered = m.row_ids()
             results[rank] = dict(trace=tr, test=np.array(test, np.float32), w1=m.var(2), h1=m.var(3), row_start=info["row_start"],
-                                 exchange=m.exchange())
+                                 exchange=m.exchange(), ids=ids, renumbered=renumbered)
             m.close()
         except BaseException as e:      # a failed rank must not leave the others at a barrier forever
             errors.append((rank, e))
@@ -75,7 +76,8 @@ def run_ranks(ds, world, flags, epochs, hidden, dropout, seed=4, run_async=False
     if errors:
         real = [e for e in errors if not isinstance(e[1], threading.BrokenBarrierError)] or errors
         raise RuntimeError(f"rank {real[0][0]} failed: {real[0][1]!r}")
-    order = sorted(range(world), key=lambda r: results[r]["row_start"])
-    return dict(trace=results[0]["trace"], test=results[0]["test"], w1=results[0]["w1"],
-                h1=np.concatenate([results[r]["h1"] for r in order], axis=0), exchange=results[0]["exchange"],
-                traces=[results[r]["trace"] for r in range(world)])
+    h1 = np.zeros((ds["num_nodes"], results[0]["h1"].shape[1]), np.float32)
+    for r in range(world):                                  # rows back in the caller's node numbering
+        h1[results[r]["ids"]] = results[r]["h1"]
+    return dict(trace=results[0]["trace"], test=results[0]["test"], w1=results[0]["w1"], h1=h1, exchange=results[0]["exchange"],
+                renumbered=results[0]["renumbered"], traces=[results[r]["trace"] for r in range(world)])

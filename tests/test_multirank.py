@@ -180,6 +180,44 @@ def test_overlap_exchange_vs_oracle_cora():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,dropout,flags", [(3, 0.0, 0), (4, 0.5, OVERLAP), (8, 0.5, 0)])
+def test_structure_partition_shuffled_communities(world, dropout, flags):
+    """a graph of communities with shuffled ids: the model renumbers the nodes by structure, the exchange becomes a halo
+    list, and the run equals the single-GPU run — of the given dataset at dropout 0 (the model is permutation-invariant), of
+    the renumbered dataset with dropout (which element gets which decision follows the numbering)"""
+    from cuda_gcn_amd import datagen
+    from cuda_gcn_amd.model import HipGCNModel, choose_node_order
+    from tests.mr_threads import run_ranks
+    ds = datagen.planted_communities()
+    epochs, hidden = 8, 16
+    got = run_ranks(ds, world, flags, epochs, hidden, dropout)
+    assert got["renumbered"] and got["exchange"]["mode"] == "halo", got["exchange"]
+    ref_ds = ds
+    if dropout > 0:
+        order = choose_node_order(ds["g_indptr"], ds["g_indices"], world)["order"]
+        inv = np.argsort(order).astype(np.int32)
+        gp, gi, F = ds["g_indptr"], ds["g_indices"], ds["input_dim"]
+        deg = np.diff(gp)
+        ngp = np.zeros(order.size + 1, np.int64)
+        ngp[1:] = np.cumsum(deg[order])
+        ngi = np.concatenate([inv[gi[gp[o]:gp[o + 1]]] for o in order]).astype(np.int32)
+        ref_ds = dict(ds, g_indptr=ngp.astype(np.int32), g_indices=ngi, f_val=ds["f_val"].reshape(-1, F)[order].reshape(-1),
+                      split=ds["split"][order], label=ds["label"][order])
+    m = HipGCNModel(ref_ds, seed=4, hidden_dim=hidden, dropout=dropout, epochs=epochs)
+    want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
+    h1 = m.var(3)
+    m.close()
+    assert np.abs(got["trace"][:, [0, 2]] - want[:, [0, 2]]).max() <= 2e-4, np.abs(got["trace"] - want).max(axis=0)
+    assert np.abs(got["trace"][:, [1, 3]] - want[:, [1, 3]]).max() <= 0.005
+    if dropout > 0:
+        h1_back = np.zeros_like(h1)
+        h1_back[order] = h1                                  # the reference ran on the renumbered dataset
+        h1 = h1_back
+    dh = np.abs(got["h1"] - h1)
+    assert np.median(dh) <= 1e-5 and np.quantile(dh, 0.999) <= 1e-3 * max(1.0, float(np.abs(h1).max())), (np.median(dh), dh.max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_round_trip_selftest_host_transport(world):
     """the halo part of gcnhost_rccl_selftest_world (synthetic plan, pack kernel, per-peer segments, every table row

@@ -102,3 +102,62 @@ def test_rmat_schedules_are_bit_identical(rmat):
     g.set_schedule(1, (np.arange(N) >> 12).astype(np.int32))
     assert np.array_equal(dev.graphsum(g, x, ld_in=48, ld_out=48), ref)
     g.set_schedule(2, None, 256)
+
+
+def test_rmat22_baseline_config4_itself(oracle):
+    """BASELINE.json configs[4] at its own size on one GPU: R-MAT scale 22 (4 194 304 nodes, avg degree 32), 256 features,
+    256 -> 128 -> 41.  (Its 8-GPU run needs 8 physical GPUs; everything that one GPU can check is checked here.)
+      * GraphSum d = 128 and d = 41 (ld 48), dealt-256: >= 1000 sampled rows against the oracle (hub rows' neighbours
+        included, int degree products defined), A^.1 = coefficient row sums over ALL rows, <y, A^x> = <A^y, x>;
+      * the whole model, device dropout RNG: three epochs (train + validation) — every loss finite, the training loss
+        falling, and two independently built models bit-identical in every number of the trace and in W1."""
+    from cuda_gcn_amd.ops import Device
+    from cuda_gcn_amd.model import HipGCNModel
+    scale = int(os.environ.get("RMAT_FULL_SCALE", "22"))
+    gp, gi = datagen.rmat_graph(scale)
+    N = gp.size - 1
+    assert N == 1 << scale
+    dev = Device(0)
+    g = dev.graph(gp, gi)
+    g.set_schedule(2, None, 256)
+    rng = np.random.default_rng(22)
+    rows, deg = _sample_rows(gp, gi, 1500, rng)
+    assert rows.size >= 1000 and deg[rows].max() > 1000
+    coef = g.coef().astype(np.float64)
+    rowsum = np.add.reduceat(coef, gp[:-1].astype(np.int64))
+    for dim, ld in ((128, 128), (41, 48)):
+        x = rng.standard_normal((N, dim), dtype=np.float32)
+        got = dev.graphsum(g, x, ld_in=ld, ld_out=ld)
+        want, overflowing = oracle.graphsum_rows(gp, gi, rows, x, dim)
+        assert overflowing == 0
+        mag, _ = oracle.graphsum_rows(gp, gi, rows, np.abs(x), dim)
+        viol = np.abs(got[rows].astype(np.float64) - want) - 8 * EPS * mag
+        assert viol.max() <= 0, f"d={dim}: max violation {viol.max():.3e}"
+        y = rng.standard_normal((N, dim), dtype=np.float32)
+        ay = dev.graphsum(g, y, ld_in=ld, ld_out=ld)
+        lhs = float(np.einsum("ij,ij->", y.astype(np.float64), got.astype(np.float64)))
+        rhs = float(np.einsum("ij,ij->", ay.astype(np.float64), x.astype(np.float64)))
+        sc = float(np.einsum("ij,ij->", np.abs(y).astype(np.float64), np.abs(got).astype(np.float64)))
+        assert abs(lhs - rhs) <= 1e-5 * sc, (dim, lhs, rhs, sc)
+        del x, y, got, ay
+    ones = dev.graphsum(g, np.ones((N, 4), np.float32))
+    assert np.abs(ones[:, 0] - rowsum).max() <= 16 * EPS * rowsum.max()
+    del ones, coef, rowsum
+    g.free()
+    dev.close()
+
+    ds = datagen.make_dataset(f"rmat-{scale}")
+    assert ds["input_dim"] == 256 and ds["output_dim"] == 41 and ds["num_nodes"] == N
+    traces, w1s = [], []
+    for _ in range(2):
+        m = HipGCNModel(ds, seed=11, hidden_dim=128, dropout=0.5, epochs=3)
+        assert m.schedule().startswith("dealt") or m.schedule() == "degree", m.schedule()
+        traces.append(m.run_epochs(3))
+        w1s.append(m.var(2))
+        m.close()
+    tr = traces[0]
+    assert np.isfinite(tr).all(), tr
+    assert tr[2, 0] < tr[0, 0], tr[:, 0]                    # training loss falls
+    assert 0.0 <= tr[:, 1].min() and tr[:, 3].max() <= 1.0
+    assert np.array_equal(traces[0], traces[1])             # no float atomics anywhere on the path
+    assert np.array_equal(w1s[0], w1s[1])

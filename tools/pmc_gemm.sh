@@ -19,12 +19,12 @@ dur = collections.defaultdict(list)
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "t128" not in k: continue
+        if "t128" not in k and "persist" not in k: continue
         agg[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(out + "/p1/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "t128" in k: dur[k.split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if "t128" in k or "persist" in k: dur[k.split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 res = {}
 for k, d in agg.items():
     e = {c: statistics.median(v) for c, v in d.items()}
@@ -34,5 +34,6 @@ for k, d in agg.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_BUSY_CU_CYCLES"):
         e["mfma_pipe_busy_share"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * e["SQ_BUSY_CU_CYCLES"])
     res[k] = e
+res["_meta"] = {"commit": __import__("os").environ.get("GCN_COMMIT"), "what": "tools/bench_gemm.py (reddit-syn shapes: 232965 x 602 x 128)", "counters": "median per launch; one rocprofv3 --pmc pass per counter group"}
 print(json.dumps(res, indent=1, sort_keys=True))
 PY

@@ -7,7 +7,10 @@ reference), without networkx / sklearn:
   * train = neither val nor test; split codes 1 train / 2 val / 3 test (:141-149);
   * nodes are renumbered 0..N-1 in sorted order of their ids (:102-105);
   * features are standardised with mean / std of the TRAIN rows only, std 0 -> 1 (:71-77);
-  * adjacency lists keep the graph's neighbour order; the loader adds the self loop.
+  * adjacency lists keep the graph's neighbour order (first occurrence of a duplicated link); the loader adds the
+    self loop in front; a self link in the data stays in the list (the reference's loader then counts it twice);
+Pinned: tests/golden/reddit_preprocess.npz holds what the reference script itself wrote for a 56-node fixture
+(tests/golden/make_reddit_golden.py ran it unmodified), and tests/test_host_cpu.py compares this converter with it.
 Output: <out>/<name>.gcnbin (binary cache, always) and, with --text, the three text files.
 Every feature row is written with all its columns (explicit zeros included), so the dense
 first-layer path is taken; sklearn's dump_svmlight_file would have dropped exact zeros.
@@ -48,14 +51,15 @@ def convert(src_dir, prefix):
     nbrs = [[] for _ in range(N)]
     for e in links:
         a, b = (node_ids[e["source"]], node_ids[e["target"]]) if by_pos else (e["source"], e["target"])
-        if a in new_id and b in new_id and a != b:
+        if a in new_id and b in new_id:
             nbrs[new_id[a]].append(new_id[b])
-            nbrs[new_id[b]].append(new_id[a])
+            if a != b:                                # a self link stays ONE entry of the node's own list, as networkx keeps it
+                nbrs[new_id[b]].append(new_id[a])     # (reddit_preprocess.py:122-125 then writes the node into its own line)
     indptr = np.zeros(N + 1, np.int64)
     rows = []
     for k in range(N):
-        seen, row = set(), [k]                        # self loop first, as the loader stores it
-        for j in nbrs[k]:
+        seen, row = set(), [k]                        # the loader's self loop first (parser.cpp:30-33); a self link in the
+        for j in nbrs[k]:                             # data follows as a neighbour of its own, exactly as the reference's file would
             if j not in seen:
                 seen.add(j); row.append(j)
         rows.append(row)
