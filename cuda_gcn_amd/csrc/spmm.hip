@@ -336,7 +336,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         // 32-row blocks, three-stage ring.  GCNHIP_GEMM_TILES keeps the tile kernels below for A/B runs.
         static const bool tiles_only = getenv("GCNHIP_GEMM_TILES") != nullptr;
         const int n_chunks = (t.K + PG_BK - 1) / PG_BK;
-        if (fast && p == 128 && !tiles_only && aligned16(t.x) && aligned16(out) &&
+        if (fast && p == 128 && !tiles_only && !c->corun && aligned16(t.x) && aligned16(out) &&
             (uint64_t)(t.m + PG_ROWS) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 4096 * sizeof(float) <= c->wpack_bytes) {
             pg_pack_w_kernel<<<ceil_div(n_chunks * 4 * 256, 256), 256, 0, c->stream>>>(w, ld_w, t.K, n_chunks * 4, c->wpack, t.bits ? t.scale : 1.f);
             GCNHIP_LAUNCH_CHECK();

@@ -570,6 +570,7 @@ void HipGCN::build_eval_lane() {
     lane.reset(new EvalLane());
     EvalLane &L = *lane;
     GCNHIP_CHECK(gcnhip_ctx_create(&L.env.ctx, /*device of the main context*/ device_, nullptr));
+    GCNHIP_CHECK(gcnhip_ctx_set_corun(L.env.ctx, 1));           // the lane's kernels share the chip with the training pass
     L.timers.reset(new DeviceTimers(L.env.ctx));
     L.timers->enabled = timers->enabled;
     L.env.timers = L.timers.get();

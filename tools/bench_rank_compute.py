@@ -4,7 +4,8 @@ rebuilt dH1, its own row schedule) but with no-op collectives (NULL_COMM), and K
 The slowest rank bounds the epoch from below; what a real run adds is the all-gathers' time that the
 validation lane does not hide.  Losses are meaningless here (gather buffers are never filled).
 
-    python tools/bench_rank_compute.py [dataset] [hidden] [P ...]
+    python tools/bench_rank_compute.py [dataset] [hidden] [P ...]        RANK_FLAGS=<int>: extra HipGCN flags, e.g. 1048576 =
+    HIPGCN_OVERLAP_EXCHANGE (the aggregations then run as two launches over the cut operators: what the cut itself costs)
 """
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +23,7 @@ def main():
     for P in worlds:
         per_rank = []
         for r in range(P):
-            flags = NO_EVAL_LANE | (NULL_COMM if P > 1 else 0) | (TIMERS if os.environ.get("RANK_TIMERS") else 0)
+            flags = NO_EVAL_LANE | (NULL_COMM if P > 1 else 0) | (TIMERS if os.environ.get("RANK_TIMERS") else 0) | int(os.environ.get("RANK_FLAGS", "0"))
             m = HipGCNModel(ds, seed=1, flags=flags, rank=r, world=P, hidden_dim=hidden, dropout=0.5, epochs=40)
             m.run_epochs(3, want_trace=False)
             m.sync()
