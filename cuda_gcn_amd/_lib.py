@@ -94,6 +94,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_rowset_size": (I, [P, C.POINTER(I)]),
     "gcnhip_graphsum_rowset": (I, [P, P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
+    "gcnhip_graphsum_relu_dropout_bits": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P, P, I]),
     "gcnhip_graphsum_part": (I, [P, P, P, P, I, P, I, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
     "gcnhip_feat_create_aggregated": (I, [P, C.POINTER(P), P, P]),
@@ -110,6 +111,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_matmul_fwd": (I, [P, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I]),
     "gcnhip_matmul_bwd_fused": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F]),
+    "gcnhip_matmul_bwd_fused_bits": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F, P, I]),
     "gcnhip_rowpack_create": (I, [P, C.POINTER(P), I, I]),
     "gcnhip_rowpack_destroy": (I, [P, P]),
     "gcnhip_rowpack_expand": (I, [P, P, P, I]),

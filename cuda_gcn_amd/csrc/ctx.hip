@@ -592,7 +592,8 @@ static int feat_aggregate_impl(gcnhip_ctx *c, gcnhip_feat *f, gcnhip_graph *g, c
     GCNHIP_TRY(hipMalloc((void **)&f->indptr, (size_t)(n + 1) * sizeof(int)));
     GCNHIP_TRY(hipMemcpy(f->indptr, ip.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice));
     GCNHIP_TRY(hipMalloc((void **)&f->values, (size_t)std::max<int64_t>(f->nnz, 4) * sizeof(float)));
-    GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (size_t)(f->nnz / 32 + 32) * sizeof(uint32_t)));
+    // no keep-bit array: an aggregated feature object serves evaluation forwards only (no dropout); a dropout call on it
+    // is refused in spmm.hip
     int rc = gcnhip_graph_reserve_width(c, g, F);
     if (rc != 0) return rc;
     const float *src = x->values_pad ? x->values_pad : x->values;

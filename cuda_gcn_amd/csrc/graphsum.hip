@@ -49,6 +49,9 @@ struct GsArgs {
     const uint8_t *keep_mask;
     const uint32_t *row_bits;   // optional: bit j == 0 -> row j of `in` is all zero and is not read
     const uint32_t *out_bits;   // optional: bit r == 0 -> nobody reads row r of `out`: it is not computed (left untouched)
+    uint32_t *pos_bits;         // optional (fuse, dim % 32 == 0, vector kernel): bit (c & 31) of pos_bits[r * wpr + (c >> 5)] =
+    int wpr;                    // (out[r, c] > 0) AFTER the ReLU/dropout epilogue — the mask their backward needs, so that it
+                                // does not have to read the activations again (gcnhip_matmul_bwd_fused_bits)
     int accumulate;             // 1: out[r,:] = out[r,:] + sum (the second of two operators that share the rows of `out`:
                                 // the remote-column part of a row-partitioned aggregation, gcnhip_graphsum_part)
 };
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+    uint32_t nib = 0;                                       // this lane's four (out > 0) bits, at their place in the row's word
     if (g == 0 && active) {
         if (slot >= 0) {
             *reinterpret_cast<float4 *>(a.partials + (size_t)slot * a.part_ld + col0) = acc;
@@ -214,7 +218,14 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
                 const float x[4] = {acc.x, acc.y, acc.z, acc.w};
                 for (int i = 0; col0 + i < a.dim; i++) o[i] = x[i];
             }
+            nib = ((acc.x > 0.f ? 1u : 0u) | (acc.y > 0.f ? 2u : 0u) | (acc.z > 0.f ? 4u : 0u) | (acc.w > 0.f ? 8u : 0u)) << (4 * (l & 7));
         }
+    }
+    if (L >= 8 && a.pos_bits && slot < 0) {                 // wave-uniform; dim % 32 == 0 (launch site): 8 lanes hold one word
+        nib |= __shfl_xor(nib, 1, WAVE);
+        nib |= __shfl_xor(nib, 2, WAVE);
+        nib |= __shfl_xor(nib, 4, WAVE);
+        if (g == 0 && active && (l & 7) == 0) a.pos_bits[(size_t)row * a.wpr + (col0 >> 5)] = nib;
     }
 }
 
@@ -634,19 +645,29 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
     const int4 sr = split_rows[s];
     const int row = sr.x, first = sr.y, ns = sr.z;
     if (!row_wanted(a, row)) return;
-    for (int col = threadIdx.x; col < a.dim; col += blockDim.x) {
-        float v = a.accumulate ? a.out[(size_t)row * a.ld_out + col] : 0.f;
-        for (int k = 0; k < ns; k++) v += a.partials[(size_t)(first + k) * a.part_ld + col];
-        if (a.fuse) {
-            v = v > 0.f ? v : 0.f;
-            if (a.training) {
-                const int64_t e = (int64_t)row * a.dim + col;
-                const bool keep = a.keep_mask ? a.keep_mask[e] != 0
-                                              : keep1(a.elem_offset + (uint64_t)e, a.d_epoch ? *a.d_epoch : 0u, a.seed, a.thr);
-                v *= keep ? a.scale : 0.f;
+    for (int c0 = 0; c0 < a.dim; c0 += blockDim.x) {        // whole waves stay in the loop: the ballot below needs them
+        const int col = c0 + threadIdx.x;
+        float v = 0.f;
+        if (col < a.dim) {
+            v = a.accumulate ? a.out[(size_t)row * a.ld_out + col] : 0.f;
+            for (int k = 0; k < ns; k++) v += a.partials[(size_t)(first + k) * a.part_ld + col];
+            if (a.fuse) {
+                v = v > 0.f ? v : 0.f;
+                if (a.training) {
+                    const int64_t e = (int64_t)row * a.dim + col;
+                    const bool keep = a.keep_mask ? a.keep_mask[e] != 0
+                                                  : keep1(a.elem_offset + (uint64_t)e, a.d_epoch ? *a.d_epoch : 0u, a.seed, a.thr);
+                    v *= keep ? a.scale : 0.f;
+                }
             }
+            a.out[(size_t)row * a.ld_out + col] = v;
         }
-        a.out[(size_t)row * a.ld_out + col] = v;
+        if (a.pos_bits) {                                   // 64 consecutive columns per wave: two words of the row
+            const uint64_t b = __ballot(col < a.dim && v > 0.f);
+            const int w0 = (c0 + (int)(threadIdx.x & ~63u)) >> 5;
+            if ((threadIdx.x & 63) == 0 && w0 < a.wpr) a.pos_bits[(size_t)row * a.wpr + w0] = (uint32_t)b;
+            if ((threadIdx.x & 63) == 32 && w0 + 1 < a.wpr) a.pos_bits[(size_t)row * a.wpr + w0 + 1] = (uint32_t)(b >> 32);
+        }
     }
 }
 
@@ -664,7 +685,7 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     // than a wave per task once the row loads are batched (1.15 vs 0.85 ms at Reddit scale): fresh waves arriving in
     // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
     static const bool pipe = getenv("GCNHIP_GS_PIPE") != nullptr;
-    if (pipe && a.n_tasks && !a.out_bits && !a.accumulate) {
+    if (pipe && a.n_tasks && !a.out_bits && !a.accumulate && !a.pos_bits) {
         const int per_xcd = std::min(max_blocks, 32 * 8);
         graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
         return;
@@ -694,7 +715,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
                          const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr,
-                         const gcnhip_rowset *rs = nullptr, int accumulate = 0) {
+                         const gcnhip_rowset *rs = nullptr, int accumulate = 0, uint32_t *pos_bits = nullptr, int wpr = 0) {
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (accumulate && in_bf) return -1;                     // the bf16 kernel has no accumulating store
     if (rs && rs->owner != g)                                // a subset brings task lists and segment slots of ITS adjacency object
@@ -722,8 +743,11 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.row_bits = row_bits;
     a.out_bits = out_bits;
     a.accumulate = accumulate;
+    a.pos_bits = pos_bits; a.wpr = wpr;
     const int nt = a.n_tasks ? a.n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
+    if (pos_bits && !(fuse && !in_bf && vec && dim % 32 == 0 && wpr * 32 >= dim))
+        return gcnhip_fail("gcnhip_graphsum_relu_dropout_bits: needs the fused epilogue, 16-byte aligned rows, dim % 32 == 0 and words_per_row * 32 >= dim");
     const int d4 = (dim + 3) / 4;
     a.n_slices = 1;
     if (in_bf) {
@@ -793,6 +817,16 @@ int gcnhip_graphsum_relu_dropout(gcnhip_ctx *c, const gcnhip_graph *g, const flo
                                  const uint8_t *keep_mask) {
     if (training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 1, training, p, seed, d_epoch, elem_offset, keep_mask);
+}
+
+int gcnhip_graphsum_relu_dropout_bits(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, int ld_in,
+                                      float *out, int ld_out, int dim, int training, float p,
+                                      uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
+                                      const uint8_t *keep_mask, uint32_t *pos_bits, int words_per_row) {
+    if (training && !(p >= 0.f && p < 1.f)) return -1;
+    if (!pos_bits) return -1;
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, 1, training, p, seed, d_epoch, elem_offset, keep_mask, nullptr, nullptr, nullptr,
+                         nullptr, 0, pos_bits, words_per_row);
 }
 
 int gcnhip_graphsum_part(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_rowset *rows, const float *in, int ld_in,

@@ -47,6 +47,22 @@ int gcnhip_matmul_bwd_fused(gcnhip_ctx *c, const float *a, int lda, const float 
     return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, da, ldda, db, lddb, m, n, p, 1, relu_dropout_scale);
 }
 
+// gcnhip_matmul_bwd_fused with the mask read from bits (written by gcnhip_graphsum_relu_dropout_bits) instead of from the
+// activations: db still needs a (= H1), da does not
+int gcnhip_matmul_bwd_fused_bits(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                                 const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                                 int m, int n, int p, float relu_dropout_scale, const uint32_t *pos_bits, int words_per_row) {
+    if (!c || !a || !b || !dc || !da || !pos_bits || m < 0 || n <= 0 || p <= 0 || lda < n || ldb < p || lddc < p || ldda < n) return -1;
+    if (db && lddb < p) return -1;
+    if (words_per_row * 32 < n) return -1;
+    if (m == 0) return matmul_bwd_impl(c, a, lda, b, ldb, dc, lddc, nullptr, 0, db, lddb, m, n, p, 0, 1.f);
+    if (db) {
+        const int rc = launch_atb(c, a, lda, dc, lddc, db, lddb, m, n, p, 0, 0.f, 0, nullptr, 0, nullptr);
+        if (rc) return rc;
+    }
+    return launch_rowstream(c, dc, lddc, b, ldb, 1, da, ldda, m, p, n, nullptr, 0, relu_dropout_scale, pos_bits, words_per_row);
+}
+
 // the same with da leaving as packed rows (dense_kernels.h): da_dense receives only the halves that do not fit a slot
 int gcnhip_matmul_bwd_packed(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
                              const float *dc, int lddc, float *da_dense, int ldda, gcnhip_rowpack *pack,

@@ -297,6 +297,7 @@ static DropSpec make_drop(float p_drop, uint64_t seed, const uint32_t *d_epoch, 
 
 // keep bits for the nnz stored elements of f (Philox or injected decisions)
 static int make_keep_bits(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d) {
+    if (!f->keep_bits) return gcnhip_fail("input dropout on a feature object without a keep-bit array (gcnhip_feat_create_aggregated builds evaluation-only objects)");
     const int64_t words = (f->nnz + 31) / 32;
     dropbits_kernel<<<ceil_div(words, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off, d.keep_mask);
     GCNHIP_LAUNCH_CHECK();
@@ -458,6 +459,7 @@ static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals
     int rps, S;
     if (!dense_bwd_plan(c, f, p, &rps, &S) || s0 < 0 || s1 > S || s0 > s1) return -1;
     if (s0 == s1) return 0;
+    if (d.on && !f->keep_bits) return gcnhip_fail("input dropout on a feature object without a keep-bit array");
     if (s0 == 0 && s1 == S) {                    // every split at once: the persistent form when the shape is its
         const int rc = dense_bwd_persist(c, f, vals, dout, ld_dout, p, d);
         if (rc <= 0) return rc;

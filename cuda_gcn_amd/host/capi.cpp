@@ -371,7 +371,7 @@ int gcnhost_choose_node_order(const int *g_indptr, const int *g_indices, int n_r
     API_TRY({
         StructureGroups sg;
         const OrderCost ids = exchange_cost(g_indptr, g_indices, n_rows, world);
-        if ((force || ids.halo_share > 0.5) && n_rows >= 4096) sg = structure_groups(g_indptr, g_indices, n_rows);
+        if ((force || ids.halo_share > 0.75) && n_rows >= 4096) sg = structure_groups(g_indptr, g_indices, n_rows);
         const NodeOrderChoice ch = choose_node_order(g_indptr, g_indices, n_rows, world, sg.useful ? sg.group.data() : nullptr, force != 0);
         if (renumbered) *renumbered = ch.order.empty() ? 0 : 1;
         if (order)

@@ -294,17 +294,17 @@ void HipGCN::init(const HipGCNOptions &opt) {
     GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
 }
 
-// Rank blocks are contiguous ranges of the node order.  When the order the dataset came in makes the exchange expensive
-// (the neediest rank would read more than half of the other ranks' rows) the graph is priced under orders derived from
-// its structure (partition.h) and, if one of them saves the neediest rank at least 15 % of its rows per exchange, the
-// dataset is renumbered once, here, before anything is built from it.  Every rank computes the same answer.
+// Rank blocks are contiguous ranges of the node order.  When the order the dataset came in forces the all-gather (the
+// neediest rank would read more than 75 % of the other ranks' rows) the graph is priced under orders derived from its
+// structure (partition.h); if one of them gets by with halo lists, the dataset is renumbered once, here, before anything
+// is built from it.  Every rank computes the same answer.
 void HipGCN::renumber_nodes(int world) {
     const int N = params.num_nodes;
     const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
     const bool force = (flags & HIPGCN_STRUCTURE_PARTITION) != 0;
     StructureGroups sg;
     const OrderCost ids = exchange_cost(gp.data(), gi.data(), N, world);
-    if ((force || ids.halo_share > 0.5) && N >= 4096) sg = structure_groups(gp.data(), gi.data(), N);
+    if ((force || ids.halo_share > 0.75) && N >= 4096) sg = structure_groups(gp.data(), gi.data(), N);
     NodeOrderChoice ch = choose_node_order(gp.data(), gi.data(), N, world, sg.useful ? sg.group.data() : nullptr, force);
     if (ch.order.empty()) return;
     if (env.comm->rank() == 0 && getenv("HIPGCN_VERBOSE"))
@@ -464,6 +464,14 @@ void HipGCN::build_modules() {
             GCNHIP_CHECK(gcnhip_rowpack_create(env.ctx, &dh1_pack, N, H));
             mm->da_pack = dh1_pack;
             gs->out_grad_pack = dh1_pack;
+        }
+        // single GPU: the ReLU/dropout mask of H1 leaves the aggregation's store epilogue as one bit per element and the
+        // Matmul backward reads those instead of H1 (-119 MB per epoch at Reddit scale); HIPGCN_NO_MASK_BITS: re-read H1
+        if (env.comm->size() == 1 && H % 32 == 0 && !env.bf16_tables && !dh1_pack && !getenv("HIPGCN_NO_MASK_BITS")) {
+            const int wpr = H / 32;
+            d_pos_bits = dev_upload(env.ctx, std::vector<uint32_t>((size_t)N * wpr, 0u).data(), (size_t)N * wpr);
+            gs->mask_bits_out = d_pos_bits;
+            mm->mask_bits = d_pos_bits; mm->mask_wpr = wpr;
         }
         if (rebuild_dh1) {
             const int wpr = (H + 31) / 32;

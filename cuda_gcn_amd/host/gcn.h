@@ -106,7 +106,12 @@ public:
     const std::vector<int> &node_order() const { return node_order_; }
     const char *node_order_name() const { return node_order_name_; }
     const ExchangePlan &exchange_plan() const { return xplan; }
-    // variable k as in gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z); rows x cols floats, this rank's rows
+    // variable k as in gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z); rows x cols floats, this rank's rows.
+    // PARTIAL-ROW CONTRACT of variable 6 (and 4 on an evaluation forward): by default the last aggregation of a forward
+    // computes only the rows of the split being scored — all the loss and the accuracy read (module.cpp:131-133,
+    // gcn.cpp:86-88) — so after train_epoch() only rows of the training split hold this epoch's logits, after eval(s)
+    // only rows of split s; the other rows keep whatever an earlier forward left (or the zeros of the allocation).  The
+    // reference fills every row on every forward: construct with HIPGCN_ALL_ROWS to get that.
     void get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols);
     void set_weights(const float *w1, const float *w2);       // [F x h], [h x C] row-major
     DeviceTimers &device_timers() { return *timers; }

@@ -40,6 +40,9 @@ void HipMatmul::backward() {
     } else if (fused_bwd_scale > 0.f && da_pack)
         GCNHIP_CHECK(gcnhip_matmul_bwd_packed(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                               a->grad, a->ld, da_pack, b->grad, b->ld, m, n, p, fused_bwd_scale));
+    else if (fused_bwd_scale > 0.f && mask_bits)
+        GCNHIP_CHECK(gcnhip_matmul_bwd_fused_bits(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
+                                                  a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale, mask_bits, mask_wpr));
     else if (fused_bwd_scale > 0.f)
         GCNHIP_CHECK(gcnhip_matmul_bwd_fused(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                              a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale));
@@ -150,6 +153,7 @@ void HipGraphSum::forward(bool training) {
     const gcnhip_rowset *out_rows = fwd_out_rows ? *fwd_out_rows : nullptr;
     const bool replicated = in->replicated && fwd_graph_replicated;
     if (replicated) graph = fwd_graph_replicated;
+    bool bits_written = false;
     if (env->bf16_tables) {
         // the table travels (and is gathered) as bfloat16: half the lines per edge, half the bytes per all-gather
         uint16_t *tab = table();
@@ -196,7 +200,17 @@ void HipGraphSum::forward(bool training) {
         const float *src = in->full ? in->full : in->data;
         env->timers->start(TMR_GRAPHSUM_FW);
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-        if (fused_relu_dropout >= 0.f)
+        // the mask of this layer's backward as bits, straight from the store epilogue: this GPU's own (single GPU), or this
+        // rank's block of the table every rank completes (several GPUs; saves the gcnhip_pack_positive pass below)
+        uint32_t *bits_here = nullptr;
+        if (training && fused_relu_dropout >= 0.f && dim % 32 == 0)
+            bits_here = mask_bits_out ? mask_bits_out : (pos_bits_full ? pos_bits_full + (size_t)env->plan->own_offset * wpr : nullptr);
+        if (bits_here) {
+            GCNHIP_CHECK(gcnhip_graphsum_relu_dropout_bits(env->ctx, graph, src, in->ld, out->data, out->ld, dim, 1,
+                                                           fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
+                                                           env->keep_hidden, bits_here, mask_bits_out ? (dim + 31) / 32 : wpr));
+            bits_written = true;
+        } else if (fused_relu_dropout >= 0.f)
             GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
                                                       fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
                                                       training ? env->keep_hidden : nullptr));
@@ -209,7 +223,7 @@ void HipGraphSum::forward(bool training) {
     }
     if (pos_bits_full && training) {
         uint32_t *mine = pos_bits_full + (size_t)env->plan->own_offset * wpr;
-        GCNHIP_CHECK(gcnhip_pack_positive(env->ctx, out->data, out->ld, out->rows, dim, mine, wpr));
+        if (!bits_written) GCNHIP_CHECK(gcnhip_pack_positive(env->ctx, out->data, out->ld, out->rows, dim, mine, wpr));
         if (env->xlane) {
             // nobody reads the other ranks' bits before the Matmul backward: the exchange stream delivers them meanwhile
             if (env->pos_bits_ready) env->xlane->wait(env->pos_bits_ready);        // (a forward whose backward never ran)

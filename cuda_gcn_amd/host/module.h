@@ -72,6 +72,10 @@ public:
     // single GPU, fused backward: da leaves as packed rows (gcnhip_matmul_bwd_packed); a->grad keeps only the halves
     // that do not fit a slot.  The consumer is the GraphSum that owns the same pack.
     gcnhip_rowpack *da_pack = nullptr;
+    // single GPU, fused backward: the ReLU/dropout mask as one bit per element, left by the producer of `a`
+    // (gcnhip_graphsum_relu_dropout_bits): da does not read `a` again
+    const uint32_t *mask_bits = nullptr;
+    int mask_wpr = 0;
     HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
 private:
     void rebuild_da(int first_row, int n_rows);     // da rows [first_row, first_row + n_rows) of the table from dc + mask bits
@@ -118,6 +122,8 @@ public:
     uint32_t *pos_bits_full = nullptr;
     int wpr = 0;
     bool out_grad_complete = false;
+    // single GPU: the same bits for this GPU's own backward (HipMatmul::mask_bits), written by the store epilogue
+    uint32_t *mask_bits_out = nullptr;
     // rows of out->grad known to be zero (bit = 0) are not gathered in backward(); NULL: none known
     const uint32_t *const *bwd_row_bits = nullptr;
     const gcnhip_graph *bwd_graph = nullptr;              // the operator without the edges that point at known-zero rows of out->grad

@@ -238,21 +238,24 @@ inline std::vector<int> degree_order(const int *gp, int n, const int *group = nu
     return order;
 }
 
-// The order to renumber with, or empty: keep the ids.  Tried only when the id order is expensive (its neediest rank reads
-// more than `try_above` of the remote rows); an alternative is kept when the neediest rank then receives at least
-// `gain` fewer rows per exchange than the cheaper of {halo list, padded all-gather} under the id order.
+// The order to renumber with, or empty: keep the ids.  Renumbering changes which element gets which dropout decision
+// (they are keyed by global element index), so a renumbered run is statistically, not numerically, the single-GPU run of
+// the given dataset (it IS numerically the single-GPU run of the renumbered dataset: tested).  It is therefore done only
+// where it changes the kind of exchange: the id order needs the all-gather (its neediest rank reads more than `plan_at`
+// of the remote rows) and the candidate order gets by with halo lists (share <= plan_at) that also move at least `gain`
+// fewer rows than the all-gather did.  HIPGCN_STRUCTURE_PARTITION forces the best candidate, HIPGCN_ID_PARTITION none.
 struct NodeOrderChoice {
     std::vector<int> order;        // empty: ids kept
     const char *name = "ids";
     OrderCost ids, chosen;
 };
 inline NodeOrderChoice choose_node_order(const int *gp, const int *gi, int n, int world, const int *group /* cluster.h, or NULL */,
-                                         bool force, double try_above = 0.5, double gain = 0.15) {
+                                         bool force, double plan_at = 0.75, double gain = 0.15) {
     NodeOrderChoice out;
     if (world < 2 || n < 2) return out;
     out.ids = out.chosen = exchange_cost(gp, gi, n, world);
-    if (!force && out.ids.halo_share <= try_above) return out;
-    auto price = [&](const OrderCost &c) { return std::min(c.recv_rows_max, (long)(world - 1) * c.rows_max); };
+    if (!force && out.ids.halo_share <= plan_at) return out;
+    auto price = [&](const OrderCost &c) { return c.halo_share <= plan_at ? c.recv_rows_max : (long)(world - 1) * c.rows_max; };
     long best = price(out.ids);
     std::vector<int> np_, ni_;
     for (int cand = 0; cand < 2; cand++) {
@@ -260,8 +263,9 @@ inline NodeOrderChoice choose_node_order(const int *gp, const int *gi, int n, in
         std::vector<int> order = degree_order(gp, n, cand == 1 ? group : nullptr);
         permute_csr(gp, gi, n, order, np_, ni_);
         const OrderCost c = exchange_cost(np_.data(), ni_.data(), n, world);
-        const bool better = price(c) < best && (force ? true : (double)price(c) <= (1.0 - gain) * (double)price(out.ids));
-        if (better || (force && out.order.empty())) {
+        const bool accept = force ? (out.order.empty() || price(c) < best)
+                                  : (c.halo_share <= plan_at && price(c) < best && (double)price(c) <= (1.0 - gain) * (double)price(out.ids));
+        if (accept) {
             best = price(c);
             out.order = std::move(order);
             out.name = cand == 1 ? "group-major (groups found in the graph), descending degree inside" : "descending degree";

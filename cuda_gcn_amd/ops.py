@@ -210,6 +210,35 @@ class Device:
                                                              seed, ep.ptr, elem_offset, km.ptr if km else None), "graphsum_relu_dropout")
         return out.download()[:, :dim]
 
+    def graphsum_relu_dropout_bits(self, g, x, training, p, seed=0, epoch=0, elem_offset=0, keep_mask=None, ld=None):
+        """-> (out, bits [n_rows x dim/32] uint32): gcnhip_graphsum_relu_dropout_bits"""
+        x = np.asarray(x, np.float32)
+        dim = x.shape[1]
+        ld = ld or dim
+        wpr = (dim + 31) // 32
+        xin = self.padded(x, ld)
+        out = self.buf(np.full((g.n_rows, ld), np.nan, np.float32))
+        bits = self.buf(np.full((g.n_rows, wpr), 0xDEADBEEF, np.uint32))
+        g.reserve(dim)
+        ep = self.buf(np.array([epoch], np.uint32))
+        km = self.buf(np.ascontiguousarray(keep_mask, np.uint8)) if keep_mask is not None else None
+        _ck(self.lib, self.lib.gcnhip_graphsum_relu_dropout_bits(self.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim, int(training), p, seed, ep.ptr,
+                                                                  elem_offset, km.ptr if km else None, bits.ptr, wpr), "graphsum_relu_dropout_bits")
+        return out.download()[:, :dim], bits.download()
+
+    def matmul_bwd_fused_bits(self, a, b, dc, scale, bits):
+        a, b, dc = (np.asarray(t, np.float32) for t in (a, b, dc))
+        m, n = a.shape
+        p = b.shape[1]
+        ldp = (p + 3) // 4 * 4
+        ab, bb, dcb = self.buf(a), self.padded(b, ldp), self.padded(dc, ldp)
+        bt = self.buf(np.ascontiguousarray(bits, np.uint32))
+        da = self.buf(np.full((m, n), np.nan, np.float32))
+        db = self.buf(np.full((n, ldp), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_matmul_bwd_fused_bits(self.ctx, ab.ptr, n, bb.ptr, ldp, dcb.ptr, ldp, da.ptr, n, db.ptr, ldp, m, n, p, scale,
+                                                             bt.ptr, bits.shape[1]), "gcnhip_matmul_bwd_fused_bits")
+        return da.download(), db.download()[:, :p]
+
     def spmm_fwd(self, f: "Feat", w, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, keep_mask=None, vals=None, ld_w=None, ld_out=None):
         w = np.asarray(w, np.float32)
         p = w.shape[1]

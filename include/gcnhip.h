@@ -181,6 +181,16 @@ int gcnhip_graphsum_relu_dropout(gcnhip_ctx *ctx, const gcnhip_graph *g, const f
                                  float *out, int ld_out, int dim, int training, float p,
                                  uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
                                  const uint8_t *keep_mask);
+/* The same, also leaving the mask its backward needs as ONE BIT per element: bit (c & 31) of
+ * pos_bits[r * words_per_row + (c >> 5)] = (out[r, c] > 0) after ReLU and dropout (the reference keeps a bool array for the
+ * ReLU and an int array for the Dropout, module.cpp:166-173, 196-205: 5 bytes per element).  The bits are assembled from
+ * the lanes that store the row, so they cost no extra pass; gcnhip_matmul_bwd_fused_bits reads them instead of re-reading
+ * the activations (119 MB per epoch at Reddit scale).  Needs dim % 32 == 0, 16-byte aligned rows and
+ * words_per_row * 32 >= dim; rows of a registered subset are not supported (the hidden layer computes every row). */
+int gcnhip_graphsum_relu_dropout_bits(gcnhip_ctx *ctx, const gcnhip_graph *g, const float *in, int ld_in,
+                                      float *out, int ld_out, int dim, int training, float p,
+                                      uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
+                                      const uint8_t *keep_mask, uint32_t *pos_bits, int words_per_row);
 
 /* ---- features (CUDASparseIndex of X + the input CUDAVariable) ----------------
  * CSR of X with n_rows rows and n_cols (= input_dim) columns.  A matrix whose
@@ -267,6 +277,10 @@ int gcnhip_matmul_bwd(gcnhip_ctx *ctx, const float *a, int lda, const float *b, 
 int gcnhip_matmul_bwd_fused(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
                             const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
                             int m, int n, int p, float relu_dropout_scale);
+/* ... with the mask taken from the bits gcnhip_graphsum_relu_dropout_bits left (same result bit for bit: the bit IS h > 0) */
+int gcnhip_matmul_bwd_fused_bits(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
+                                 const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                                 int m, int n, int p, float relu_dropout_scale, const uint32_t *pos_bits, int words_per_row);
 
 /* Packed dH1 (exact).  ReLU and dropout zero about three quarters of dH1 = mask . (dZ0 . W2^T), at positions known
  * from H1, and its only reader is the hidden layer's backward aggregation (module.cpp:103-119), which pays per

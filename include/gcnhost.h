@@ -106,6 +106,10 @@ int gcnhost_model_row_ids(gcnhost_model *m, int *ids, int *renumbered);
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
 /* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
  * out == NULL: only report the shape. */
+/* Variable k of the reference's list (gcn.cpp:21-54: 1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z), this rank's rows, row-major rows x cols
+ * (call with out == NULL for the shape).  Variable 6 holds CURRENT logits only for the rows of the split scored by the last
+ * forward (train_epoch: split 1; eval(s): split s) unless the model was built with GCNHOST flag ALL_ROWS (4096): the
+ * default path does not compute rows nobody reads; the reference fills every row. */
 int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *rows, int *cols);
 int gcnhost_model_set_weights(gcnhost_model *m, const float *w1, const float *w2);
 /* device-event timer `id` (host/timer.h, ids of src/common/timer.h:5-20 plus 13 Adam, 14 comm,

@@ -446,6 +446,33 @@ def test_graphsum_relu_dropout(dev, oracle, dim, ld):
     g.free()
 
 
+@pytest.mark.parametrize("dim", [32, 64, 128, 256])
+def test_graphsum_relu_dropout_bits_and_fused_bits_backward(dev, dim):
+    """the mask of the hidden layer's backward as one bit per element, written by the aggregation's store epilogue (split hub
+    rows included: they go through the segment-sum kernel): bits == (out > 0) exactly, `out` == the entry point without
+    bits, and the Matmul backward that reads the bits == the one that re-reads the activations, bit for bit"""
+    gp, gi = hub_graph(3000, 2600, 3)             # rows above the 1024-edge split length
+    n = gp.size - 1
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = dev.graph(gp, gi)
+    seed, epoch, off = 0xabcdef12345, 3, 128 * 7
+    for training in (True, False):
+        want = dev.graphsum_relu_dropout(g, x, training=training, p=0.5, seed=seed, epoch=epoch, elem_offset=off)
+        got, bits = dev.graphsum_relu_dropout_bits(g, x, training=training, p=0.5, seed=seed, epoch=epoch, elem_offset=off)
+        assert np.array_equal(got, want)
+        pos = (got > 0)
+        packed = np.packbits(pos.reshape(n, dim // 32, 32), axis=2, bitorder="little").view(np.uint32).reshape(n, dim // 32)
+        assert np.array_equal(bits, packed)
+        assert 0.1 < pos.mean() < 0.6
+    b = rng.standard_normal((dim, 41)).astype(np.float32)
+    dc = rng.standard_normal((n, 41)).astype(np.float32)
+    da0, db0 = dev.matmul_bwd(got, b, dc, ldb=44, lddc=44, fused_scale=2.0)
+    da1, db1 = dev.matmul_bwd_fused_bits(got, b, dc, 2.0, bits)
+    assert np.array_equal(da0, da1) and np.array_equal(db0, db1)
+    g.free()
+
+
 # ----------------------------------------------------------------- SparseMatmul
 @pytest.mark.parametrize("name", ["tiny-syn", "cora-syn"])
 @pytest.mark.parametrize("p", [16, 7, 128, 3])
