@@ -101,8 +101,16 @@ __device__ inline float4 relu_dropout4(float4 v, const GsArgs &a, int64_t r, int
 constexpr int GS_U = 4;        // row loads in flight per lane group when the table is cache resident (bf16 kernel: always)
 // One chunk of <= 64 edges whose (index, coef) pairs sit in the wave's lanes: acc += sum over the chunk, lane group g
 // taking edges g, g + G, ... in order (the order every form of the kernel keeps, so all of them agree bit for bit).
-template <int L, int GS_U>
+// NT: the row loads carry the non-temporal hint (the line is not to be kept in L2 / Infinity Cache at the expense of others)
+template <int L, int GS_U, bool NT = false>
 __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in, int my_idx, float my_c, int cnt, int g, float4 acc) {
+    auto ldrow = [&](const float *p) __attribute__((always_inline)) -> float4 {
+        if (NT) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
+        return *reinterpret_cast<const float4 *>(p);
+    };
     constexpr int G = WAVE / L;
     const int iters = (cnt + G - 1) / G;
     // GS_U row loads per lane group are in flight together whenever the next GS_U iterations are all real edges
@@ -120,7 +128,7 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
                 const int src = (k + u) * G + g;
                 const int j = __shfl(my_idx, src, WAVE);
                 cc[u] = __shfl(my_c, src, WAVE);
-                v[u] = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld_in);
+                v[u] = ldrow(in + (size_t)j * a.ld_in);
             }
 #pragma unroll
             for (int u = 0; u < GS_U; u++) acc = f4_fma(cc[u], v[u], acc);
@@ -139,7 +147,7 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
             const int j = __shfl(my_idx, src & 63, WAVE);
             cc[u] = __shfl(my_c, src & 63, WAVE);
             on[u] = src < cnt && cc[u] != 0.f;         // padded lanes and known-zero rows contribute nothing
-            v[u] = *reinterpret_cast<const float4 *>(in + (size_t)(on[u] ? j : j_safe) * a.ld_in);
+            v[u] = ldrow(in + (size_t)(on[u] ? j : j_safe) * a.ld_in);
         }
 #pragma unroll
         for (int u = 0; u < GS_U; u++) {
@@ -153,7 +161,7 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
 // L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
 // SLICED: the launch binds one column slice to each XCD group (it only changes the block -> (tasks, columns) mapping; the
 // flag is a template argument so that profiles name the hidden-width launches apart from the class-width ones).
-template <int L, int U = GS_U, bool SLICED = false>
+template <int L, int U = GS_U, bool SLICED = false, bool NT = false>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
             my_c = a.coef[base + lane];                    // > 0 for every real edge
             if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
         }
-        acc = gather_chunk<L, U>(a, in, my_idx, my_c, cnt, g, acc);
+        acc = gather_chunk<L, U, NT>(a, in, my_idx, my_c, cnt, g, acc);
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -696,6 +704,8 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     static const int force_u = getenv("GCNHIP_GS_U") ? atoi(getenv("GCNHIP_GS_U")) : 0;
     const int u = force_u ? force_u : (a.table_bytes > ((size_t)256 << 20) ? 2 : 4);
     const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
+    static const bool nt_all = getenv("GCNHIP_GS_NT") != nullptr;     // EXPERIMENT: every row load non-temporal
+    if (sliced && nt_all && L == 16) { graphsum_vec_kernel<16, 4, true, true><<<grid, 256, 0, s>>>(a); return; }
     if (sliced) {
         if (u >= 4) graphsum_vec_kernel<L, 4, true><<<grid, 256, 0, s>>>(a);
         else if (u >= 2) graphsum_vec_kernel<L, 2, true><<<grid, 256, 0, s>>>(a);
