@@ -658,7 +658,21 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
         float v = 0.f;
         if (col < a.dim) {
             v = a.accumulate ? a.out[(size_t)row * a.ld_out + col] : 0.f;
-            for (int k = 0; k < ns; k++) v += a.partials[(size_t)(first + k) * a.part_ld + col];
+            // four partials in flight per batch (unconditional loads from clamped slots; the same left-to-right sum)
+            const float *pp = a.partials + (size_t)first * a.part_ld + col;
+            int k = 0;
+            for (; k + 4 <= ns; k += 4) {
+                const float p0 = pp[(size_t)k * a.part_ld], p1 = pp[(size_t)(k + 1) * a.part_ld];
+                const float p2 = pp[(size_t)(k + 2) * a.part_ld], p3 = pp[(size_t)(k + 3) * a.part_ld];
+                v += p0; v += p1; v += p2; v += p3;
+            }
+            {
+                const float p0 = pp[(size_t)min(k, ns - 1) * a.part_ld], p1 = pp[(size_t)min(k + 1, ns - 1) * a.part_ld];
+                const float p2 = pp[(size_t)min(k + 2, ns - 1) * a.part_ld];
+                if (k < ns) v += p0;
+                if (k + 1 < ns) v += p1;
+                if (k + 2 < ns) v += p2;
+            }
             if (a.fuse) {
                 v = v > 0.f ? v : 0.f;
                 if (a.training) {
