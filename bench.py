@@ -76,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--bursts", type=int, default=4, help="extra repetitions of the K-step timed region (median/min/max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-regime leg and the structure-blind rerun")
+    ap.add_argument("--sustain", type=int, default=1500, help="epochs of the long back-to-back region of the extras (0: skip)")
     ap.add_argument("--hbm-scale", type=int, default=21, help="R-MAT scale of the HBM-regime leg (21: 1 GiB table at d=128)")
     ap.add_argument("--no-row-groups", action="store_true", help="plain descending-degree aggregation schedule (no label hint)")
     ap.add_argument("--bf16-tables", action="store_true",
@@ -371,7 +372,7 @@ def main():
     lane_flag = EVAL_LANE if lane_on else NO_EVAL_LANE
     overlap_on = args.overlap == "on" and world > 1
     base_flags = lane_flag | (BF16_TABLES if args.bf16_tables else 0) | (OVERLAP_EXCHANGE if overlap_on else 0)
-    n_epochs_total = args.warmup + args.steps * (2 + args.bursts) + 64
+    n_epochs_total = args.warmup + args.steps * (2 + args.bursts) + 64 + args.sustain
 
     def build(flags):
         t0 = time.perf_counter()
@@ -404,6 +405,13 @@ def main():
         burst_eps.append(args.steps / d)
     if rank == 0:
         log(f"timed: {args.steps / dt:.2f} epochs/s; bursts {['%.1f' % b for b in burst_eps]}")
+    # one long region on the same model (one GPU, extras on): seconds of back-to-back epochs, so that a sustained rate stands
+    # beside the K-step figure (clocks and temperatures settle; an external busy-sampler sees the card at work)
+    sustained = None
+    if world == 1 and not args.no_extras and args.sustain > 0:
+        d_s, _tr = timed_region(model, args.sustain)
+        sustained = {"epochs": args.sustain, "seconds": round(d_s, 3), "epochs_per_s": args.sustain / d_s}
+        log(f"sustained: {args.sustain / d_s:.2f} epochs/s over {args.sustain} epochs ({d_s:.1f} s)")
 
     # ---- separate pass, same process and model: per-op HIP-event timers on (the epoch then runs eagerly, one
     # event pair per op on the stream the op runs on; on one GPU everything runs on ONE stream in this pass, so a launch
@@ -525,6 +533,7 @@ def main():
                        "logit_rows": "all" if os.environ.get("HIPGCN_ALL_ROWS") else "rows of the scored split only"},
             "bursts": {"epochs_per_s": [round(b, 2) for b in burst_eps], "median": statistics.median(burst_eps), "min": min(burst_eps),
                        "max": max(burst_eps), "steps_each": args.steps},
+            "sustained": sustained,
             "roofline": roof,
             "breakdown_ms_per_epoch": breakdown, "timers_pass_ms_per_epoch": round(1e3 * dt_tm / n_tm, 4),
             "train_only_ms_per_epoch": round(train_only_ms, 4),

@@ -118,3 +118,42 @@ def test_c_abi_rejects_bad_arguments():
     assert np.allclose(dw.download(), n)                      # X^T . 1 with X = 1: every entry is the row count
     f.free(); g.free()
     dev.close()
+
+
+def test_wide_aggregation_on_split_rows_needs_reserve_width(oracle):
+    """an adjacency object with split (hub) rows sizes its segment scratch for 256 columns; a wider call is refused with a
+    message that names gcnhip_graph_reserve_width, works after the reservation, and a restricted child made
+    AFTER the reservation inherits the width"""
+    import ctypes as C
+    from cuda_gcn_amd.ops import Device, _ck
+    from tests.test_ops_gpu import hub_graph, close_mag
+    gp, gi = hub_graph(3000, 2600, 5)
+    n = gp.size - 1
+    dim = 320
+    dev = Device(0)
+    lib = dev.lib
+    g = dev.graph(gp, gi)
+    x = np.random.default_rng(1).standard_normal((n, dim)).astype(np.float32)
+    xin, out = dev.buf(x), dev.buf(np.zeros((n, dim), np.float32))
+    rc = lib.gcnhip_graphsum(dev.ctx, g.h, xin.ptr, dim, out.ptr, dim, dim)
+    assert rc == -1 and b"gcnhip_graph_reserve_width" in lib.gcnhip_last_error()
+    _ck(lib, lib.gcnhip_graph_reserve_width(dev.ctx, g.h, dim), "reserve_width")
+    _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, xin.ptr, dim, out.ptr, dim, dim), "graphsum")
+    want = oracle.graphsum(gp, gi, x, dim)
+    mag = oracle.graphsum(gp, gi, np.abs(x), dim)
+    close_mag(out.download(), want, mag)
+    # restricted child created after the reservation: same width
+    bits = np.full(n // 32 + 2, 0xFFFFFFFF, np.uint32)
+    child = C.c_void_p()
+    _ck(lib, lib.gcnhip_graph_create_restricted(dev.ctx, C.byref(child), g.h, bits.ctypes.data), "create_restricted")
+    out2 = dev.buf(np.zeros((n, dim), np.float32))
+    _ck(lib, lib.gcnhip_graphsum(dev.ctx, child, xin.ptr, dim, out2.ptr, dim, dim), "graphsum on the restricted object")
+    close_mag(out2.download(), want, mag)
+    # a subset registered on one object is refused on another
+    rs = C.c_void_p()
+    _ck(lib, lib.gcnhip_graph_add_rowset(dev.ctx, g.h, bits.ctypes.data, C.byref(rs)), "add_rowset")
+    rc = lib.gcnhip_graphsum_rowset(dev.ctx, child, rs, xin.ptr, dim, out2.ptr, dim, dim, None)
+    assert rc == -1 and b"another adjacency object" in lib.gcnhip_last_error()
+    lib.gcnhip_graph_destroy(dev.ctx, child)
+    g.free()
+    dev.close()
