@@ -67,6 +67,10 @@ struct gcnhip_graph {
     float *partials;    // [n_slots * part_ld]
     int part_ld;
     int n_slots;
+    // in-kernel segment sum (graphsum.hip): per segment slot {first slot of its row, number of segments}; per split row
+    // and column slice an arrival counter (index first_slot * 8 + slice), zero between launches
+    int2 *slot_info;    // [n_slots]
+    uint32_t *seg_count; // [n_slots * 8]
     // task ranges of equal edge count for 1, 2, 4 or 8 XCD groups: bounds[log2 G][g] .. bounds[log2 G][g+1]
     int bounds[4][9];
     int *tmp_col_deg;   // only during construction

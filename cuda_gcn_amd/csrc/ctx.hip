@@ -276,8 +276,19 @@ static int build_tasks(gcnhip_graph *g, const std::vector<int> &order) {
     // segment scratch for the widest aggregation this object will serve: sized HERE (and by
     // gcnhip_graph_reserve_width), never inside a launch path
     if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); g->partials = nullptr; }
+    if (g->slot_info) { GCNHIP_TRY(hipFree(g->slot_info)); g->slot_info = nullptr; }
+    if (g->seg_count) { GCNHIP_TRY(hipFree(g->seg_count)); g->seg_count = nullptr; }
     if (g->part_ld < 256) g->part_ld = 256;
-    if (n_slots) GCNHIP_TRY(hipMalloc((void **)&g->partials, (size_t)n_slots * g->part_ld * sizeof(float)));
+    if (n_slots) {
+        GCNHIP_TRY(hipMalloc((void **)&g->partials, (size_t)n_slots * g->part_ld * sizeof(float)));
+        std::vector<int2> info((size_t)n_slots);
+        for (const int4 &sr : srows)
+            for (int q = 0; q < sr.z; q++) info[(size_t)sr.y + q] = make_int2(sr.y, sr.z);
+        GCNHIP_TRY(hipMalloc((void **)&g->slot_info, (size_t)n_slots * sizeof(int2)));
+        GCNHIP_TRY(hipMemcpy(g->slot_info, info.data(), (size_t)n_slots * sizeof(int2), hipMemcpyHostToDevice));
+        GCNHIP_TRY(hipMalloc((void **)&g->seg_count, (size_t)n_slots * 8 * sizeof(uint32_t)));
+        GCNHIP_TRY(hipMemset(g->seg_count, 0, (size_t)n_slots * 8 * sizeof(uint32_t)));
+    }
     xcd_bounds(tasks, g->bounds);
     if (!g->h_tasks) g->h_tasks = new std::vector<int4>();
     if (!g->h_srows) g->h_srows = new std::vector<int4>();
@@ -432,6 +443,8 @@ int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
     if (g->tasks) hipFree(g->tasks);
     if (g->split_rows) hipFree(g->split_rows);
     if (g->partials) hipFree(g->partials);
+    if (g->slot_info) hipFree(g->slot_info);
+    if (g->seg_count) hipFree(g->seg_count);
     delete g;
     return 0;
 }

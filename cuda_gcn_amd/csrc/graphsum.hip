@@ -52,6 +52,11 @@ struct GsArgs {
     uint32_t *pos_bits;         // optional (fuse, dim % 32 == 0, vector kernel): bit (c & 31) of pos_bits[r * wpr + (c >> 5)] =
     int wpr;                    // (out[r, c] > 0) AFTER the ReLU/dropout epilogue — the mask their backward needs, so that it
                                 // does not have to read the activations again (gcnhip_matmul_bwd_fused_bits)
+    // in-kernel segment sum (vector kernel): the wave that finishes a split row's LAST outstanding segment adds the row's
+    // partials in segment order and runs the store epilogue itself — no second launch.  NULL: a finalize launch follows.
+    const int2 *slot_info;      // [slot] = {first slot of the row, segments of the row}
+    uint32_t *seg_count;        // [first_slot * 8 + column slice] arrivals; zero before and after every launch
+    int n_slots_bytes;          // size of `partials` in bytes (buffer descriptor of the write-through stores)
     int accumulate;             // 1: out[r,:] = out[r,:] + sum (the second of two operators that share the rows of `out`:
                                 // the remote-column part of a row-partitioned aggregation, gcnhip_graphsum_part)
 };
@@ -204,32 +209,72 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-    uint32_t nib = 0;                                       // this lane's four (out > 0) bits, at their place in the row's word
-    if (g == 0 && active) {
-        if (slot >= 0) {
-            *reinterpret_cast<float4 *>(a.partials + (size_t)slot * a.part_ld + col0) = acc;
-        } else {
-            float *o = a.out + (size_t)row * a.ld_out + col0;
-            if (a.accumulate) {                            // what the first operator left in this row, then this one's terms
-                if (col0 + 4 <= a.dim) {
-                    acc = f4_add(*reinterpret_cast<const float4 *>(o), acc);
-                } else {
-                    float x[4] = {acc.x, acc.y, acc.z, acc.w};
-                    for (int i = 0; col0 + i < a.dim; i++) x[i] = o[i] + x[i];
-                    acc = make_float4(x[0], x[1], x[2], x[3]);
-                }
+    if (slot >= 0 && !a.seg_count) {                        // a finalize launch will add the segments
+        if (g == 0 && active) *reinterpret_cast<float4 *>(a.partials + (size_t)slot * a.part_ld + col0) = acc;
+        return;
+    }
+    if (slot >= 0) {
+        // Hand-off between workgroups on any XCDs (cdna guide, Guideline 16): the partial leaves WRITE-THROUGH (sc1: no
+        // release fence, which would write back this XCD's whole dirty L2), the wave drains its stores, one lane takes a
+        // ticket; the wave that draws the last ticket invalidates its CU's L1 (agent-scope acquire) and reads every
+        // segment's partial — in segment order, so the row's sum has the bits the finalize kernel gives it.
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, a.n_slots_bytes, 0x00020000);
+        if (g == 0 && active) {
+            const v4u raw = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(raw, prsrc, (int)(((uint32_t)slot * (uint32_t)a.part_ld + (uint32_t)col0) * 4u), 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int2 info = a.slot_info[slot];
+        uint32_t *cnt = a.seg_count + (size_t)info.x * 8 + cslice;
+        unsigned prev = 0;
+        if (lane == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if ((int)prev != info.y - 1) return;                // other segments of this row are still on their way
+        if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g == 0 && active) {
+            if (a.accumulate) {                            // (what the first operator left) + p0 + p1 + ..., as the finalize kernel adds
+                const float *o = a.out + (size_t)row * a.ld_out + col0;
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 4 && col0 + i < a.dim; i++) x[i] = o[i];
+                acc = make_float4(x[0], x[1], x[2], x[3]);
             }
-            if (a.fuse) acc = relu_dropout4(acc, a, row, col0);
-            if (col0 + 4 <= a.dim) {
-                *reinterpret_cast<float4 *>(o) = acc;
-            } else {                                       // ragged tail: dim % 4 != 0
-                const float x[4] = {acc.x, acc.y, acc.z, acc.w};
-                for (int i = 0; col0 + i < a.dim; i++) o[i] = x[i];
+            const float *pp = a.partials + (size_t)info.x * a.part_ld + col0;
+            int k = 0;
+            for (; k + 4 <= info.y; k += 4) {               // four partials in flight; left-to-right sum
+                const float4 p0 = *reinterpret_cast<const float4 *>(pp + (size_t)k * a.part_ld);
+                const float4 p1 = *reinterpret_cast<const float4 *>(pp + (size_t)(k + 1) * a.part_ld);
+                const float4 p2 = *reinterpret_cast<const float4 *>(pp + (size_t)(k + 2) * a.part_ld);
+                const float4 p3 = *reinterpret_cast<const float4 *>(pp + (size_t)(k + 3) * a.part_ld);
+                acc = f4_add(acc, p0); acc = f4_add(acc, p1); acc = f4_add(acc, p2); acc = f4_add(acc, p3);
             }
-            nib = ((acc.x > 0.f ? 1u : 0u) | (acc.y > 0.f ? 2u : 0u) | (acc.z > 0.f ? 4u : 0u) | (acc.w > 0.f ? 8u : 0u)) << (4 * (l & 7));
+            for (; k < info.y; k++) acc = f4_add(acc, *reinterpret_cast<const float4 *>(pp + (size_t)k * a.part_ld));
         }
     }
-    if (L >= 8 && a.pos_bits && slot < 0) {                 // wave-uniform; dim % 32 == 0 (launch site): 8 lanes hold one word
+    uint32_t nib = 0;                                       // this lane's four (out > 0) bits, at their place in the row's word
+    if (g == 0 && active) {
+        float *o = a.out + (size_t)row * a.ld_out + col0;
+        if (a.accumulate && slot < 0) {                    // what the first operator left in this row, then this one's terms
+            if (col0 + 4 <= a.dim) {
+                acc = f4_add(*reinterpret_cast<const float4 *>(o), acc);
+            } else {
+                float x[4] = {acc.x, acc.y, acc.z, acc.w};
+                for (int i = 0; col0 + i < a.dim; i++) x[i] = o[i] + x[i];
+                acc = make_float4(x[0], x[1], x[2], x[3]);
+            }
+        }
+        if (a.fuse) acc = relu_dropout4(acc, a, row, col0);
+        if (col0 + 4 <= a.dim) {
+            *reinterpret_cast<float4 *>(o) = acc;
+        } else {                                           // ragged tail: dim % 4 != 0
+            const float x[4] = {acc.x, acc.y, acc.z, acc.w};
+            for (int i = 0; col0 + i < a.dim; i++) o[i] = x[i];
+        }
+        nib = ((acc.x > 0.f ? 1u : 0u) | (acc.y > 0.f ? 2u : 0u) | (acc.z > 0.f ? 4u : 0u) | (acc.w > 0.f ? 8u : 0u)) << (4 * (l & 7));
+    }
+    if (L >= 8 && a.pos_bits) {                             // wave-uniform; dim % 32 == 0 (launch site): 8 lanes hold one word
         nib |= __shfl_xor(nib, 1, WAVE);
         nib |= __shfl_xor(nib, 2, WAVE);
         nib |= __shfl_xor(nib, 4, WAVE);
@@ -694,10 +739,11 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
 }
 
 template <int L>
-static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
+static void launch_vec(GsArgs &a, const int (*xb)[9], hipStream_t s) {
     const int ychunks = ceil_div(a.dim, L * 4);
     const bool sliced = ychunks > 1 && 8 % ychunks == 0;   // XCD-sliced columns (1-D grid)
     a.n_slices = sliced ? ychunks : 1;
+    if (ychunks > 8) { a.seg_count = nullptr; a.slot_info = nullptr; }   // one arrival counter per (split row, column chunk), 8 per row
     const int G = 8 / a.n_slices;                          // XCD groups that share the task list
     const int lg = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
     int max_blocks = 1;
@@ -708,6 +754,7 @@ static void launch_vec(GsArgs a, const int (*xb)[9], hipStream_t s) {
     // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
     static const bool pipe = getenv("GCNHIP_GS_PIPE") != nullptr;
     if (pipe && a.n_tasks && !a.out_bits && !a.accumulate && !a.pos_bits) {
+        a.seg_count = nullptr; a.slot_info = nullptr;      // the experiment keeps the finalize launch
         const int per_xcd = std::min(max_blocks, 32 * 8);
         graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
         return;
@@ -768,6 +815,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.out_bits = out_bits;
     a.accumulate = accumulate;
     a.pos_bits = pos_bits; a.wpr = wpr;
+    a.slot_info = nullptr; a.seg_count = nullptr; a.n_slots_bytes = 0;
     const int nt = a.n_tasks ? a.n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
     if (pos_bits && !(fuse && !in_bf && vec && dim % 32 == 0 && wpr * 32 >= dim))
@@ -781,6 +829,15 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         else if (d8 <= 4) launch_bf16<4>(a, xb, c->stream);
         else if (d8 % 16 == 0) launch_bf16<16>(a, xb, c->stream);   // 128-column (two-line) slices as in the f32 kernel: 305 -> 322 epochs/s
         else launch_bf16<8>(a, xb, c->stream);               // 64-column (one line) slices, one per XCD group when 8 % slices == 0
+    }
+    // the vector kernel adds the segments of a split row itself (the last segment to finish does): no finalize launch.
+    // GCNHIP_GS_FINALIZE keeps the two-launch form (A/B runs, tests of the finalize kernel).
+    static const bool two_launches = getenv("GCNHIP_GS_FINALIZE") != nullptr;
+    if (!in_bf && vec && n_split_rows && g->seg_count && !two_launches) {
+        a.slot_info = g->slot_info; a.seg_count = g->seg_count;
+        a.n_slots_bytes = (int)std::min<size_t>((size_t)g->n_slots * g->part_ld * sizeof(float), 0x7FFFFFFFu);
+    }
+    if (in_bf) {
     } else if (vec && dim % 64 == 0 && 8 % (dim / 64) == 0) {
         // rows of whole 128-byte lines: 64-float (two-line) column slices, one per XCD group, so each XCD's L2 holds
         // 1/slices of the table and the (index, coef) stream is re-read only once per slice.  Measured at Reddit scale
@@ -805,7 +862,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         else launch_scalar<64>(a, nt, c->stream);
     }
     GCNHIP_LAUNCH_CHECK();
-    if (n_split_rows) {
+    if (n_split_rows && !a.seg_count) {
         graphsum_finalize_kernel<<<n_split_rows, 256, 0, c->stream>>>(a, split_rows, n_split_rows);
         GCNHIP_LAUNCH_CHECK();
     }

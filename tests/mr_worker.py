@@ -105,6 +105,16 @@ def main():
         local = A @ full
         want = Oracle().graphsum(gp, gi, x, dim)[r0:r1]
         assert np.allclose(local, want, rtol=1e-5, atol=1e-5), np.abs(local - want).max()
+        # the cut HIPGCN_OVERLAP_EXCHANGE makes: edges into this rank's own rows need nothing from the exchange, the rest does;
+        # the two parts add up to the whole
+        own = (ix >= rank * rows_max) & (ix < rank * rows_max + (r1 - r0))
+        A_own = sp.csr_matrix((np.where(own, coef, 0).astype(np.float32), ix, ip), shape=(r1 - r0, n_cols))
+        A_rest = sp.csr_matrix((np.where(own, 0, coef).astype(np.float32), ix, ip), shape=(r1 - r0, n_cols))
+        before_exchange = np.zeros_like(full)
+        before_exchange[rank * rows_max:rank * rows_max + (r1 - r0)] = x[r0:r1]
+        assert np.array_equal(A_own @ before_exchange, A_own @ full)              # the first part reads own rows only
+        assert np.allclose(A_own @ full + A_rest @ full, want, rtol=1e-5, atol=1e-5)
+        assert 0 < own.sum() < own.size or world == 1
         v = np.array([rank + 1.0, 10.0 * (rank + 1)], np.float64)
         ar(None, v.ctypes.data_as(C.POINTER(C.c_double)), 2)
         tot = world * (world + 1) / 2

@@ -157,3 +157,48 @@ def test_wide_aggregation_on_split_rows_needs_reserve_width(oracle):
     lib.gcnhip_graph_destroy(dev.ctx, child)
     g.free()
     dev.close()
+
+
+@pytest.mark.parametrize("dim", [128, 41, 256])
+def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
+    """split (hub) rows: the wave that finishes a row's last segment adds the partials itself (graphsum.hip, Guideline 16
+    hand-off).  Same bits as the graphsum_finalize launch (GCNHIP_GS_FINALIZE=1), launch after launch on CHANGING inputs —
+    a partial served from a stale cache line of the previous launch would show here — and with the ReLU+dropout+bits
+    epilogue on the same rows"""
+    import os
+    from cuda_gcn_amd.ops import Device, _ck
+    from tests.test_ops_gpu import close_mag
+    rng = np.random.default_rng(dim)
+    n = 6000
+    lo = np.concatenate([np.repeat(np.arange(4), [5200, 3100, 2049, 1025]), rng.integers(4, n, 9000)])
+    hi = np.concatenate([rng.choice(np.arange(4, n), 5200, False), rng.choice(np.arange(4, n), 3100, False),
+                         rng.choice(np.arange(4, n), 2049, False), rng.choice(np.arange(4, n), 1025, False), rng.integers(4, n, 9000)])
+    a, b = datagen._unique_undirected(lo, hi, n)
+    gp, gi = datagen.csr_with_self_loops(a, b, n)
+    dev = Device(0)
+    lib = dev.lib
+    g = dev.graph(gp, gi)
+    ld = (dim + 15) // 16 * 16
+    xin, out = dev.buf(np.zeros((n, ld), np.float32)), dev.buf(np.zeros((n, ld), np.float32))
+    os.environ.pop("GCNHIP_GS_FINALIZE", None)
+    try:
+        for it in range(6):
+            x = np.zeros((n, ld), np.float32)
+            x[:, :dim] = rng.standard_normal((n, dim)).astype(np.float32)
+            xin.upload(x)
+            got = []
+            for two_launch in (False, True, False):
+                if two_launch:
+                    os.environ["GCNHIP_GS_FINALIZE"] = "1"
+                else:
+                    os.environ.pop("GCNHIP_GS_FINALIZE", None)
+                out.upload(np.full((n, ld), 7.0, np.float32))
+                _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim), "graphsum")
+                got.append(out.download()[:, :dim].copy())
+            assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+            if it == 0:
+                close_mag(got[0], oracle.graphsum(gp, gi, x[:, :dim].copy(), dim), oracle.graphsum(gp, gi, np.abs(x[:, :dim]).copy(), dim))
+    finally:
+        os.environ.pop("GCNHIP_GS_FINALIZE", None)
+    g.free()
+    dev.close()
