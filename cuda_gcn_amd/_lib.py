@@ -139,6 +139,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_adam_step": (I, [P, C.POINTER(AdamVar), I, F, P, P, F, F, F, F, P]),
     "gcnhip_counter_add": (I, [P, P, C.c_uint32]),
     "gcnhip_metrics_record": (I, [P, P, I, I, P, P, P, P]),
+    "gcnhip_metrics_record_with_next_loss": (I, [P, P, I, I, P, P]),
     "gcnhip_capture_begin": (I, [P]),
     "gcnhip_capture_end": (I, [P, C.POINTER(P)]),
     "gcnhip_graph_launch": (I, [P, P]),

@@ -28,7 +28,10 @@ struct gcnhip_ctx {
     // scratch for block-level partial reductions (xent, sumsq, adam sumsq)
     float *red_f;       // [RED_SLOTS * 4]
     int32_t *red_i;     // [RED_SLOTS * 4]
-    uint32_t *ticket;   // arrival counters for last-block reductions
+    uint32_t *ticket;   // arrival counters for last-block reductions: [0] the loss kernels, [1] Adam's sum of squares; zero between launches
+    // gcnhip_metrics_record_with_next_loss: the next loss launch on this context writes the ring row itself
+    bool rec_armed = false;
+    float *rec_ring = nullptr; int rec_capacity = 0, rec_slot = 0; const uint32_t *rec_epoch = nullptr; const float *rec_sumsq = nullptr;
     // split-K slabs for the dense weight-gradient GEMMs
     float *slab;
     size_t slab_bytes;

@@ -59,10 +59,18 @@ __device__ inline uint64_t spread4(uint32_t x) {
 // KCH > 0: the K extent is KCH chunks of 16 (K <= 128) and a wave issues all of its KCH
 // 16-byte loads of a row tile before the first MFMA (KCH KiB in flight per wave instead of
 // one dependent load per chunk).  KCH == 0: generic loop for longer K.
-template <int NT, bool VEC, bool FUSE, int KCH, bool PACK = false>
+// BITS (SW kernels with a mask): the mask comes from a.hbits, not from a.H — a template argument so that only one of the
+// two prefetch register sets exists in a kernel.
+template <int NT, bool VEC, bool FUSE, int KCH, bool PACK = false, bool BITS = false>
 __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float Bs[];
     constexpr int NCLD = NT * 16 + 4;        // +4: the four k-groups of a wave hit disjoint banks
+    // SW (round 3): the two MFMA operands change places, so the instruction computes the TRANSPOSED 16x16 tile — the same
+    // products added in the same k order, bit for bit — and a lane ends up with 4 consecutive COLUMNS of one row
+    // (D[4*(lane>>4)+reg][lane&15] is now [column][row]) instead of one column of 4 rows.  Rows then leave as 16-byte lane
+    // stores and the mask arrives as 16-byte loads / one bit word straight from the accumulators: the LDS staging of the
+    // result, its two wave barriers and 34 of dA's 59 KB of LDS are gone (2 -> 4 workgroups per CU).
+    constexpr bool SW = VEC && !PACK;
     const int Kp = (a.K + 15) / 16 * 16;
     const int c_base = blockIdx.y * NT * 16;
     // The small operand into LDS, 8 elements per thread in flight: unconditional loads from clamped addresses (element 0
@@ -107,21 +115,52 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
             for (int s = 0; s < 4; s++) if (kk + s >= a.K) av[s] = 0.f;   // pad columns may hold anything
         }
     };
+    constexpr int NW = (NT + 1) / 2;                          // 32-column mask words per row of this column block
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        // Bs is loop-invariant and, without the staged epilogue, nothing in the loop writes LDS: left alone the compiler
+        // keeps the WHOLE operand in registers (96 per lane; 226 VGPRs, one or two waves per SIMD) — measured slower
+        // (H1.W2 38 -> 53 us, dA+dW2 125 -> 150 us): this kernel lives on waves in flight.  Re-read it per tile.
+        asm volatile("" ::: "memory");
         const int row = tile * 16 + li;
         const bool valid = row < a.m;
         const float *ap = a.A + (size_t)row * a.lda;
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // SW + mask: the row's mask words (or its H quads) are requested HERE, from clamped addresses and without a
+        // branch, so they travel beside the A loads and under the MFMAs.  As loads inside the store loop they were NT
+        // dependent round trips per tile (load, wait, store, next column block).
+        uint32_t kbw[BITS ? NW : 1];
+        float4 hq[BITS ? 1 : NT];
+        if constexpr (SW && FUSE) {
+            const size_t rc = (size_t)min(row, a.m - 1);
+            if constexpr (BITS) {                              // c_base % 32 == 0 (NT is even whenever there is a second block)
+                const uint32_t *hb = a.hbits + rc * a.wpr;
+#pragma unroll
+                for (int j = 0; j < NW; j++) {
+                    const int w = (c_base >> 5) + j;
+                    kbw[j] = hb[w < a.wpr ? w : 0];
+                }
+            } else if (a.vec_out) {
+                const float *hrow = a.H + rc * a.ldh;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int col = c_base + t * 16 + 4 * kq;
+                    hq[t] = *reinterpret_cast<const float4 *>(hrow + (col + 4 <= a.Nc ? col : 0));
+                }
+            }
+        }
         if (KCH > 0) {
             float av[KCH > 0 ? KCH : 1][4];
             if (VEC && a.lda >= KCH * 16) {
                 // Every float4 of the K extent lies inside the row's allocation (wave-uniform test): the KCH loads are
                 // issued UNCONDITIONALLY from a clamped row — a load inside a per-lane branch is waited for at the end
                 // of that branch, which kept ONE load in flight per wave here until round 2 (the same disease as
-                // GraphSum's; H1.W2 at Reddit scale: 55 -> 42 us with the K = 128 case batched).  Rows past m compute on a copy of the last row and are never stored;
-                // columns past K (row padding) are zeroed by selects.
+                // GraphSum's; H1.W2 at Reddit scale: 55 -> 42 us with the K = 128 case batched).  Rows
+                // past m compute on a copy of the last row and are never stored; columns past K are zeroed by selects.
+                // (Round 3, measured and dropped: issuing the NEXT tile's loads before this tile's MFMAs.  The extra
+                // registers cost a wave per SIMD and the launch got slower, 38 -> 45 us: waves in flight hide the
+                // round trip better than a wave's own prefetch.)
                 const float *apc = a.A + (size_t)min(row, a.m - 1) * a.lda + 4 * kq;
                 float4 raw[KCH > 0 ? KCH : 1];
 #pragma unroll
@@ -144,9 +183,11 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
                         const float b = Bs[(kk + s) * NCLD + t * 16 + li];
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][s], b, acc[t], 0, 0, 0);
+                        acc[t] = SW ? __builtin_amdgcn_mfma_f32_16x16x4f32(b, av[c][s], acc[t], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][s], b, acc[t], 0, 0, 0);
                     }
                 }
+                if (SW) __builtin_amdgcn_sched_barrier(0);      // one chunk's 4*NT LDS reads in flight, not all KCH*4*NT of them
             }
         } else {
             for (int k0 = 0; k0 < Kp; k0 += 16) {
@@ -158,12 +199,44 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
                         const float b = Bs[(kk + s) * NCLD + t * 16 + li];
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b, acc[t], 0, 0, 0);
+                        acc[t] = SW ? __builtin_amdgcn_mfma_f32_16x16x4f32(b, av[s], acc[t], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b, acc[t], 0, 0, 0);
                     }
                 }
             }
         }
-        if (a.vec_out) {
+        if constexpr (SW) {
+            const int r = tile * 16 + li;
+            if (r < a.m) {
+                float *crow = a.C + (size_t)r * a.ldc;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int col = c_base + t * 16 + 4 * kq;
+                    if (col >= a.Nc) continue;
+                    float x[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                    if constexpr (FUSE && BITS) {             // col % 4 == 0: the quad's four bits sit in one word
+                        const uint32_t kb = kbw[t >> 1] >> ((t & 1) * 16 + 4 * kq);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) x[q] = ((kb >> q) & 1u) ? x[q] * a.scale : 0.f;
+                    }
+                    if (a.vec_out && col + 4 <= a.Nc) {
+                        if constexpr (FUSE && !BITS) {
+                            x[0] = hq[t].x > 0.f ? x[0] * a.scale : 0.f; x[1] = hq[t].y > 0.f ? x[1] * a.scale : 0.f;
+                            x[2] = hq[t].z > 0.f ? x[2] * a.scale : 0.f; x[3] = hq[t].w > 0.f ? x[3] * a.scale : 0.f;
+                        }
+                        *reinterpret_cast<float4 *>(crow + col) = make_float4(x[0], x[1], x[2], x[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {           // fully unrolled: x[] stays in registers
+                            if (col + q >= a.Nc) continue;
+                            float y = x[q];
+                            if constexpr (FUSE && !BITS) y = a.H[(size_t)r * a.ldh + col + q] > 0.f ? y * a.scale : 0.f;
+                            crow[col + q] = y;
+                        }
+                    }
+                }
+            }
+        } else if (a.vec_out) {
             // Stage the 16 x (NT*16) result through LDS so rows leave as whole 16-byte lane
             // stores (and the mask operand H arrives as 16-byte loads): a lane owns 4
             // consecutive columns of one row instead of 1 column of 4 rows.
@@ -560,22 +633,29 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
     a.pack_slots = pack_slots; a.pack_halves = pack_halves;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.transB = transB; a.C = C; a.ldc = ldc;
     a.m = m; a.K = K; a.Nc = Nc; a.H = H; a.ldh = ldh; a.scale = scale;
-    a.vec_out = (Nc >= 64 && ldc % 4 == 0 && aligned16(C) && (!H || hbits || (ldh % 4 == 0 && aligned16(H)))) ? 1 : 0;
     const bool vec = lda % 4 == 0 && aligned16(A);
+    // 16-byte stores of whole column quads (the ragged tail of Nc % 4 != 0 goes out as single floats; padding columns are
+    // never written).  The packed-row experiment keeps the LDS-staged epilogue, which wants whole 64-column halves.
+    a.vec_out = ((pack_slots ? Nc >= 64 : true) && ldc % 4 == 0 && aligned16(C) && (!H || hbits || (ldh % 4 == 0 && aligned16(H)))) ? 1 : 0;
+    if (!vec && !pack_slots) a.vec_out = a.vec_out && Nc >= 64;    // the unaligned-A kernels: staged epilogue as before
     if (pack_slots && !(a.vec_out && vec && (H || hbits) && Nc % 64 == 0 && pack_halves * 64 == Nc)) return -1;
     const int nt_total = ceil_div(Nc, 16);
     const int NT = nt_total >= 8 ? 8 : (nt_total > 4 ? 8 : (nt_total > 3 ? 4 : nt_total));
     const int gy = ceil_div(nt_total, NT);
     const int Kp = (K + 15) / 16 * 16;
-    const size_t lds = ((size_t)Kp * (NT * 16 + 4) + (a.vec_out ? 4 * 16 * (NT * 16 + 4) : 0)) * sizeof(float);   // Bs (+ 4 waves' C staging)
+    const bool staged = a.vec_out && (pack_slots || !vec);     // only those epilogues go through LDS
+    const size_t lds = ((size_t)Kp * (NT * 16 + 4) + (staged ? 4 * 16 * (NT * 16 + 4) : 0)) * sizeof(float);   // Bs (+ 4 waves' C staging)
     if (lds > 156 * 1024) return -1;          // K too long for an LDS-resident operand (gfx950: 160 KiB per CU)
     int gx = ceil_div(ceil_div(m, 16), 4);
-    const int cap = c->n_cu * (lds > 76 * 1024 ? 1 : (lds > 32 * 1024 ? 2 : 4));
+    int per_cu = lds > 76 * 1024 ? 1 : (lds > 32 * 1024 ? 2 : 4);
+    if (const char *e = getenv("GCNHIP_RS_WGS")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // experiment: persistent workgroups per CU
+    const int cap = c->n_cu * per_cu;
     if (gx > cap) gx = cap;
     dim3 grid(gx, gy);
 #define RS2(NT_, V_, F_, K_)                                                                              \
     do {                                                                                                  \
-        auto kern = gemm_rowstream_kernel<NT_, V_, F_, K_>;                                               \
+        auto kern = (V_ && F_ && hbits) ? gemm_rowstream_kernel<NT_, V_, F_, K_, false, (V_ && F_)>       \
+                                        : gemm_rowstream_kernel<NT_, V_, F_, K_>;                         \
         if (lds > 64 * 1024)                                                                              \
             GCNHIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<grid, 256, lds, c->stream>>>(a);                                                           \

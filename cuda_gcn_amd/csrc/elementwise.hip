@@ -5,6 +5,7 @@
 // per-block partials summed in block order by a one-block kernel, so every
 // result is bitwise reproducible (no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 static inline int stream_grid(int64_t n_items, int per_block) {
     int64_t b = (n_items + per_block - 1) / per_block;
@@ -128,6 +129,8 @@ struct AdamArgs {
     const float *d_step_sizes;
     const uint32_t *d_epoch;
     float *partial;             // per-block sum of w0^2 after the update (or NULL)
+    uint32_t *ticket;           // with `partial`: the block that arrives last adds the partials (NULL: sum_partials_kernel follows)
+    float *sumsq_out;
 };
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ float sh[4];
@@ -156,7 +159,27 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
     if (a.partial) {
         const float s = block_sum(sq, sh);
-        if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+        if (!a.ticket) {
+            if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+            return;
+        }
+        // last-block sum in this launch (same hand-off as xent_block_tail, xent.hip): agent-scope store of the partial,
+        // drain, ticket; the last block adds the partials as sum_partials_kernel does (256 threads striding the list,
+        // block_sum) — same bits, one launch fewer per epoch
+        __shared__ int sh_last;
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_last = prev == gridDim.x - 1;
+            if (sh_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!sh_last) return;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float tot = block_sum(acc, sh);
+        if (threadIdx.x == 0) *a.sumsq_out = tot;
     }
 }
 
@@ -302,9 +325,12 @@ int gcnhip_adam_step(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, flo
     int blocks = stream_grid(a.start[n_vars], 1024);
     if (blocks > 1024) blocks = 1024;
     a.partial = d_sumsq ? c->red_f + 1024 : nullptr;       // second quarter of the scratch
+    const bool two_launches = getenv("GCNHIP_ADAM_SUM_LAUNCH") != nullptr;      // A/B aid, tests
+    a.ticket = (d_sumsq && !two_launches) ? c->ticket + 1 : nullptr;
+    a.sumsq_out = d_sumsq;
     adam_kernel<<<blocks, 256, 0, c->stream>>>(a);
     GCNHIP_LAUNCH_CHECK();
-    if (d_sumsq) {
+    if (d_sumsq && !a.ticket) {
         sum_partials_kernel<<<1, 256, 0, c->stream>>>(a.partial, blocks, d_sumsq);
         GCNHIP_LAUNCH_CHECK();
     }
@@ -314,6 +340,13 @@ int gcnhip_counter_add(gcnhip_ctx *c, uint32_t *d_counter, uint32_t inc) {
     if (!c || !d_counter) return -1;
     counter_add_kernel<<<1, 1, 0, c->stream>>>(d_counter, inc);
     GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+int gcnhip_metrics_record_with_next_loss(gcnhip_ctx *c, float *d_ring, int capacity, int slot_in_row,
+                                         const uint32_t *d_epoch, const float *d_sumsq) {
+    if (!c || !d_ring || capacity <= 0 || slot_in_row < 0 || slot_in_row > 3) return -1;
+    c->rec_armed = true;
+    c->rec_ring = d_ring; c->rec_capacity = capacity; c->rec_slot = slot_in_row; c->rec_epoch = d_epoch; c->rec_sumsq = d_sumsq;
     return 0;
 }
 int gcnhip_metrics_record(gcnhip_ctx *c, float *d_ring, int capacity, int slot_in_row,

@@ -19,6 +19,12 @@ struct XentArgs {
     const int32_t *rows;       // optional: only these rows (all labelled) are visited, n_rows = their number
     float *part_f;             // [blocks] loss partials
     int32_t *part_i;           // [blocks*2] {correct, total}
+    // in-launch final reduction (xent_block_tail): the block that arrives last at `ticket` adds the partials in block order
+    uint32_t *ticket;          // NULL: xent_finalize_kernel follows
+    float *res;                // d_result[4] or NULL
+    int32_t *res_i;            // d_result_i[2] or NULL
+    // optional: what gcnhip_metrics_record would copy afterwards (gcnhip_metrics_record_with_next_loss)
+    float *ring; int ring_capacity, ring_slot; const uint32_t *ring_epoch; const float *ring_sumsq;
 };
 
 __device__ inline float wave_max(float v) {
@@ -28,6 +34,57 @@ __device__ inline float wave_max(float v) {
 }
 
 constexpr int XENT_MAXC_REG = 4;     // up to 256 classes held in registers
+
+// The end of both loss kernels.  Thread 0 holds the block's totals.  Without a ticket it stores them for
+// xent_finalize_kernel.  With one, the final reduction happens in this launch: the partial leaves with agent-scope stores
+// (write-through past this XCD's L2; cdna guide, Guideline 16), the thread drains them and takes a ticket; the block that
+// draws the last one reads every partial with agent-scope loads and adds them exactly as xent_finalize_kernel does (256
+// threads striding the block list, wave shuffles, four wave totals) — the result has the same bits, the launch after the
+// loss (and, on request, the metrics_record launch after that) is gone.  No block waits for another.
+__device__ inline void xent_block_tail(const XentArgs &a, float bl, int bc, int bt) {
+    __shared__ int sh_last;
+    __shared__ float shf[4];
+    __shared__ int shi[8];
+    if (!a.ticket) {
+        if (threadIdx.x == 0) { a.part_f[blockIdx.x] = bl; a.part_i[blockIdx.x * 2] = bc; a.part_i[blockIdx.x * 2 + 1] = bt; }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.part_f + blockIdx.x, bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part_i + blockIdx.x * 2, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part_i + blockIdx.x * 2 + 1, bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = prev == gridDim.x - 1;
+        if (sh_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    float l = 0.f;
+    int c = 0, t = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        l += __hip_atomic_load(a.part_f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c += __hip_atomic_load(a.part_i + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t += __hip_atomic_load(a.part_i + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    l = wave_sum(l); c = wave_sum_i(c); t = wave_sum_i(t);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { shf[w] = l; shi[2 * w] = c; shi[2 * w + 1] = t; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int cc = shi[0] + shi[2] + shi[4] + shi[6], tt = shi[1] + shi[3] + shi[5] + shi[7];
+        const float r0 = (shf[0] + shf[1]) + (shf[2] + shf[3]);
+        if (a.res_i) { a.res_i[0] = cc; a.res_i[1] = tt; }
+        if (a.res && !a.acc_only) { a.res[0] = r0; a.res[1] = (float)tt; a.res[2] = (float)cc; a.res[3] = (float)tt; }
+        if (a.ring && !a.acc_only) {                          // metrics_record_kernel's row (elementwise.hip)
+            const uint32_t e = a.ring_epoch ? *a.ring_epoch : 0u;
+            float *row = a.ring + ((size_t)(e % (uint32_t)a.ring_capacity) * 4 + a.ring_slot) * 8;
+            row[0] = r0; row[1] = (float)tt; row[2] = (float)cc; row[3] = (float)tt;
+            row[4] = a.ring_sumsq ? *a.ring_sumsq : 0.f;
+            row[5] = (float)e; row[6] = 0.f; row[7] = 0.f;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
     __shared__ float sh_f[4];
@@ -112,11 +169,14 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
     // block partials (lane 0 of each wave carries the wave's totals)
     if (lane == 0) { sh_f[wave] = loss; sh_i[wave * 2] = correct; sh_i[wave * 2 + 1] = total; }
     __syncthreads();
+    float bl = 0.f;
+    int bc = 0, bt = 0;
     if (threadIdx.x == 0) {
-        a.part_f[blockIdx.x] = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
-        a.part_i[blockIdx.x * 2] = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
-        a.part_i[blockIdx.x * 2 + 1] = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
+        bl = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
+        bc = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
+        bt = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
     }
+    xent_block_tail(a, bl, bc, bt);
 }
 
 // ---- narrow logits (C <= 64, rows of whole float4 pieces): one LANE per row --------------------------------------
@@ -183,11 +243,14 @@ __global__ __launch_bounds__(256) void xent_lane_kernel(XentArgs a) {
     loss = wave_sum(loss); correct = wave_sum_i(correct); total = wave_sum_i(total);
     if (lane == 0) { sh_f[wave] = loss; sh_i[wave * 2] = correct; sh_i[wave * 2 + 1] = total; }
     __syncthreads();
+    float bl = 0.f;
+    int bc = 0, bt = 0;
     if (threadIdx.x == 0) {
-        a.part_f[blockIdx.x] = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
-        a.part_i[blockIdx.x * 2] = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
-        a.part_i[blockIdx.x * 2 + 1] = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
+        bl = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
+        bc = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
+        bt = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
     }
+    xent_block_tail(a, bl, bc, bt);
 }
 
 __global__ __launch_bounds__(256) void count_labelled_kernel(const int32_t *truth, int n, int32_t *part) {
@@ -243,6 +306,16 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
     if (a.n_rows == 0) blocks = 1;                      // a rank that owns no rows still reports zeros
     a.part_f = c->red_f + 2048;
     a.part_i = c->red_i;
+    // the final reduction (and an armed metrics record) ride in the loss launch; GCNHIP_XENT_FINALIZE keeps the second launch
+    const bool two_launches = getenv("GCNHIP_XENT_FINALIZE") != nullptr;
+    a.ticket = two_launches ? nullptr : c->ticket;
+    a.res = d_result; a.res_i = d_result_i;
+    a.ring = nullptr; a.ring_capacity = 1; a.ring_slot = 0; a.ring_epoch = nullptr; a.ring_sumsq = nullptr;
+    const bool record = c->rec_armed && !a.acc_only && d_result;
+    if (record) {
+        a.ring = c->rec_ring; a.ring_capacity = c->rec_capacity; a.ring_slot = c->rec_slot; a.ring_epoch = c->rec_epoch; a.ring_sumsq = c->rec_sumsq;
+        c->rec_armed = false;
+    }
     if (!a.acc_only && a.training && a.count <= 0) {    // count first, like module.cpp:127-133
         int cb = ceil_div(a.n_rows, 4096);
         if (cb > 1024) cb = 1024;
@@ -270,8 +343,11 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
         xent_kernel<<<blocks, 256, 0, c->stream>>>(a);
     }
     GCNHIP_LAUNCH_CHECK();
-    xent_finalize_kernel<<<1, 256, 0, c->stream>>>(a.part_f, a.part_i, blocks, d_result, d_result_i, a.acc_only);
-    GCNHIP_LAUNCH_CHECK();
+    if (!a.ticket) {
+        xent_finalize_kernel<<<1, 256, 0, c->stream>>>(a.part_f, a.part_i, blocks, d_result, d_result_i, a.acc_only);
+        GCNHIP_LAUNCH_CHECK();
+        if (record) return gcnhip_metrics_record(c, a.ring, a.ring_capacity, a.ring_slot, a.ring_epoch, d_result, nullptr, a.ring_sumsq);
+    }
     return 0;
 }
 

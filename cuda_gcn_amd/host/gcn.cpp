@@ -782,8 +782,17 @@ void HipGCN::host_masks_for_epoch() {
     GCNHIP_CHECK(gcnhip_h2d(env.ctx, d_keep1, h_keep1.data(), h_keep1.size()));
 }
 
+// One GPU: the loss launch fills the metrics row itself (gcnhip_metrics_record_with_next_loss) — its result needs no
+// all-reduce first.  HIPGCN_RECORD_LAUNCH keeps the separate launch (A/B).
+static bool loss_records() {
+    static const bool off = getenv("HIPGCN_RECORD_LAUNCH") != nullptr;
+    return !off;
+}
+
 void HipGCN::train_begin() {
     GCNHIP_CHECK(gcnhip_counter_add(env.ctx, env.d_epoch, 1u));
+    if (env.comm->size() == 1 && loss_records())   // loss/accuracy of this forward + the L2 term of the weights it uses
+        GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(env.ctx, d_ring, RING, 0, env.d_epoch, optimizer->d_sumsq));
     epochs_done++;
     if (flags & HIPGCN_MODULAR)                  // set_input (gcn.cpp:73-76): device-to-device, never from the host
         GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
@@ -798,7 +807,8 @@ void HipGCN::train_end() {
         timers->stop(TMR_COMM);
     }
     // loss/accuracy of this forward + the L2 term of the weights it used, then the update
-    GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, 0, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
+    if (!(env.comm->size() == 1 && loss_records()))
+        GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, 0, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
     if (lane && lane->pending) {                    // the previous validation pass still reads W1, W2 and the L2 term
         GCNHIP_CHECK(gcnhip_stream_wait_event(env.ctx, lane->ev_done));
         lane->pending = false;
@@ -827,6 +837,8 @@ void HipGCN::lane_begin(int s) {
     L.out_rows = L.split_rows[s];
     L.rows = d_split_list[s];
     L.rows_n = split_local_n[s];
+    if (L.env.comm->size() == 1 && loss_records())
+        GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(L.env.ctx, d_ring, RING, s == 2 ? 1 : 2, L.env.d_epoch, optimizer->d_sumsq));
 }
 
 void HipGCN::lane_end(int s) {
@@ -836,7 +848,8 @@ void HipGCN::lane_end(int s) {
         L.env.comm->allreduce_sum(L.d_result, 4);
         L.timers->stop(TMR_COMM);
     }
-    GCNHIP_CHECK(gcnhip_metrics_record(L.env.ctx, d_ring, RING, s == 2 ? 1 : 2, L.env.d_epoch, L.d_result, nullptr, optimizer->d_sumsq));
+    if (!(L.env.comm->size() == 1 && loss_records()))
+        GCNHIP_CHECK(gcnhip_metrics_record(L.env.ctx, d_ring, RING, s == 2 ? 1 : 2, L.env.d_epoch, L.d_result, nullptr, optimizer->d_sumsq));
     GCNHIP_CHECK(gcnhip_event_record(L.env.ctx, L.ev_done));
     L.pending = true;
 }
@@ -884,13 +897,15 @@ void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
     if (flags & HIPGCN_MODULAR)
         GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
     set_truth(s);
+    const bool in_loss = env.comm->size() == 1 && loss_records();
+    if (in_loss) GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch, optimizer->d_sumsq));
     for (auto m : eval_modules.empty() ? modules : eval_modules) m->forward(false);
     if (env.comm->size() > 1) {
         timers->start(TMR_COMM);
         env.comm->allreduce_sum(d_result, 4);
         timers->stop(TMR_COMM);
     }
-    GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
+    if (!in_loss) GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
 }
 
 std::pair<float, float> HipGCN::read_metrics(long epoch_index, int slot) {

@@ -407,6 +407,14 @@ int gcnhip_counter_add(gcnhip_ctx *ctx, uint32_t *d_counter, uint32_t inc);
 int gcnhip_metrics_record(gcnhip_ctx *ctx, float *d_ring, int capacity, int slot_in_row,
                           const uint32_t *d_epoch, const float *d_result, const int32_t *d_result_i,
                           const float *d_sumsq);
+/* The same row, written by the NEXT gcnhip_xent_fwd / gcnhip_xent_fwd_rows launched on ctx, from that launch's own
+ * final reduction (the block that finishes last adds the block partials in block order and then fills the row: no
+ * launch for the final sum, none for the copy).  One-shot: the loss call disarms it.  For a run whose d_result needs
+ * no all-reduce before it is reported (one GPU); correct/total are taken from the launch's counts, as
+ * gcnhip_metrics_record does with d_result_i == NULL.  Reference: the four scalars CUDACrossEntropyLoss leaves for
+ * GCN::train_epoch / eval to read back (src/cuda/cuda_module.cu, src/seq/gcn.cpp:107-128). */
+int gcnhip_metrics_record_with_next_loss(gcnhip_ctx *ctx, float *d_ring, int capacity, int slot_in_row,
+                                         const uint32_t *d_epoch, const float *d_sumsq);
 
 /* ---- hipGraph capture of a launch sequence (small graphs are launch-bound: ~25 kernels of a few
  *      microseconds per epoch).  Everything the ops read that changes from epoch to epoch lives in

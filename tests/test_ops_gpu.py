@@ -677,6 +677,82 @@ def test_xent_vs_oracle(dev, oracle, n, c, ld):
     assert np.array_equal(lst["grad"][lab], full["grad"][lab]) and np.all(lst["grad"][~lab] == 7.0)
 
 
+@pytest.mark.parametrize("n,c,ld", [(153756, 41, 48), (700, 7, 8), (64, 100, 100), (1, 3, 4)])
+def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, ld):
+    """the block that finishes last adds the block partials (xent.hip, xent_block_tail): same bits as xent_finalize_kernel
+    (GCNHIP_XENT_FINALIZE=1), launch after launch on changing inputs; the armed metrics row
+    (gcnhip_metrics_record_with_next_loss) equals what gcnhip_metrics_record copies, once, and does not fire again"""
+    import os
+    from cuda_gcn_amd.ops import _ck
+    lib = dev.lib
+    rng = np.random.default_rng(n)
+    tr = rng.integers(-1, c, n).astype(np.int32)
+    tr[0] = 0
+    rows = np.flatnonzero(tr >= 0).astype(np.int32)
+    tb, rb = dev.buf(tr), dev.buf(rows)
+    res, resi = dev.buf(np.zeros(4, np.float32)), dev.buf(np.zeros(2, np.int32))
+    ring = dev.buf(np.full((4, 4, 8), -1.0, np.float32))
+    ep, sq = dev.buf(np.array([6], np.uint32)), dev.buf(np.array([2.5], np.float32))
+    gb = dev.buf(np.zeros((n, ld), np.float32))
+    try:
+        for it in range(4):
+            lb = dev.padded((rng.standard_normal((n, c)) * 3).astype(np.float32), ld)
+            got = []
+            for two in (False, True, False):
+                os.environ.pop("GCNHIP_XENT_FINALIZE", None)
+                if two:
+                    os.environ["GCNHIP_XENT_FINALIZE"] = "1"
+                res.upload(np.zeros(4, np.float32)); resi.upload(np.zeros(2, np.int32))
+                if it % 2:
+                    _ck(lib, lib.gcnhip_xent_fwd_rows(dev.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, rb.ptr, int(rows.size), c, 1, int(rows.size), 0, res.ptr, resi.ptr), "xent rows")
+                else:
+                    _ck(lib, lib.gcnhip_xent_fwd(dev.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, n, c, 1, int(rows.size), 0, res.ptr, resi.ptr), "xent")
+                got.append((res.download().copy(), resi.download().copy()))
+            for a, b in zip(got[0] + got[0], got[1] + got[2]):
+                assert np.array_equal(a, b)
+            assert got[0][1][1] == rows.size
+            # the armed record, with and without the second launch
+            for two in (False, True):
+                os.environ.pop("GCNHIP_XENT_FINALIZE", None)
+                if two:
+                    os.environ["GCNHIP_XENT_FINALIZE"] = "1"
+                ring.upload(np.full((4, 4, 8), -1.0, np.float32))
+                _ck(lib, lib.gcnhip_metrics_record_with_next_loss(dev.ctx, ring.ptr, 4, 2, ep.ptr, sq.ptr), "arm")
+                _ck(lib, lib.gcnhip_xent_fwd(dev.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, n, c, 1, int(rows.size), 0, res.ptr, resi.ptr), "xent")
+                armed = ring.download().copy()
+                ring.upload(np.full((4, 4, 8), -1.0, np.float32))
+                _ck(lib, lib.gcnhip_xent_fwd(dev.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, n, c, 1, int(rows.size), 0, res.ptr, resi.ptr), "xent")
+                assert np.all(ring.download() == -1.0)                       # one-shot
+                _ck(lib, lib.gcnhip_metrics_record(dev.ctx, ring.ptr, 4, 2, ep.ptr, res.ptr, None, sq.ptr), "record")
+                want = ring.download()
+                assert np.array_equal(armed, want)
+                r = want[6 % 4, 2]
+                assert r[0] == got[0][0][0] and r[2] == got[0][1][0] and r[3] == rows.size and r[4] == 2.5 and r[5] == 6.0
+    finally:
+        os.environ.pop("GCNHIP_XENT_FINALIZE", None)
+
+
+def test_adam_sum_of_squares_in_the_launch_equals_the_second_launch(dev):
+    """gcnhip_adam_step's sum(w0^2): last-block sum inside the Adam launch == sum_partials_kernel (GCNHIP_ADAM_SUM_LAUNCH=1)"""
+    import os
+    rng = np.random.default_rng(5)
+    try:
+        for n in (77056, 300, 1_000_000):
+            w = rng.standard_normal(n).astype(np.float32)
+            gs = rng.standard_normal((3, n)).astype(np.float32)
+            out = []
+            for two in (False, True, False):
+                os.environ.pop("GCNHIP_ADAM_SUM_LAUNCH", None)
+                if two:
+                    os.environ["GCNHIP_ADAM_SUM_LAUNCH"] = "1"
+                (wn,), sq = dev.adam_steps([w], [[g] for g in gs], [1], 0.01, 5e-4)
+                out.append((wn, sq))
+            assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] == out[2][1]
+            assert abs(out[0][1] - float((out[0][0].astype(np.float64) ** 2).sum())) <= 1e-5 * out[0][1]
+    finally:
+        os.environ.pop("GCNHIP_ADAM_SUM_LAUNCH", None)
+
+
 def test_xent_golden(dev, mods):
     lg, tr = mods["ce_logits"], mods["ce_truth"]
     cnt = int((tr >= 0).sum())

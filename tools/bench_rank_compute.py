@@ -22,23 +22,24 @@ def main():
     out = {}
     for P in worlds:
         per_rank = []
-        for r in range(P):
+        for r in ([int(os.environ['RANK_ONLY'])] if os.environ.get('RANK_ONLY') else range(P)):    # RANK_ONLY: one rank under a profiler
             flags = NO_EVAL_LANE | (NULL_COMM if P > 1 else 0) | (TIMERS if os.environ.get("RANK_TIMERS") else 0) | int(os.environ.get("RANK_FLAGS", "0"))
             m = HipGCNModel(ds, seed=1, flags=flags, rank=r, world=P, hidden_dim=hidden, dropout=0.5, epochs=40)
             m.run_epochs(3, want_trace=False)
             m.sync()
             m.timers_reset()
             t0 = time.perf_counter()
-            m.run_epochs(10, want_trace=False)
+            n_ep = int(os.environ.get('RANK_EPOCHS', '10'))
+            m.run_epochs(n_ep, want_trace=False)
             m.sync()
-            ms = 1e3 * (time.perf_counter() - t0) / 10
+            ms = 1e3 * (time.perf_counter() - t0) / n_ep
             info = m.info()
             if os.environ.get("RANK_TIMERS") and r == 0:
                 bd = {}
                 for nm in ("spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw", "matmul_fw", "matmul_bw", "loss_fw", "adam", "comm"):
                     sec, n = m.timer(nm)
                     if n:
-                        bd[nm] = round(1e3 * sec / 10, 4)
+                        bd[nm] = round(1e3 * sec / n_ep, 4)
                 print(f"  P={P} rank 0 timers (ms per epoch): {bd}  sum={sum(bd.values()):.3f}", flush=True)
             per_rank.append(dict(rank=r, ms=round(ms, 3), rows=info["local_rows"], edges=info["local_edges"], schedule=m.schedule()))
             m.close()
