@@ -97,6 +97,9 @@ def main():
         gs(h, h); gs(Cc, 48)
         gs_bf16(h, h); gs_bf16(Cc, 64); gs_bf16(Cc, 48)
         return
+    if len(sys.argv) > 4 and sys.argv[4] == 'only_c':       # PMC passes: the class-width launches alone (41 columns in 48-float rows)
+        gs(Cc, 48)
+        return
     gs(h, h)
     if len(sys.argv) > 4 and sys.argv[4] == 'only_h':       # PMC passes: the hidden-width launches alone under their kernel name
         return
