@@ -52,8 +52,8 @@ L2_AGG_GBPS = 34500.0         # "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggreg
 MALL_GATHER_GBPS = 8600.0     # "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache: 33.5 GB/s per CU = 8.6 TB/s
 PMC_FILES = ["r03_graphsum_pmc.json", "r02_graphsum_pmc.json"]           # newest first (profiles/)
 PMC_RMAT_FILES = ["r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
-GS_KERNEL = "graphsum_vec_kernel<16, 4, true>"       # the hidden-width launch on a cache-resident table (graphsum.hip, launch_vec)
-GS_KERNEL_HBM = "graphsum_vec_kernel<16, 2, true>"   # ... past the Infinity Cache (two row loads in flight)
+GS_KERNEL = "graphsum_vec_kernel<16, 4, true, false>"       # the hidden-width launch on a cache-resident table (graphsum.hip, launch_vec)
+GS_KERNEL_HBM = "graphsum_vec_kernel<16, 2, true, false>"   # ... past the Infinity Cache (two row loads in flight)
 
 
 def log(*a):
