@@ -830,10 +830,12 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         else if (d8 % 16 == 0) launch_bf16<16>(a, xb, c->stream);   // 128-column (two-line) slices as in the f32 kernel: 305 -> 322 epochs/s
         else launch_bf16<8>(a, xb, c->stream);               // 64-column (one line) slices, one per XCD group when 8 % slices == 0
     }
-    // the vector kernel adds the segments of a split row itself (the last segment to finish does): no finalize launch.
-    // GCNHIP_GS_FINALIZE keeps the two-launch form (A/B runs, tests of the finalize kernel).
-    static const bool two_launches = getenv("GCNHIP_GS_FINALIZE") != nullptr;
-    if (!in_bf && vec && n_split_rows && g->seg_count && !two_launches) {
+    // GCNHIP_GS_FOLD (opt-in, round 3): the vector kernel adds the segments of a split row itself (the last segment to finish
+    // does) and no finalize launch follows.  Same bits; measured no faster at 5 K segments and slower as their number grows
+    // (every segment wave keeps its slot through a store drain and an atomic round trip: 0.835 vs 0.774 ms at 20 K segments),
+    // so the default stays the fire-and-forget partial store plus one 8 us launch.  Read per call: tests switch it.
+    const bool fold = getenv("GCNHIP_GS_FOLD") != nullptr;
+    if (!in_bf && vec && n_split_rows && g->seg_count && fold) {
         a.slot_info = g->slot_info; a.seg_count = g->seg_count;
         a.n_slots_bytes = (int)std::min<size_t>((size_t)g->n_slots * g->part_ld * sizeof(float), 0x7FFFFFFFu);
     }

@@ -162,7 +162,7 @@ def test_wide_aggregation_on_split_rows_needs_reserve_width(oracle):
 @pytest.mark.parametrize("dim", [128, 41, 256])
 def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
     """split (hub) rows: the wave that finishes a row's last segment adds the partials itself (graphsum.hip, Guideline 16
-    hand-off).  Same bits as the graphsum_finalize launch (GCNHIP_GS_FINALIZE=1), launch after launch on CHANGING inputs —
+    hand-off; opt-in, GCNHIP_GS_FOLD=1).  Same bits as the default graphsum_finalize launch, launch after launch on CHANGING inputs —
     a partial served from a stale cache line of the previous launch would show here — and with the ReLU+dropout+bits
     epilogue on the same rows"""
     import os
@@ -180,7 +180,7 @@ def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
     g = dev.graph(gp, gi)
     ld = (dim + 15) // 16 * 16
     xin, out = dev.buf(np.zeros((n, ld), np.float32)), dev.buf(np.zeros((n, ld), np.float32))
-    os.environ.pop("GCNHIP_GS_FINALIZE", None)
+    os.environ.pop("GCNHIP_GS_FOLD", None)
     try:
         for it in range(6):
             x = np.zeros((n, ld), np.float32)
@@ -189,16 +189,32 @@ def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
             got = []
             for two_launch in (False, True, False):
                 if two_launch:
-                    os.environ["GCNHIP_GS_FINALIZE"] = "1"
+                    os.environ.pop("GCNHIP_GS_FOLD", None)
                 else:
-                    os.environ.pop("GCNHIP_GS_FINALIZE", None)
+                    os.environ["GCNHIP_GS_FOLD"] = "1"
                 out.upload(np.full((n, ld), 7.0, np.float32))
                 _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim), "graphsum")
                 got.append(out.download()[:, :dim].copy())
             assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+            if dim % 32 == 0:                                  # the ReLU + dropout + mask-bits epilogue on the same rows
+                wpr = dim // 32
+                bits = dev.buf(np.zeros((n, wpr), np.uint32))
+                ep = dev.buf(np.array([it + 1], np.uint32))
+                eb = []
+                for two_launch in (False, True):
+                    os.environ.pop("GCNHIP_GS_FOLD", None)
+                    if not two_launch:
+                        os.environ["GCNHIP_GS_FOLD"] = "1"
+                    out.upload(np.full((n, ld), 7.0, np.float32)); bits.upload(np.zeros((n, wpr), np.uint32))
+                    _ck(lib, lib.gcnhip_graphsum_relu_dropout_bits(dev.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim, 1, 0.5, 99, ep.ptr, 0, None,
+                                                                   bits.ptr, wpr), "graphsum_relu_dropout_bits")
+                    eb.append((out.download().copy(), bits.download().copy()))
+                assert np.array_equal(eb[0][0], eb[1][0]) and np.array_equal(eb[0][1], eb[1][1])
+                unpacked = ((eb[0][1][:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, dim).astype(bool)
+                assert np.array_equal(unpacked, eb[0][0][:, :dim] > 0)
             if it == 0:
                 close_mag(got[0], oracle.graphsum(gp, gi, x[:, :dim].copy(), dim), oracle.graphsum(gp, gi, np.abs(x[:, :dim]).copy(), dim))
     finally:
-        os.environ.pop("GCNHIP_GS_FINALIZE", None)
+        os.environ.pop("GCNHIP_GS_FOLD", None)
     g.free()
     dev.close()
