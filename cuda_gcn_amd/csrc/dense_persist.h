@@ -14,8 +14,9 @@
 //  * the input dropout moves from the staging pass to the operand read (a select on the A fragment), the keep bits of a
 //    chunk travelling through the same ring.
 // Exact f32 (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  Within an 8-wide k group the forward visits k in the order
-// 0,4,1,5,2,6,3,7 (a lane's 16-byte LDS read supplies four MFMA steps), so its sums are associated differently from
-// dense_tile128.h's — same real number, compared against the oracle with the same bound.
+// 0,4,1,5,2,6,3,7 (a lane's 16-byte LDS read supplies four MFMA steps); dense_tile128.h's forward kernels walk their LDS
+// tiles in the same order (T_KO), so both forms give the same bits (tests/test_ops_gpu.py,
+// test_dense_forward_persistent_and_tile_kernels_give_the_same_bits) — the validation lane launches the tile kernel.
 #pragma once
 #include "dense_tile128.h"
 

@@ -74,6 +74,11 @@ __device__ inline uint32_t bits_at(const uint32_t *bits, uint64_t e) {
 
 // --------------------------------------------------------------------- forward
 constexpr int T_BM = 128, T_BN = 128, T_BK = 32;
+// k order of the FORWARD kernels (round 3): inside an 8-wide k group the two k's of MFMA step t are 8j + t and 8j + 4 + t
+// (lane half kq supplies 8j + 4*kq + t) — the order dense_persist.h's forward has from its 16-byte LDS reads — so the tile
+// kernels and the persistent kernel add the same products in the same order: the validation lane (tile kernel beside the
+// aggregation) and the one-stream epoch (persistent kernel) give the same bits again.  T_KO(kk) = offset of step kk / 2.
+#define T_KO(kk_) ((((kk_) >> 3) << 3) + (((kk_) >> 1) & 3))
 constexpr int T_ALD = T_BK + 1;       // A tile [row][k]: lanes of a half-wave walk rows -> odd stride, conflict-free
 
 // FAST: the launch site guarantees 16-byte aligned rows of X whose stride covers round_up(K, 32) columns
@@ -189,12 +194,13 @@ __global__ __launch_bounds__(256) void dense_fwd_t128_kernel(Tile128Args a) {
         stash(k0);
         __syncthreads();
         if (k0 + T_BK < a.K) fetch(k0 + T_BK);      // FAST: k0 + 32 <= round_up(K, 32) <= ldx
-        const float *Ap = &As[(wm * 64 + li) * T_ALD + kq];
-        const float *Bp = &Bs[kq * T_BN + wn * 64 + li];
+        const float *Ap = &As[(wm * 64 + li) * T_ALD + 4 * kq];
+        const float *Bp = &Bs[4 * kq * T_BN + wn * 64 + li];
 #pragma unroll
         for (int kk = 0; kk < T_BK; kk += 2) {
-            const float a0 = Ap[kk], a1 = Ap[32 * T_ALD + kk];
-            const float b0 = Bp[kk * T_BN], b1 = Bp[kk * T_BN + 32];
+            const int ko = T_KO(kk);                             // the k pair of this step: (8j + t, 8j + 4 + t), see T_KO
+            const float a0 = Ap[ko], a1 = Ap[32 * T_ALD + ko];
+            const float b0 = Bp[ko * T_BN], b1 = Bp[ko * T_BN + 32];
             acc[0][0] = MFMA32(a0, b0, acc[0][0]);
             acc[0][1] = MFMA32(a0, b1, acc[0][1]);
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
@@ -284,15 +290,15 @@ __global__ __launch_bounds__(512) void dense_fwd_t128w8_kernel(Tile128Args a) {
         stash(k0);
         __syncthreads();
         if (k0 + T_BK < a.K) fetch(k0 + T_BK);
-        const float *Ap = &As[(wm * 32 + li) * T_ALD + kq];
-        const float *Bp = &Bs[kq * T_BN + wn * 64 + li];
+        const float *Ap = &As[(wm * 32 + li) * T_ALD + 4 * kq];
+        const float *Bp = &Bs[4 * kq * T_BN + wn * 64 + li];
         // operands of step kk+2 are read from LDS before the MFMAs of step kk are issued (the scheduler otherwise puts every
         // read right in front of its use and the wave waits out the LDS latency once per MFMA pair)
         float a0 = Ap[0], b0 = Bp[0], b1 = Bp[32];
 #pragma unroll
         for (int kk = 0; kk < T_BK; kk += 2) {
             float an = 0.f, bn0 = 0.f, bn1 = 0.f;
-            if (kk + 2 < T_BK) { an = Ap[kk + 2]; bn0 = Bp[(kk + 2) * T_BN]; bn1 = Bp[(kk + 2) * T_BN + 32]; }
+            if (kk + 2 < T_BK) { const int kn = T_KO(kk + 2); an = Ap[kn]; bn0 = Bp[kn * T_BN]; bn1 = Bp[kn * T_BN + 32]; }
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = MFMA32(a0, b0, acc[0]);
             acc[1] = MFMA32(a0, b1, acc[1]);

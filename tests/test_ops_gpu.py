@@ -525,6 +525,33 @@ def test_spmm_dense_vs_oracle(dev, oracle, N, F, p):
     f.free()
 
 
+@pytest.mark.parametrize("N,F", [(5000, 602), (257, 602), (70000, 96), (31, 40)])
+def test_dense_forward_persistent_and_tile_kernels_give_the_same_bits(dev, N, F):
+    """p = 128, dense X: the persistent LDS-DMA kernel (dense_persist.h) and the 128 x 128 tile kernel (dense_tile128.h; what
+    a context marked gcnhip_ctx_set_corun launches — the validation lane) add the same products in the same order: outputs
+    equal bit for bit, without dropout, with p = 0.5 (scale 2 folds exactly into either operand) and with the ReLU epilogue.
+    This is what makes the two-stream epoch reproduce the one-stream epoch's validation losses exactly."""
+    from cuda_gcn_amd.ops import _ck
+    rng = np.random.default_rng(N)
+    vals = rng.standard_normal(N * F).astype(np.float32)
+    fp = (np.arange(N + 1) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    w = rng.standard_normal((F, 128)).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    assert f.dense
+    try:
+        got = {}
+        for corun in (0, 1):
+            _ck(dev.lib, dev.lib.gcnhip_ctx_set_corun(dev.ctx, corun), "gcnhip_ctx_set_corun")
+            got[corun] = (dev.spmm_fwd(f, w), dev.spmm_fwd(f, w, p_drop=0.5, seed=7, epoch=3), dev.spmm_fwd_relu(f, w))
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert (got[0][2] >= 0).all() and np.array_equal(got[0][2], np.maximum(got[0][0], 0))
+    finally:
+        dev.lib.gcnhip_ctx_set_corun(dev.ctx, 0)
+    f.free()
+
+
 @pytest.mark.parametrize("p", [16, 8, 3])
 def test_spmm_golden(dev, mods, p):
     fp, fi, F = mods["sp_tiny_indptr"], mods["sp_tiny_indices"], int(mods["sp_tiny_F"])
