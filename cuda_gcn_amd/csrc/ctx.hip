@@ -172,12 +172,14 @@ __global__ void edge_coef_kernel(const int *__restrict__ indptr, const int *__re
 }
 
 // Rows longer than the split length are cut into segments (one wave each).  A segment is a serial walk, so it
-// must stay short against the work one wave slot gets: nnz / (256 CUs x 32 waves), clamped to [128, 512]
-// (a full Reddit graph keeps 512; a 1/8 row block of it gets 256, which removed a 50 us critical path
+// must stay short against the work one wave slot gets: nnz / (256 CUs x 32 waves), clamped to [128, 1024]
+// (a full Reddit graph keeps 1024; a 1/8 row block of it gets 256, which removed a 50 us critical path
 // from a 130 us launch).
 static int split_length(int64_t nnz) {
     if (const char *e = getenv("GCNHIP_SPLIT_EDGES")) { const int v = atoi(e); if (v >= 16) return v; }   // experiments
-    int s = 512;       // round 3: 1024 -> 512 at Reddit scale (hidden width 0.766 -> 0.756 ms, epoch +0.4 %); 256 loses again (0.774)
+    int s = 1024;      // round 3 sweep: 512 is 1 % better on reddit-syn's hidden width (0.766 -> 0.756 ms, epoch +0.4 %) and 5 % worse on
+                       // the R-MAT scale-22 model (24.5 vs 25.8 epochs/s: ten times the segments, all through the partial scratch); 256 and
+                       // 2048+ lose on both.  1024 stays.
     while (s > 128 && (int64_t)s * 8192 > nnz) s >>= 1;
     return s;
 }
