@@ -409,9 +409,31 @@ def main():
     # beside the K-step figure (clocks and temperatures settle; an external busy-sampler sees the card at work)
     sustained = None
     if world == 1 and not args.no_extras and args.sustain > 0:
+        # socket power and shader clock of the visible card while the region runs (rocm-smi from a side thread, ~0.2 s a
+        # sample, read-only): DESIGN.md §4.4 — every hot kernel of this epoch alone draws 1.25-1.36 kW of the 1.4 kW cap
+        import threading
+        smi, stop = [], threading.Event()
+
+        def sample():
+            while not stop.is_set():
+                try:
+                    o = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+                    d = json.loads(o).get("card0", {})
+                    smi.append((float(d["Current Socket Graphics Package Power (W)"]), float(d["sclk clock speed:"].strip("()Mhz"))))
+                except Exception:
+                    stop.wait(0.5)
+        th = threading.Thread(target=sample, daemon=True)
+        th.start()
         d_s, _tr = timed_region(model, args.sustain)
+        stop.set()
+        th.join(timeout=10)
         sustained = {"epochs": args.sustain, "seconds": round(d_s, 3), "epochs_per_s": args.sustain / d_s}
-        log(f"sustained: {args.sustain / d_s:.2f} epochs/s over {args.sustain} epochs ({d_s:.1f} s)")
+        tail = smi[len(smi) // 3:]                              # the first third: ramp
+        if tail:
+            sustained.update({"socket_power_W": round(sum(x[0] for x in tail) / len(tail), 1), "sclk_MHz": round(sum(x[1] for x in tail) / len(tail), 1),
+                              "smi_samples": len(tail), "smi": "rocm-smi --showpower --showclocks, sampled during the region"})
+        log(f"sustained: {args.sustain / d_s:.2f} epochs/s over {args.sustain} epochs ({d_s:.1f} s)" +
+            (f"; socket {sustained['socket_power_W']} W, sclk {sustained['sclk_MHz']} MHz" if tail else ""))
 
     # ---- separate pass, same process and model: per-op HIP-event timers on (the epoch then runs eagerly, one
     # event pair per op on the stream the op runs on; on one GPU everything runs on ONE stream in this pass, so a launch
