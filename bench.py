@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument("--dataset", default="reddit-syn")
     ap.add_argument("--bursts", type=int, default=4, help="extra repetitions of the K-step timed region (median/min/max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cli", action="store_true", help="skip the `cli` block (the shipped gcn-hip binary on the same workload from its .gcnbin cache)")
+    ap.add_argument("--cli-epochs", type=int, default=100, help="epochs of the `cli` block's run (the reference's default epoch count)")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-regime leg and the structure-blind rerun")
     ap.add_argument("--sustain", type=int, default=1500, help="epochs of the long back-to-back region of the extras (0: skip)")
     ap.add_argument("--hbm-scale", type=int, default=21, help="R-MAT scale of the HBM-regime leg (21: 1 GiB table at d=128)")
@@ -603,6 +605,31 @@ def main():
         except Exception as e:          # the leg is an extra: report its failure, keep the headline
             out["roofline"]["hbm_regime"] = {"error": repr(e)}
 
+    if rank == 0 and world == 1 and not args.no_cli:
+        # The shipped program on the same workload: `gcn-hip <dataset> - - <hidden> - - - - <epochs>` as a child process,
+        # reading the dataset from its binary cache, with the command line's own defaults — epochs/s from ITS
+        # `total training time=` line (src/seq/gcn.cpp:152), so the driver's record states what the drop-in binary
+        # delivers next to what the library delivers under this file's driver loop.
+        try:
+            from cuda_gcn_amd import clirun
+            r = clirun.run_on_dataset(ds, hidden=args.hidden, epochs=args.cli_epochs, env={"GCN_SEED": "1"})
+            rs = clirun.run_on_dataset(ds, hidden=args.hidden, epochs=max(10, args.cli_epochs // 5),
+                                       env={"GCN_SEED": "1", "GCN_SYNC_EPOCHS": "1", "GCN_REFERENCE_ORDER": "1", "GCN_EVAL_LANE": "0"})
+            out["cli"] = {"command": r["command"], "epochs": len(r["epochs"]), "total_training_time_s": r["total_training_time_s"],
+                          "epochs_per_s": r["epochs_per_s"], "ms_per_epoch": r["ms_per_epoch"],
+                          "epochs_per_s_after_warmup": r.get("epochs_per_s_after_warmup"),
+                          "load_s": r.get("load_s"), "model_build_s": r.get("model_build_s"), "process_wall_s": round(r["process_wall_s"], 2),
+                          "cache_MB": r["cache_MB"], "cache_write_s": r["cache_write_s"],
+                          "final": r["epochs"][-1], "test": r.get("test"),
+                          "schedule": "the command line's defaults at early_stopping == 0: epochs enqueued ahead of the printed line, validation "
+                                      "lane, aggregate-first evaluation (host/main.cpp)",
+                          "reference_loop": {"command": rs["command"], "env": rs["env"], "epochs": len(rs["epochs"]),
+                                             "epochs_per_s": rs["epochs_per_s"], "ms_per_epoch": rs["ms_per_epoch"],
+                                             "what": "one epoch, wait, print (gcn.cpp:133-151), the reference's operation order, one stream"}}
+            log(f"cli: {r['epochs_per_s']:.1f} epochs/s over {len(r['epochs'])} epochs (load {r.get('load_s')} s, build {r.get('model_build_s')} s); "
+                f"reference loop {rs['epochs_per_s']:.1f}")
+        except Exception as e:          # an extra: report its failure, keep the headline
+            out["cli"] = {"error": repr(e)}
     if rank == 0:
         # rank 0, any N: the CPU path on this box's host cores (the other ranks wait at the barrier below)
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(ds, args.hidden)

@@ -80,6 +80,9 @@ GCNHIP_SYMBOLS = {
     "gcnhip_h2d": (I, [P, P, P, C.c_size_t]),
     "gcnhip_d2h": (I, [P, P, P, C.c_size_t]),
     "gcnhip_d2d_async": (I, [P, P, P, C.c_size_t]),
+    "gcnhip_host_alloc": (I, [C.POINTER(P), C.c_size_t]),
+    "gcnhip_host_free": (I, [P]),
+    "gcnhip_d2h_async": (I, [P, P, P, C.c_size_t]),
     "gcnhip_graph_create": (I, [P, C.POINTER(P), P, P, I, I, P]),
     "gcnhip_graph_create_grouped": (I, [P, C.POINTER(P), P, P, I, I, P, P]),
     "gcnhip_graph_set_schedule": (I, [P, P, I, P, I]),
@@ -150,6 +153,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_event_record": (I, [P, P]),
     "gcnhip_stream_wait_event": (I, [P, P]),
     "gcnhip_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),
+    "gcnhip_event_sync": (I, [P]),
 }
 
 

@@ -115,6 +115,21 @@ int gcnhip_d2d_async(gcnhip_ctx *c, void *dst, const void *src, size_t bytes) {
     return 0;
 }
 
+int gcnhip_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return -1;
+    GCNHIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+int gcnhip_host_free(void *ptr) {
+    if (ptr) GCNHIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+int gcnhip_d2h_async(gcnhip_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || !dst || !src) return -1;
+    if (bytes) GCNHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
 int gcnhip_capture_begin(gcnhip_ctx *c) {
     GCNHIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     return 0;
@@ -146,6 +161,7 @@ int gcnhip_stream_wait_event(gcnhip_ctx *c, void *ev) {
     GCNHIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));
     return 0;
 }
+int gcnhip_event_sync(void *ev) { GCNHIP_TRY(hipEventSynchronize((hipEvent_t)ev)); return 0; }
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms) {
     GCNHIP_TRY(hipEventSynchronize((hipEvent_t)stop));
     GCNHIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

@@ -693,6 +693,7 @@ void HipGCN::release() {
     variables.clear();
     optimizer.reset();
     if (epoch_graph) { gcnhip_graph_exec_destroy(epoch_graph); epoch_graph = nullptr; }
+    readback_destroy();
     destroy_bwd_pipeline();
     env.xlane = nullptr;
     xlane.reset();                                            // its communicator goes before the parent's
@@ -929,42 +930,47 @@ std::pair<float, float> HipGCN::eval(int s) {
     return read_metrics(epochs_done - 1, s == 2 ? 1 : 2);
 }
 
+// One epoch (train + validation) is a fixed launch sequence whose epoch-dependent inputs all live in device memory, so it
+// is captured once into a hipGraph and replayed (single GPU, one stream, device RNG, no per-op timers).  The first epoch
+// runs eagerly so every scratch buffer has its final size.
+bool HipGCN::enqueue_epoch_replay() {
+    const bool graph_ok = env.comm->size() == 1 && !lane && !timers->enabled && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_NO_GRAPH));
+    if (!(graph_ok && epochs_done >= 1 && optimizer->can_replay(1))) return false;
+    if (!epoch_graph) {
+        const long epochs_before = epochs_done;
+        const int steps_before = optimizer->steps();
+        GCNHIP_CHECK(gcnhip_capture_begin(env.ctx));
+        try {
+            train_epoch_async();
+            eval_async(2);
+        } catch (...) {
+            // never leave the stream capturing: end the capture, drop whatever it recorded, restore
+            // the host-side counters, then let the caller see the failure
+            void *broken = nullptr;
+            gcnhip_capture_end(env.ctx, &broken);
+            if (broken) gcnhip_graph_exec_destroy(broken);
+            epochs_done = epochs_before;
+            optimizer->note_replayed(steps_before - optimizer->steps());
+            throw;
+        }
+        GCNHIP_CHECK(gcnhip_capture_end(env.ctx, &epoch_graph));
+        // the capture only recorded: undo its host-side bookkeeping, then run it for real
+        epochs_done = epochs_before;
+        optimizer->note_replayed(steps_before - optimizer->steps());
+    }
+    GCNHIP_CHECK(gcnhip_graph_launch(env.ctx, epoch_graph));
+    epochs_done++;
+    optimizer->note_replayed(1);
+    return true;
+}
+
 void HipGCN::run_epochs(int n, float *trace) {
     int done = 0;
-    // One epoch (train + validation) is a fixed launch sequence whose epoch-dependent inputs all live in
-    // device memory, so it is captured once into a hipGraph and replayed (single GPU, device RNG, no
-    // per-op timers).  The first epoch runs eagerly so every scratch buffer has its final size.
-    const bool graph_ok = env.comm->size() == 1 && !lane && !timers->enabled && !(flags & (HIPGCN_HOST_MASKS | HIPGCN_NO_GRAPH));
     while (done < n) {
         const int chunk = std::min(n - done, RING);
         const long first = epochs_done;
         for (int i = 0; i < chunk; i++) {
-            if (graph_ok && epochs_done >= 1 && optimizer->can_replay(1)) {
-                if (!epoch_graph) {
-                    const long epochs_before = epochs_done;
-                    const int steps_before = optimizer->steps();
-                    GCNHIP_CHECK(gcnhip_capture_begin(env.ctx));
-                    try {
-                        train_epoch_async();
-                        eval_async(2);
-                    } catch (...) {
-                        // never leave the stream capturing: end the capture, drop whatever it recorded, restore
-                        // the host-side counters, then let the caller see the failure
-                        void *broken = nullptr;
-                        gcnhip_capture_end(env.ctx, &broken);
-                        if (broken) gcnhip_graph_exec_destroy(broken);
-                        epochs_done = epochs_before;
-                        optimizer->note_replayed(steps_before - optimizer->steps());
-                        throw;
-                    }
-                    GCNHIP_CHECK(gcnhip_capture_end(env.ctx, &epoch_graph));
-                    // the capture only recorded: undo its host-side bookkeeping, then run it for real
-                    epochs_done = epochs_before;
-                    optimizer->note_replayed(steps_before - optimizer->steps());
-                }
-                GCNHIP_CHECK(gcnhip_graph_launch(env.ctx, epoch_graph));
-                epochs_done++;
-                optimizer->note_replayed(1);
+            if (enqueue_epoch_replay()) {
             } else if (lane && !(timers->enabled && env.comm->size() == 1)) {
                 // (one GPU with per-op timers on: one stream, so that every launch is timed alone — the branch below)
                 // validation of epoch i-1 zipped with training of epoch i; the chunk's last validation runs alone
@@ -992,7 +998,93 @@ void HipGCN::run_epochs(int n, float *trace) {
     }
 }
 
+void HipGCN::readback_create() {
+    if (readback) return;
+    readback.reset(new Readback());
+    Readback &R = *readback;
+    GCNHIP_CHECK(gcnhip_ctx_create(&R.ctx, device_, nullptr));
+    void *q = nullptr;
+    GCNHIP_CHECK(gcnhip_host_alloc(&q, (size_t)PIPELINE_DEPTH * 16 * sizeof(float)));
+    R.host = (float *)q;
+    for (int k = 0; k < PIPELINE_DEPTH; k++) {
+        GCNHIP_CHECK(gcnhip_event_create_sync(&R.ev_ready[k]));
+        GCNHIP_CHECK(gcnhip_event_create_sync(&R.ev_copied[k]));
+    }
+}
+
+void HipGCN::readback_destroy() {
+    if (!readback) return;
+    Readback &R = *readback;
+    if (R.ctx) gcnhip_ctx_sync(R.ctx);
+    for (int k = 0; k < PIPELINE_DEPTH; k++) {
+        if (R.ev_ready[k]) gcnhip_event_destroy(R.ev_ready[k]);
+        if (R.ev_copied[k]) gcnhip_event_destroy(R.ev_copied[k]);
+    }
+    gcnhip_host_free(R.host);
+    if (R.ctx) gcnhip_ctx_destroy(R.ctx);
+    readback.reset();
+}
+
+// everything of epoch `e` (0-based) has been enqueued, its validation pass last on `producer`: when that has run, the
+// read-back stream copies slots 0 and 1 of the epoch's ring row (16 floats) to pinned memory
+void HipGCN::readback_enqueue(long e, gcnhip_ctx *producer) {
+    Readback &R = *readback;
+    const int k = (int)(e % PIPELINE_DEPTH);
+    GCNHIP_CHECK(gcnhip_event_record(producer, R.ev_ready[k]));
+    GCNHIP_CHECK(gcnhip_stream_wait_event(R.ctx, R.ev_ready[k]));
+    GCNHIP_CHECK(gcnhip_d2h_async(R.ctx, R.host + (size_t)k * 16, d_ring + (size_t)((uint32_t)e % RING) * 32, 16 * sizeof(float)));
+    GCNHIP_CHECK(gcnhip_event_record(R.ctx, R.ev_copied[k]));
+}
+
 void HipGCN::run() {                            // gcn.cpp:130-158
+    if (getenv("HIPGCN_SYNC_EPOCHS")) flags |= HIPGCN_SYNC_EPOCHS;
+    if (params.early_stopping > 0 || (flags & HIPGCN_SYNC_EPOCHS) || params.epochs < 1) run_synchronous();
+    else run_pipelined();
+    report_test();
+}
+
+// No printed number feeds back into the run (no early stopping): epochs are enqueued up to PIPELINE_DEPTH ahead of the
+// line being printed.  With the validation lane, eval(e) is zipped with train(e+1) exactly as in run_epochs.
+void HipGCN::run_pipelined() {
+    readback_create();
+    Readback &R = *readback;
+    const bool talk = env.comm->rank() == 0;
+    const long E = params.epochs, first = epochs_done;
+    long enq = 0, printed = 0;                   // epochs (of this run) whose training pass is enqueued / whose line is out
+    const bool zipped = lane && !(timers->enabled && env.comm->size() == 1);
+    double total_train = 0;
+    auto t_prev = std::chrono::high_resolution_clock::now();
+    while (printed < E) {
+        while (enq < E && enq - printed < PIPELINE_DEPTH) {
+            if (zipped) {
+                if (enq == 0) train_epoch_async();
+                else { eval_then_train_zipped(2); readback_enqueue(first + enq - 1, lane->env.ctx); }
+                if (enq == E - 1) { eval_on_lane(2); readback_enqueue(first + enq, lane->env.ctx); }
+            } else {
+                if (!enqueue_epoch_replay()) { train_epoch_async(); eval_async(2); }
+                readback_enqueue(first + enq, env.ctx);
+            }
+            enq++;
+        }
+        const int k = (int)((first + printed) % PIPELINE_DEPTH);
+        GCNHIP_CHECK(gcnhip_event_sync(R.ev_copied[k]));
+        const auto t_now = std::chrono::high_resolution_clock::now();
+        const float dt = std::chrono::duration_cast<std::chrono::duration<float>>(t_now - t_prev).count();
+        t_prev = t_now;
+        total_train += dt;
+        const float *tr = R.host + (size_t)k * 16, *va = tr + 8;
+        const float train_loss = tr[0] / (int)tr[1] + params.weight_decay * tr[4] / 2, train_acc = (float)tr[2] / (int)tr[3];
+        const float val_loss = va[0] / (int)va[1] + params.weight_decay * va[4] / 2, val_acc = (float)va[2] / (int)va[3];
+        if (talk)
+            printf("epoch=%ld train_loss=%.5f train_acc=%.5f val_loss=%.5f val_acc=%.5f time=%.5f\n",
+                   printed + 1, train_loss, train_acc, val_loss, val_acc, dt);
+        printed++;
+    }
+    sync();
+    if (talk) printf("total training time=%.5f\n", (float)total_train);
+}
+
+void HipGCN::run_synchronous() {
     int epoch = 1;
     std::vector<float> loss_history;
     double total_train = 0;
@@ -1020,6 +1112,10 @@ void HipGCN::run() {                            // gcn.cpp:130-158
         }
     }
     if (talk) printf("total training time=%.5f\n", (float)total_train);
+}
+
+void HipGCN::report_test() {
+    const bool talk = env.comm->rank() == 0;
     float test_loss, test_acc;
     auto t0 = std::chrono::high_resolution_clock::now();
     std::tie(test_loss, test_acc) = eval(3);

@@ -61,6 +61,9 @@ enum HipGCNFlags {
     HIPGCN_STRUCTURE_PARTITION = 2097152, // multi-GPU: rank blocks formed from groups found in the graph (cluster.h) instead of
                                           // contiguous id ranges, when that shrinks the neediest rank's halo (default: decided per graph)
     HIPGCN_ID_PARTITION = 4194304,        // ... never
+    HIPGCN_SYNC_EPOCHS = 8388608,         // run(): wait for every epoch before the next is enqueued (the reference's loop, gcn.cpp:133-151:
+                                          // `time=` is then that epoch's own latency).  Default: epochs are enqueued ahead of the line being
+                                          // printed whenever no decision depends on a printed number (early_stopping == 0)
 };
 
 struct HipGCNOptions {
@@ -85,7 +88,12 @@ public:
     ~HipGCN();
     HipGCN(const HipGCN &) = delete;
 
-    void run();                                               // gcn.cpp:130-158, same output lines
+    // gcn.cpp:130-158, same output lines.  With early stopping (or HIPGCN_SYNC_EPOCHS) the loop is the reference's: enqueue
+    // one epoch, wait, print, decide.  Otherwise nothing the host prints feeds back into the run, so up to PIPELINE_DEPTH
+    // epochs are in flight while epoch e's line is printed (its 16 metrics floats arrive through a read-back stream):
+    // `time=` is then the interval between consecutive epoch completions and `total training time` their sum = the wall
+    // time of the whole loop.
+    void run();
     std::pair<float, float> train_epoch();                    // synchronises to return (loss, acc)
     std::pair<float, float> eval(int current_split);
     // enqueue n x (train_epoch + eval(2)) with no host synchronisation in between, then read back
@@ -200,6 +208,21 @@ private:
     long keep0_first = 0;                                      // global nnz index of h_keep0[0]
     long epochs_done = 0;                                      // host mirror of *d_epoch + 1
     void *epoch_graph = nullptr;                               // captured train_epoch + eval(2)
+    bool enqueue_epoch_replay();                               // one epoch from the captured hipGraph (captures it on first use); false: not replayable
+    // run(): read-back of an epoch's metrics row without stalling the producer streams
+    static constexpr int PIPELINE_DEPTH = 4;
+    struct Readback {
+        gcnhip_ctx *ctx = nullptr;                             // its own stream
+        float *host = nullptr;                                 // pinned [PIPELINE_DEPTH][16]: slots 0 (train) and 1 (validation) of a ring row
+        void *ev_ready[PIPELINE_DEPTH] = {}, *ev_copied[PIPELINE_DEPTH] = {};
+    };
+    std::unique_ptr<Readback> readback;
+    void readback_create();
+    void readback_destroy();
+    void readback_enqueue(long epoch_index, gcnhip_ctx *producer);
+    void run_synchronous();
+    void run_pipelined();
+    void report_test();
 
     // Validation lane.  eval(e) reads only the weights Adam(e) wrote, and train(e+1) needs the same
     // weights and nothing from eval(e): the two are independent until Adam(e+1).  With more than one GPU

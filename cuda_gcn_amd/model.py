@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO, PACKED_DH1, MASKED_BWD, BWD_PIPELINE, NO_LABEL_HINT, OVERLAP_EXCHANGE, STRUCTURE_PARTITION, ID_PARTITION = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304
+MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO, PACKED_DH1, MASKED_BWD, BWD_PIPELINE, NO_LABEL_HINT, OVERLAP_EXCHANGE, STRUCTURE_PARTITION, ID_PARTITION, SYNC_EPOCHS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608
 TIMER_NAMES = ["train", "test", "matmul_fw", "matmul_bw", "spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw",
                "loss_fw", "relu_fw", "relu_bw", "dropout_fw", "dropout_bw", "adam", "comm", "graphsum_wide"]
 

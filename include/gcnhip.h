@@ -74,6 +74,14 @@ int gcnhip_memset_async(gcnhip_ctx *ctx, void *ptr, int byte, size_t bytes);
 int gcnhip_h2d(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronises */
 int gcnhip_d2h(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronises */
 int gcnhip_d2d_async(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* Read-back without stalling the producer: page-locked host memory and a device-to-host copy that is only ENQUEUED on
+ * ctx's stream (wait for it with an event recorded behind it + gcnhip_event_sync).  HipGCN::run() uses them to print
+ * epoch e's line while epochs e+1.. are already running: a second context's stream waits for the epoch's event, copies
+ * the 16 floats of its metrics row and records an event the host sleeps on.  (The reference's CUDA path instead blocks
+ * on a cudaMemcpy of the whole logits matrix per accuracy call, src/cuda/cuda_gcn.cu:100-120.) */
+int gcnhip_host_alloc(void **ptr, size_t bytes);
+int gcnhip_host_free(void *ptr);
+int gcnhip_d2h_async(gcnhip_ctx *ctx, void *dst_pinned, const void *src, size_t bytes);
 
 /* ---- adjacency (CUDASparseIndex(const SparseIndex&): cuda_variable.cu:55-64) --
  * Copies the CSR of n_rows rows to the device and precomputes, once, the per
@@ -435,6 +443,7 @@ int gcnhip_event_create_sync(void **ev);
 int gcnhip_event_destroy(void *ev);
 int gcnhip_event_record(gcnhip_ctx *ctx, void *ev);
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+int gcnhip_event_sync(void *ev);                                   /* the host waits for the work recorded before ev */
 /* make the context's stream wait (on the device) for work recorded before `ev` on another context's stream */
 int gcnhip_stream_wait_event(gcnhip_ctx *ctx, void *ev);
 
