@@ -70,6 +70,8 @@ GCNHIP_SYMBOLS = {
     "gcnhip_ctx_destroy": (I, [P]),
     "gcnhip_ctx_sync": (I, [P]),
     "gcnhip_ctx_set_corun": (I, [P, I]),
+    "gcnhip_ctx_set_option": (I, [P, C.c_char_p, I]),
+    "gcnhip_ctx_get_option": (I, [P, C.c_char_p, C.POINTER(I)]),
     "gcnhip_ctx_stream": (P, [P]),
     "gcnhip_error_string": (C.c_char_p, [I]),
     "gcnhip_last_error": (C.c_char_p, []),

@@ -20,8 +20,36 @@ constexpr int WAVE = 64;
 // detail text for a -1 return (gcnhip_last_error); returns -1 so that a check can `return gcnhip_fail("...")`
 int gcnhip_fail(const char *detail);
 
+// Options of a context (gcnhip_ctx_set_option / _get_option).  Each starts from the environment variable
+// GCNHIP_<NAME IN CAPITALS>, read ONCE when the context is created — never at launch time — so a call's behaviour does not
+// depend on what the process environment holds at that moment.  Most are A/B aids for measurements DESIGN.md records.
+struct GcnOptions {
+    int gs_pipe;            // 1: persistent index-prefetching aggregation kernel (measured slower)
+    int gs_u;               // > 0: row loads in flight per lane group of the aggregation (0: by table size)
+    int gs_nt;              // 1: non-temporal row loads in the sliced aggregation (measured slower)
+    int gs_fold;            // 1: split rows are summed inside the aggregation launch (same bits; no faster)
+    int gemm_tiles;         // 1: first-layer forward by the tile kernels instead of the persistent form
+    int gemm_w4;            // 1: four-wave forward tiles
+    int gemm_persist_bwd;   // 1: persistent first-layer weight gradient (measured slower)
+    int dbg_linear;         // timing experiment only: the persistent forward reads X as if tile-major (wrong results)
+    int xent_finalize;      // 1: the loss's final reduction as its own launch
+    int xent_wave;          // 1: wave-per-row loss kernel for any width
+    int adam_sum_launch;    // 1: Adam's sum of squares by a second launch
+    int atb_cap_mb;         // split-K slab budget of A^T.B in MiB
+    int rs_wgs;             // > 0: workgroups per CU of the row-streaming GEMM
+    int spmm_lds;           // 1: sparse forward with W staged in LDS whenever it fits (measured slower: opt-in)
+    int spmm_general;       // 1: narrow rows also take the general (shuffle-based) sparse kernels; -1: narrow kernels at any size (A/B, tests)
+    int spmm_rows;          // > 0: rows per wave of the sparse forward (default: by row count, 1 .. 8)
+    int spmm_nw;            // > 0: waves per column task of the sparse weight gradient (1, 4, 16), read by gcnhip_feat_create
+    int split_edges;        // >= 16: segment length of split rows, read by gcnhip_graph_create*
+};
+struct GcnOptionEntry { const char *name; int GcnOptions::*field; int dflt; };
+extern const GcnOptionEntry GCN_OPTION_TABLE[];
+extern const int GCN_OPTION_COUNT;
+
 struct gcnhip_ctx {
     int device;
+    GcnOptions opt;
     hipStream_t stream;
     bool own_stream;
     int n_cu;
@@ -63,6 +91,7 @@ struct gcnhip_graph {
     int *indices;       // [nnz]
     float *coef;        // [nnz]
     // long-row splitting (rows above SPLIT_EDGES are cut into segments)
+    int split_edges_opt; // the creating context's split_edges option (0: by size)
     int n_tasks;        // number of (row, e0, e1) tasks; 0 => one task per row
     int4 *tasks;        // {row, e_begin, e_end, partial_slot or -1}
     int n_split_rows;   // rows that own partial slots
@@ -101,7 +130,16 @@ struct gcnhip_feat {
     int *csc_ptr;       // [n_cols+1]
     int *csc_row;       // [nnz] source row of each entry
     int *csc_pos;       // [nnz] position jj in CSR order (selects value + dropout decision)
+    float *csc_val;     // [nnz] values[csc_pos[q]]: the pristine values in CSC order (one dependent load less per entry)
     uint32_t *keep_bits; // [ceil(nnz/32)+1] input-dropout decisions of the current call (dense path)
+    // the weight gradient's task list over the CSC view (sparse X, spmm_sparse.h): a column is one task of bwd_nw waves, a
+    // column longer than the segment length several tasks whose partial rows a fold launch adds in order
+    int4 *bwd_tasks;    // {column, q_begin, q_end, partial slot or -1}
+    int n_bwd_tasks, bwd_nw;
+    int4 *bwd_split;    // {column, first slot, segments, 0} for the columns that were cut
+    int n_bwd_split, n_bwd_slots;
+    float *bwd_partials; // [n_bwd_slots * bwd_part_ld], sized by the first backward call that needs it (and on a wider call)
+    int bwd_part_ld;
 };
 
 // ---- Philox4x32-10 (Salmon et al., SC'11): counter-based, so the dropout

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <vector>
 #include <algorithm>
 
@@ -14,9 +15,48 @@ int gcnhip_fail(const char *detail) {
     return -1;
 }
 
+const GcnOptionEntry GCN_OPTION_TABLE[] = {
+    {"gs_pipe", &GcnOptions::gs_pipe, 0}, {"gs_u", &GcnOptions::gs_u, 0}, {"gs_nt", &GcnOptions::gs_nt, 0}, {"gs_fold", &GcnOptions::gs_fold, 0},
+    {"gemm_tiles", &GcnOptions::gemm_tiles, 0}, {"gemm_w4", &GcnOptions::gemm_w4, 0}, {"gemm_persist_bwd", &GcnOptions::gemm_persist_bwd, 0},
+    {"dbg_linear", &GcnOptions::dbg_linear, 0}, {"xent_finalize", &GcnOptions::xent_finalize, 0}, {"xent_wave", &GcnOptions::xent_wave, 0},
+    {"adam_sum_launch", &GcnOptions::adam_sum_launch, 0}, {"atb_cap_mb", &GcnOptions::atb_cap_mb, 12}, {"rs_wgs", &GcnOptions::rs_wgs, 0},
+    {"spmm_lds", &GcnOptions::spmm_lds, 0}, {"spmm_rows", &GcnOptions::spmm_rows, 0}, {"spmm_general", &GcnOptions::spmm_general, 0}, {"spmm_nw", &GcnOptions::spmm_nw, 0}, {"split_edges", &GcnOptions::split_edges, 0},
+};
+const int GCN_OPTION_COUNT = (int)(sizeof GCN_OPTION_TABLE / sizeof GCN_OPTION_TABLE[0]);
+
+// defaults, then GCNHIP_<NAME> from the environment (a set but empty or non-numeric variable means 1): once, here
+static void options_from_environment(GcnOptions *o) {
+    for (int i = 0; i < GCN_OPTION_COUNT; i++) {
+        const GcnOptionEntry &e = GCN_OPTION_TABLE[i];
+        o->*e.field = e.dflt;
+        char var[64] = "GCNHIP_";
+        size_t n = strlen(var);
+        for (const char *q = e.name; *q && n + 1 < sizeof var; q++) var[n++] = (char)toupper((unsigned char)*q);
+        var[n] = 0;
+        if (const char *v = getenv(var)) {
+            char *end;
+            const long x = strtol(v, &end, 10);
+            o->*e.field = end == v ? 1 : (int)x;
+        }
+    }
+}
+
 extern "C" {
 
 const char *gcnhip_last_error(void) { return g_detail; }
+
+int gcnhip_ctx_set_option(gcnhip_ctx *c, const char *name, int value) {
+    if (!c || !name) return -1;
+    for (int i = 0; i < GCN_OPTION_COUNT; i++)
+        if (!strcmp(GCN_OPTION_TABLE[i].name, name)) { c->opt.*GCN_OPTION_TABLE[i].field = value; return 0; }
+    return gcnhip_fail("gcnhip_ctx_set_option: unknown option");
+}
+int gcnhip_ctx_get_option(const gcnhip_ctx *c, const char *name, int *value) {
+    if (!c || !name || !value) return -1;
+    for (int i = 0; i < GCN_OPTION_COUNT; i++)
+        if (!strcmp(GCN_OPTION_TABLE[i].name, name)) { *value = c->opt.*GCN_OPTION_TABLE[i].field; return 0; }
+    return gcnhip_fail("gcnhip_ctx_get_option: unknown option");
+}
 
 int gcnhip_device_count(int *count) {
     GCNHIP_TRY(hipGetDeviceCount(count));
@@ -36,6 +76,7 @@ int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
     gcnhip_ctx *c = new gcnhip_ctx();
     memset(c, 0, sizeof *c);
     c->device = device;
+    options_from_environment(&c->opt);
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
@@ -191,8 +232,8 @@ __global__ void edge_coef_kernel(const int *__restrict__ indptr, const int *__re
 // must stay short against the work one wave slot gets: nnz / (256 CUs x 32 waves), clamped to [128, 1024]
 // (a full Reddit graph keeps 1024; a 1/8 row block of it gets 256, which removed a 50 us critical path
 // from a 130 us launch).
-static int split_length(int64_t nnz) {
-    if (const char *e = getenv("GCNHIP_SPLIT_EDGES")) { const int v = atoi(e); if (v >= 16) return v; }   // experiments
+static int split_length(int64_t nnz, int forced) {
+    if (forced >= 16) return forced;                 // the split_edges option of the creating context (experiments)
     int s = 1024;      // round 3 sweep: 512 is 1 % better on reddit-syn's hidden width (0.766 -> 0.756 ms, epoch +0.4 %) and 5 % worse on
                        // the R-MAT scale-22 model (24.5 vs 25.8 epochs/s: ten times the segments, all through the partial scratch); 256 and
                        // 2048+ lose on both.  1024 stays.
@@ -265,7 +306,7 @@ static int build_schedule(gcnhip_graph *g, const int *h_row_group) {
 // the task list of a given row order
 static int build_tasks(gcnhip_graph *g, const std::vector<int> &order) {
     const int *h_indptr = g->h_indptr->data();
-    const int SPLIT_EDGES = split_length(g->nnz);
+    const int SPLIT_EDGES = split_length(g->nnz, g->split_edges_opt);
     const int n_rows = g->n_rows;
     int n_slots = 0;
     std::vector<int4> tasks, srows;
@@ -353,6 +394,7 @@ static int graph_create_impl(gcnhip_ctx *c, gcnhip_graph *g, const int *h_indptr
     GCNHIP_TRY(hipSetDevice(c->device));
     const int nnz = h_indptr[n_rows];
     g->n_rows = n_rows; g->n_cols = n_cols; g->nnz = nnz;
+    g->split_edges_opt = c->opt.split_edges;
     GCNHIP_TRY(hipMalloc((void **)&g->indptr, (size_t)(n_rows + 1) * sizeof(int)));
     GCNHIP_TRY(hipMalloc((void **)&g->indices, (size_t)std::max(nnz, 1) * sizeof(int)));
     GCNHIP_TRY(hipMalloc((void **)&g->coef, (size_t)std::max(nnz, 1) * sizeof(float)));
@@ -421,6 +463,7 @@ int gcnhip_graph_create_restricted(gcnhip_ctx *c, gcnhip_graph **out, const gcnh
     auto fail = [&](int rc) { gcnhip_graph_destroy(c, g); return rc; };
     g->n_rows = n_rows; g->n_cols = parent->n_cols; g->nnz = (int)w;
     g->part_ld = parent->part_ld;
+    g->split_edges_opt = parent->split_edges_opt;
     if (hipMalloc((void **)&g->indptr, (size_t)(n_rows + 1) * sizeof(int)) != hipSuccess) return fail(-2);
     if (hipMalloc((void **)&g->indices, std::max(w, (size_t)1) * sizeof(int)) != hipSuccess) return fail(-2);
     if (hipMalloc((void **)&g->coef, std::max(w, (size_t)1) * sizeof(float)) != hipSuccess) return fail(-2);
@@ -608,6 +651,35 @@ static int feat_create_impl(gcnhip_ctx *c, gcnhip_feat *f, const int *h_indptr, 
         if (nnz) {
             GCNHIP_TRY(hipMemcpy(f->csc_row, row.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
             GCNHIP_TRY(hipMemcpy(f->csc_pos, pos.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+            std::vector<float> cv((size_t)nnz);
+            for (int64_t q = 0; q < nnz; q++) cv[q] = h_values[pos[q]];
+            GCNHIP_TRY(hipMalloc((void **)&f->csc_val, (size_t)nnz * sizeof(float)));
+            GCNHIP_TRY(hipMemcpy(f->csc_val, cv.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+        }
+        // Task list of the weight gradient (spmm_sparse.h).  Waves per task by the mean column length: a short column is
+        // one wave's walk, a long one is shared by 4 or 16 waves of one workgroup (Pubmed: ~2 000 entries per column);
+        // anything beyond the segment length is cut into several tasks with partial rows (skewed bag-of-words columns).
+        const double mean = n_cols ? (double)nnz / n_cols : 0.0;
+        f->bwd_nw = mean <= 128.0 ? 1 : (mean <= 1024.0 ? 4 : 16);
+        if (c->opt.spmm_nw == 1 || c->opt.spmm_nw == 4 || c->opt.spmm_nw == 16) f->bwd_nw = c->opt.spmm_nw;      // experiments
+        const int seg = std::max(1024, f->bwd_nw * 256);
+        std::vector<int4> tasks, split;
+        tasks.reserve((size_t)n_cols + 16);
+        int n_slots = 0;
+        for (int k = 0; k < n_cols; k++) {
+            const int q0 = ptr[k], q1 = ptr[k + 1];
+            if (q1 - q0 <= seg) { tasks.push_back(make_int4(k, q0, q1, -1)); continue; }
+            const int ns = (q1 - q0 + seg - 1) / seg;
+            split.push_back(make_int4(k, n_slots, ns, 0));
+            for (int q = 0; q < ns; q++) tasks.push_back(make_int4(k, q0 + q * seg, std::min(q1, q0 + (q + 1) * seg), n_slots + q));
+            n_slots += ns;
+        }
+        f->n_bwd_tasks = (int)tasks.size(); f->n_bwd_split = (int)split.size(); f->n_bwd_slots = n_slots;
+        GCNHIP_TRY(hipMalloc((void **)&f->bwd_tasks, std::max(tasks.size(), (size_t)1) * sizeof(int4)));
+        if (!tasks.empty()) GCNHIP_TRY(hipMemcpy(f->bwd_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
+        if (!split.empty()) {
+            GCNHIP_TRY(hipMalloc((void **)&f->bwd_split, split.size() * sizeof(int4)));
+            GCNHIP_TRY(hipMemcpy(f->bwd_split, split.data(), split.size() * sizeof(int4), hipMemcpyHostToDevice));
         }
     }
     return 0;
@@ -664,8 +736,12 @@ int gcnhip_feat_destroy(gcnhip_ctx *c, gcnhip_feat *f) {
     if (f->csc_ptr) hipFree(f->csc_ptr);
     if (f->csc_row) hipFree(f->csc_row);
     if (f->csc_pos) hipFree(f->csc_pos);
+    if (f->csc_val) hipFree(f->csc_val);
     if (f->keep_bits) hipFree(f->keep_bits);
     if (f->values_pad) hipFree(f->values_pad);
+    if (f->bwd_tasks) hipFree(f->bwd_tasks);
+    if (f->bwd_split) hipFree(f->bwd_split);
+    if (f->bwd_partials) hipFree(f->bwd_partials);
     delete f;
     return 0;
 }

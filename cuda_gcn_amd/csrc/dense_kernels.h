@@ -593,7 +593,7 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
     const size_t slab_per_worker = (size_t)n * a.p_ld * sizeof(float);
     int per_cu = slab_per_worker <= (256u << 10) ? 16 : 4;
     int workers = ceil_div((int64_t)c->n_cu * per_cu, (int64_t)gy * gz);
-    static const size_t cap_mb = getenv("GCNHIP_ATB_CAP_MB") ? (size_t)atoi(getenv("GCNHIP_ATB_CAP_MB")) : 12;   // experiments
+    const size_t cap_mb = c->opt.atb_cap_mb > 0 ? (size_t)c->opt.atb_cap_mb : 12;                               // experiments
     while (workers > 4 && (size_t)(workers / 4) * slab_per_worker > (cap_mb << 20)) workers = workers * 3 / 4;   // <= 12 MB of partials (one slab per workgroup of 4 workers)
     // at least 8 K-steps (32 rows) per worker.  (64 until round 2: on a Cora-sized product that left 12 waves with
     // 57 dependent K-steps each — 41 us of a 126 us epoch; the workgroup-level sum made more workers free.)
@@ -648,7 +648,7 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
     if (lds > 156 * 1024) return -1;          // K too long for an LDS-resident operand (gfx950: 160 KiB per CU)
     int gx = ceil_div(ceil_div(m, 16), 4);
     int per_cu = lds > 76 * 1024 ? 1 : (lds > 32 * 1024 ? 2 : 4);
-    if (const char *e = getenv("GCNHIP_RS_WGS")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // experiment: persistent workgroups per CU
+    if (c->opt.rs_wgs > 0) per_cu = c->opt.rs_wgs;                                            // experiment: persistent workgroups per CU
     const int cap = c->n_cu * per_cu;
     if (gx > cap) gx = cap;
     dim3 grid(gx, gy);

@@ -325,7 +325,7 @@ int gcnhip_adam_step(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, flo
     int blocks = stream_grid(a.start[n_vars], 1024);
     if (blocks > 1024) blocks = 1024;
     a.partial = d_sumsq ? c->red_f + 1024 : nullptr;       // second quarter of the scratch
-    const bool two_launches = getenv("GCNHIP_ADAM_SUM_LAUNCH") != nullptr;      // A/B aid, tests
+    const bool two_launches = c->opt.adam_sum_launch != 0;                      // A/B aid, tests (context option)
     a.ticket = (d_sumsq && !two_launches) ? c->ticket + 1 : nullptr;
     a.sumsq_out = d_sumsq;
     adam_kernel<<<blocks, 256, 0, c->stream>>>(a);

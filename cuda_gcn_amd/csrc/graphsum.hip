@@ -739,7 +739,8 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
 }
 
 template <int L>
-static void launch_vec(GsArgs &a, const int (*xb)[9], hipStream_t s) {
+static void launch_vec(GsArgs &a, const int (*xb)[9], const gcnhip_ctx *c) {
+    hipStream_t s = c->stream;
     const int ychunks = ceil_div(a.dim, L * 4);
     const bool sliced = ychunks > 1 && 8 % ychunks == 0;   // XCD-sliced columns (1-D grid)
     a.n_slices = sliced ? ychunks : 1;
@@ -752,7 +753,7 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], hipStream_t s) {
     // EXPERIMENT (GCNHIP_GS_PIPE): the persistent form that also prefetches the next chunk's indices.  Measured slower
     // than a wave per task once the row loads are batched (1.15 vs 0.85 ms at Reddit scale): fresh waves arriving in
     // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
-    static const bool pipe = getenv("GCNHIP_GS_PIPE") != nullptr;
+    const bool pipe = c->opt.gs_pipe != 0;
     if (pipe && a.n_tasks && !a.out_bits && !a.accumulate && !a.pos_bits) {
         a.seg_count = nullptr; a.slot_info = nullptr;      // the experiment keeps the finalize launch
         const int per_xcd = std::min(max_blocks, 32 * 8);
@@ -762,10 +763,10 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], hipStream_t s) {
     // Batch depth by regime.  A table that fits the 256 MiB Infinity Cache is gathered with 4 row loads in flight per lane
     // group (latency-bound otherwise: 1.08 -> 0.85 ms at Reddit scale).  Past it the kernel is HBM-bound and 2 is the
     // optimum (R-MAT scale 21, 1 GiB table, d = 128: 5.33 / 5.16 / 5.51 ms with 1 / 2 / 4 in flight).
-    static const int force_u = getenv("GCNHIP_GS_U") ? atoi(getenv("GCNHIP_GS_U")) : 0;
+    const int force_u = c->opt.gs_u;
     const int u = force_u ? force_u : (a.table_bytes > ((size_t)256 << 20) ? 2 : 4);
     const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
-    static const bool nt_all = getenv("GCNHIP_GS_NT") != nullptr;     // EXPERIMENT: every row load non-temporal
+    const bool nt_all = c->opt.gs_nt != 0;                            // EXPERIMENT: every row load non-temporal
     if (sliced && nt_all && L == 16) { graphsum_vec_kernel<16, 4, true, true><<<grid, 256, 0, s>>>(a); return; }
     if (sliced) {
         if (u >= 4) graphsum_vec_kernel<L, 4, true><<<grid, 256, 0, s>>>(a);
@@ -833,8 +834,8 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     // GCNHIP_GS_FOLD (opt-in, round 3): the vector kernel adds the segments of a split row itself (the last segment to finish
     // does) and no finalize launch follows.  Same bits; measured no faster at 5 K segments and slower as their number grows
     // (every segment wave keeps its slot through a store drain and an atomic round trip: 0.835 vs 0.774 ms at 20 K segments),
-    // so the default stays the fire-and-forget partial store plus one 8 us launch.  Read per call: tests switch it.
-    const bool fold = getenv("GCNHIP_GS_FOLD") != nullptr;
+    // so the default stays the fire-and-forget partial store plus one 8 us launch.  (Context option gs_fold.)
+    const bool fold = c->opt.gs_fold != 0;
     if (!in_bf && vec && n_split_rows && g->seg_count && fold) {
         a.slot_info = g->slot_info; a.seg_count = g->seg_count;
         a.n_slots_bytes = (int)std::min<size_t>((size_t)g->n_slots * g->part_ld * sizeof(float), 0x7FFFFFFFu);
@@ -845,15 +846,15 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
         // 1/slices of the table and the (index, coef) stream is re-read only once per slice.  Measured at Reddit scale
         // with 4 row loads in flight, 32- / 64- / 128-float slices: d = 64: 0.434 / 0.403 / - ms; d = 128: 0.843 / 0.760 /
         // 0.874; d = 256: 2.36 / 1.77 / 1.78; R-MAT scale 21 (HBM regime), d = 128: 5.20 / 4.57 ms.
-        launch_vec<16>(a, xb, c->stream);
+        launch_vec<16>(a, xb, c);
     } else if (vec) {
-        if (d4 <= 1) launch_vec<1>(a, xb, c->stream);
-        else if (d4 <= 2) launch_vec<2>(a, xb, c->stream);
-        else if (d4 <= 4) launch_vec<4>(a, xb, c->stream);
-        else if (d4 <= 8) launch_vec<8>(a, xb, c->stream);
-        else if (d4 <= 16) launch_vec<16>(a, xb, c->stream);
-        else if (d4 <= 32) launch_vec<32>(a, xb, c->stream);
-        else launch_vec<64>(a, xb, c->stream);
+        if (d4 <= 1) launch_vec<1>(a, xb, c);
+        else if (d4 <= 2) launch_vec<2>(a, xb, c);
+        else if (d4 <= 4) launch_vec<4>(a, xb, c);
+        else if (d4 <= 8) launch_vec<8>(a, xb, c);
+        else if (d4 <= 16) launch_vec<16>(a, xb, c);
+        else if (d4 <= 32) launch_vec<32>(a, xb, c);
+        else launch_vec<64>(a, xb, c);
     } else {
         if (dim <= 1) launch_scalar<1>(a, nt, c->stream);
         else if (dim <= 2) launch_scalar<2>(a, nt, c->stream);

@@ -14,150 +14,7 @@
 #include "dense_kernels.h"
 #include "dense_tile128.h"
 #include "dense_persist.h"
-
-struct DropSpec {
-    int on, thr;
-    float scale;
-    uint64_t seed, off;
-    const uint32_t *d_epoch;
-    const uint8_t *keep_mask;
-};
-
-__device__ inline float drop_scale(const DropSpec &d, uint64_t e, uint32_t epoch) {
-    if (!d.on) return 1.f;
-    const bool keep = d.keep_mask ? d.keep_mask[e] != 0 : keep1(d.off + e, epoch, d.seed, d.thr);
-    return keep ? d.scale : 0.f;
-}
-
-// ------------------------------------------------------------ sparse forward
-// one wave per row of X; L lanes (float4 each) per row of W
-struct SpFwdArgs {
-    const int *indptr, *indices;
-    const float *vals, *w;
-    float *out;
-    int n_rows, ld_w, ld_out, p;
-    DropSpec d;
-    int relu;                       // store max(x, 0) (module.cpp:175-185 folded into the producer)
-};
-
-template <int L, bool VEC>
-__global__ __launch_bounds__(256) void spmm_csr_fwd_kernel(SpFwdArgs a) {
-    constexpr int G = WAVE / L;
-    constexpr int V = VEC ? 4 : 1;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.n_rows) return;
-    const int g = lane / L, l = lane % L;
-    const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
-    const int e0 = a.indptr[row], e1 = a.indptr[row + 1];
-    for (int cb = blockIdx.y * L * V; cb < a.p; cb += gridDim.y * L * V) {
-        const int col0 = cb + l * V;
-        const bool active = col0 < a.p;
-        float acc[V];
-#pragma unroll
-        for (int i = 0; i < V; i++) acc[i] = 0.f;
-        for (int base = e0; base < e1; base += WAVE) {
-            const int cnt = min(WAVE, e1 - base);
-            int my_idx = 0;
-            float my_v = 0.f;
-            if (lane < cnt) {
-                my_idx = a.indices[base + lane];
-                my_v = a.vals[base + lane] * drop_scale(a.d, (uint64_t)(base + lane), epoch);
-            }
-            const int iters = (cnt + G - 1) / G;
-#pragma unroll 4
-            for (int k = 0; k < iters; k++) {
-                const int src = k * G + g;
-                const int j = __shfl(my_idx, src, WAVE);
-                const float c = __shfl(my_v, src, WAVE);
-                if (active && src < cnt) {
-                    const float *wp = a.w + (size_t)j * a.ld_w + col0;
-                    if (VEC) {
-                        const float4 v = *reinterpret_cast<const float4 *>(wp);
-                        acc[0] += c * v.x; acc[1 % V] += c * v.y; acc[2 % V] += c * v.z; acc[3 % V] += c * v.w;
-                    } else {
-                        acc[0] += c * wp[0];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < V; i++)
-#pragma unroll
-            for (int m = L; m < WAVE; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
-        if (g == 0 && active) {
-            float *o = a.out + (size_t)row * a.ld_out + col0;
-#pragma unroll
-            for (int i = 0; i < V; i++)
-                if (col0 + i < a.p) o[i] = (a.relu && !(acc[i] > 0.f)) ? 0.f : acc[i];
-        }
-    }
-}
-
-// ----------------------------------------------------------- sparse backward
-// one wave per column j of X (row j of dW): dW[j,:] = sum_q X~[pos q] * dout[row q,:]
-struct SpBwdArgs {
-    const int *csc_ptr, *csc_row, *csc_pos;
-    const float *vals, *dout;
-    float *dw;
-    int n_cols, ld_dout, ld_dw, p;
-    DropSpec d;
-};
-
-template <int L, bool VEC>
-__global__ __launch_bounds__(256) void spmm_csc_bwd_kernel(SpBwdArgs a) {
-    constexpr int G = WAVE / L;
-    constexpr int V = VEC ? 4 : 1;
-    const int lane = threadIdx.x & 63;
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (col >= a.n_cols) return;
-    const int g = lane / L, l = lane % L;
-    const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
-    const int q0 = a.csc_ptr[col], q1 = a.csc_ptr[col + 1];
-    for (int cb = blockIdx.y * L * V; cb < a.p; cb += gridDim.y * L * V) {
-        const int col0 = cb + l * V;
-        const bool active = col0 < a.p;
-        float acc[V];
-#pragma unroll
-        for (int i = 0; i < V; i++) acc[i] = 0.f;
-        for (int base = q0; base < q1; base += WAVE) {
-            const int cnt = min(WAVE, q1 - base);
-            int my_row = 0;
-            float my_v = 0.f;
-            if (lane < cnt) {
-                my_row = a.csc_row[base + lane];
-                const int pos = a.csc_pos[base + lane];
-                my_v = a.vals[pos] * drop_scale(a.d, (uint64_t)pos, epoch);
-            }
-            const int iters = (cnt + G - 1) / G;
-#pragma unroll 4
-            for (int k = 0; k < iters; k++) {
-                const int src = k * G + g;
-                const int j = __shfl(my_row, src, WAVE);
-                const float c = __shfl(my_v, src, WAVE);
-                if (active && src < cnt) {
-                    const float *dp = a.dout + (size_t)j * a.ld_dout + col0;
-                    if (VEC) {
-                        const float4 v = *reinterpret_cast<const float4 *>(dp);
-                        acc[0] += c * v.x; acc[1 % V] += c * v.y; acc[2 % V] += c * v.z; acc[3 % V] += c * v.w;
-                    } else {
-                        acc[0] += c * dp[0];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < V; i++)
-#pragma unroll
-            for (int m = L; m < WAVE; m <<= 1) acc[i] += __shfl_xor(acc[i], m, WAVE);
-        if (g == 0 && active) {
-            float *o = a.dw + (size_t)col * a.ld_dw + col0;
-#pragma unroll
-            for (int i = 0; i < V; i++)
-                if (col0 + i < a.p) o[i] = acc[i];
-        }
-    }
-}
+#include "spmm_sparse.h"
 
 // ------------------------------------------------------------- dense forward
 // out[m x p] = X~[m x K] . W[K x p].  Workgroup tile 128 rows x (NT*16) cols,
@@ -286,6 +143,9 @@ __global__ __launch_bounds__(256) void spmm_dense_fwd_kernel(DenseFwdArgs a) {
         }
 }
 
+constexpr int64_t SPMM_NARROW_MIN_NNZ = 262144;     // below this the general sparse kernels run (option spmm_general = -1: narrow kernels always)
+constexpr size_t SPMM_LDS_MAX_BYTES = 128 * 1024;   // W1 in LDS: Cora 92 KB and Pubmed 32 KB fit (gfx950: 160 KB per CU)
+
 static DropSpec make_drop(float p_drop, uint64_t seed, const uint32_t *d_epoch, uint64_t off, const uint8_t *keep_mask) {
     DropSpec d;
     d.on = p_drop > 0.f || keep_mask != nullptr;
@@ -335,7 +195,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         const bool fast = vx == 4 && t.ldx % 4 == 0 && (t.K + 31) / 32 * 32 <= t.ldx && ld_w % 4 == 0 && p % T_BN == 0 && aligned16(w);
         // p = 128: the persistent LDS-DMA form (dense_persist.h) — one workgroup per CU for the whole launch, rows dealt in
         // 32-row blocks, three-stage ring.  GCNHIP_GEMM_TILES keeps the tile kernels below for A/B runs.
-        static const bool tiles_only = getenv("GCNHIP_GEMM_TILES") != nullptr;
+        const bool tiles_only = c->opt.gemm_tiles != 0;
         const int n_chunks = (t.K + PG_BK - 1) / PG_BK;
         if (fast && p == 128 && !tiles_only && !c->corun && aligned16(t.x) && aligned16(out) &&
             (uint64_t)(t.m + PG_ROWS) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 4096 * sizeof(float) <= c->wpack_bytes) {
@@ -345,8 +205,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
             pa.x = t.x; pa.ldx = t.ldx; pa.wp = c->wpack; pa.out = out; pa.ldo = ld_out;
             pa.m = t.m; pa.K = t.K; pa.n_chunks = n_chunks; pa.n_rb = ceil_div(t.m, 32);
             pa.bits = t.bits; pa.relu = relu;
-            static const bool dbg_linear = getenv("GCNHIP_DBG_LINEAR") != nullptr;
-            pa.dbg_linear = dbg_linear ? 1 : 0;
+            pa.dbg_linear = c->opt.dbg_linear ? 1 : 0;
             const int wgs = std::max(1, std::min(c->n_cu, pa.n_rb));
             if (pa.bits) dense_fwd_persist_kernel<true><<<wgs, 512, 0, c->stream>>>(pa);
             else dense_fwd_persist_kernel<false><<<wgs, 512, 0, c->stream>>>(pa);
@@ -355,7 +214,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         }
         // eight waves per tile: same bits, 4 % faster than the four-wave form (0.383 -> 0.367 ms at Reddit scale);
         // GCNHIP_GEMM_W4 selects the four-wave kernel for A/B runs
-        static const bool w4 = getenv("GCNHIP_GEMM_W4") != nullptr;
+        const bool w4 = c->opt.gemm_w4 != 0;
         if (fast && !w4) dense_fwd_t128w8_kernel<<<grid, 512, 0, c->stream>>>(t);
         else if (fast) dense_fwd_t128_kernel<4, true><<<grid, 256, 0, c->stream>>>(t);
         else if (vx == 4) dense_fwd_t128_kernel<4><<<grid, 256, 0, c->stream>>>(t);
@@ -386,9 +245,64 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
     SpFwdArgs a;
     a.indptr = f->indptr; a.indices = f->indices; a.vals = vals; a.w = w; a.out = out;
     a.n_rows = f->n_rows; a.ld_w = ld_w; a.ld_out = ld_out; a.p = p; a.d = d; a.relu = relu;
+    a.w_floats = f->n_cols * ld_w;
+    a.rows_per_wave = 1;
     const bool vec = ld_w % 4 == 0 && aligned16(w);
     const int units = vec ? (p + 3) / 4 : p;              // lanes needed for one row of W
-    dim3 grid(ceil_div(f->n_rows, 4), 1);
+    // W staged in LDS (one 1024-thread workgroup per CU walks rows; north_star's "LDS staging of the feature tile"): built,
+    // bit-identical to the general kernel, and measured SLOWER wherever W fits (round 4, profiles/r04_spmm_lds.log: pubmed-syn
+    // 11.7 vs 9.0 us; 2 M rows x 50 values, F = 500 / 2000, h = 16: 0.91 vs 0.72 / 0.87 ms) — a W that fits LDS also sits in
+    // every XCD's L2, and the rows were never what bound these kernels (spmm_sparse.h).  Opt-in: context option spmm_lds = 1.
+    const size_t w_bytes = (size_t)a.w_floats * sizeof(float);
+    const int wgs = std::max(1, std::min(c->n_cu, ceil_div(f->n_rows, 16)));
+    const bool lds_form = c->opt.spmm_lds == 1 && vec && units <= 64 && p <= 256 && w_bytes <= SPMM_LDS_MAX_BYTES && f->n_rows > 0;
+    a.nnz_bytes = (int)std::min<int64_t>(f->nnz * 4, 0x7FFFFFFF);
+    if (lds_form && units <= 16 && f->nnz * 4 < 0x7FFFFFFF && !c->opt.spmm_general) {      // narrow rows: the shuffle-free kernel over LDS
+        const int per_cu = w_bytes <= 32 * 1024 ? 2 : 1;                                    // 1024-thread workgroups: at most two per CU
+        const int wq = std::max(1, std::min(c->n_cu * per_cu, ceil_div(f->n_rows, 16)));
+        a.rows_per_wave = std::max(1, std::min(8, (int)(f->n_rows / ((int64_t)wq * 16 * 4))));
+#define SPLQ(L_)                                                                                                         \
+    do {                                                                                                                 \
+        auto kern = spmm_csr_fwd_q_lds_kernel<L_>;                                                                       \
+        if (w_bytes > 64 * 1024) GCNHIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_bytes)); \
+        kern<<<wq, 1024, w_bytes, c->stream>>>(a);                                                                       \
+    } while (0)
+        if (units <= 1) SPLQ(1); else if (units <= 2) SPLQ(2); else if (units <= 4) SPLQ(4); else if (units <= 8) SPLQ(8); else SPLQ(16);
+#undef SPLQ
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    if (lds_form) {
+#define SPL(L_)                                                                                                          \
+    do {                                                                                                                 \
+        auto kern = spmm_csr_fwd_lds_kernel<L_>;                                                                         \
+        if (w_bytes > 64 * 1024) GCNHIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_bytes)); \
+        kern<<<wgs, 1024, w_bytes, c->stream>>>(a);                                                                      \
+    } while (0)
+        if (units <= 1) SPL(1); else if (units <= 2) SPL(2); else if (units <= 4) SPL(4);
+        else if (units <= 8) SPL(8); else if (units <= 16) SPL(16); else if (units <= 32) SPL(32); else SPL(64);
+#undef SPL
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    // rows per wave: enough waves to fill every slot about twice, at most 8 rows each (one wave per row on small inputs)
+    a.rows_per_wave = std::max(1, std::min(8, (int)(f->n_rows / ((int64_t)c->n_cu * 64))));
+    if (c->opt.spmm_rows > 0) a.rows_per_wave = std::min(32, c->opt.spmm_rows);
+    dim3 grid(ceil_div(ceil_div(f->n_rows, a.rows_per_wave), 4), 1);
+    a.nnz_bytes = (int)std::min<int64_t>(f->nnz * 4, 0x7FFFFFFF);
+    // narrow 16-byte aligned rows (hidden <= 64; the reference's default is 16): the shuffle-free kernel (spmm_sparse.h)
+    // (small inputs keep the general kernel: at a few microseconds per launch the shorter program wins — cora-syn / citeseer-syn
+    //  3.3 / 3.5 us against 3.3 / 4.4; pubmed-syn and up: 7.7 against 8.9 us, 2 M rows: 0.81 against 0.95 ms)
+    const bool narrow = vec && units <= 16 && f->nnz * 4 < 0x7FFFFFFF && !c->opt.spmm_general && (f->nnz >= SPMM_NARROW_MIN_NNZ || c->opt.spmm_general < 0);
+    if (narrow) {
+        if (units <= 1) spmm_csr_fwd_q_kernel<1><<<grid, 256, 0, c->stream>>>(a);
+        else if (units <= 2) spmm_csr_fwd_q_kernel<2><<<grid, 256, 0, c->stream>>>(a);
+        else if (units <= 4) spmm_csr_fwd_q_kernel<4><<<grid, 256, 0, c->stream>>>(a);
+        else if (units <= 8) spmm_csr_fwd_q_kernel<8><<<grid, 256, 0, c->stream>>>(a);
+        else spmm_csr_fwd_q_kernel<16><<<grid, 256, 0, c->stream>>>(a);
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
 #define SPF(L_)                                                                           \
     do {                                                                                  \
         if (vec) spmm_csr_fwd_kernel<L_, true><<<grid, 256, 0, c->stream>>>(a);           \
@@ -431,7 +345,7 @@ static int dense_bwd_persist(gcnhip_ctx *c, const gcnhip_feat *f, const float *v
     // EXPERIMENT, opt-in (GCNHIP_GEMM_PERSIST_BWD): measured SLOWER than the split tiles at Reddit scale (0.50 ms without,
     // 0.61 ms with dropout against 0.387 ms; profiles/r03_gemm_pmc.json: the pipes 41-53 % busy, 37 % of the wave cycles
     // parked) — ten k-major A reads + ten keep-word pairs per k step and wave make the VALU/LDS side as long as the MFMAs
-    static const bool persist_bwd = getenv("GCNHIP_GEMM_PERSIST_BWD") != nullptr;
+    const bool persist_bwd = c->opt.gemm_persist_bwd != 0;
     if (!persist_bwd || p != 128 || f->n_rows < 1) return 1;
     const float *x = vals; int ldx = f->n_cols;
     if (vals == f->values && f->values_pad) { x = f->values_pad; ldx = f->ld_pad; }
@@ -538,22 +452,58 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
         return launch_atb(c, vals, f->n_cols, dout, ld_dout, dw, ld_dw, f->n_rows, f->n_cols, p,
                           d.on, p_drop, seed, d_epoch, nnz_offset, keep_mask, d.on ? f->keep_bits : nullptr);
     }
+    // sparse X: CSC gather over the task list built with the feature object (spmm_sparse.h)
+    const int p_ld = (p + 3) / 4 * 4;
+    if (f->n_bwd_slots && f->bwd_part_ld < p_ld) {
+        // the partial rows of cut columns: sized by the first call that needs them (synchronises once, like the split-K slabs)
+        gcnhip_feat *fm = const_cast<gcnhip_feat *>(f);
+        GCNHIP_TRY(hipStreamSynchronize(c->stream));
+        if (fm->bwd_partials) { GCNHIP_TRY(hipFree(fm->bwd_partials)); fm->bwd_partials = nullptr; fm->bwd_part_ld = 0; }
+        GCNHIP_TRY(hipMalloc((void **)&fm->bwd_partials, (size_t)f->n_bwd_slots * p_ld * sizeof(float)));
+        fm->bwd_part_ld = p_ld;
+    }
     SpBwdArgs a;
-    a.csc_ptr = f->csc_ptr; a.csc_row = f->csc_row; a.csc_pos = f->csc_pos;
-    a.vals = vals; a.dout = dout; a.dw = dw;
-    a.n_cols = f->n_cols; a.ld_dout = ld_dout; a.ld_dw = ld_dw; a.p = p; a.d = d;
+    a.tasks = f->bwd_tasks; a.n_tasks = f->n_bwd_tasks;
+    a.csc_row = f->csc_row; a.csc_pos = f->csc_pos;
+    a.csc_val = vals == f->values ? f->csc_val : nullptr;
+    a.vals = vals; a.dout = dout; a.dw = dw; a.partials = f->bwd_partials; a.part_ld = f->bwd_part_ld;
+    a.ld_dout = ld_dout; a.ld_dw = ld_dw; a.p = p; a.d = d;
+    if (a.n_tasks == 0) return 0;
     const bool vec = ld_dout % 4 == 0 && aligned16(dout);
     const int units = vec ? (p + 3) / 4 : p;
-    dim3 grid(ceil_div(f->n_cols, 4), 1);
+    a.nnz_bytes = (int)std::min<int64_t>(f->nnz * 4, 0x7FFFFFFF);
+    if (vec && units <= 16 && a.csc_val && f->nnz * 4 < 0x7FFFFFFF && !c->opt.spmm_general &&
+        (f->nnz >= SPMM_NARROW_MIN_NNZ || c->opt.spmm_general < 0)) {                            // narrow rows: the shuffle-free kernel
+#define SPQ(L_)                                                                                             \
+    do {                                                                                                    \
+        if (f->bwd_nw == 16) spmm_csc_bwd_q_kernel<L_, 16><<<a.n_tasks, 1024, 0, c->stream>>>(a);           \
+        else if (f->bwd_nw == 4) spmm_csc_bwd_q_kernel<L_, 4><<<a.n_tasks, 256, 0, c->stream>>>(a);         \
+        else spmm_csc_bwd_q_kernel<L_, 1><<<ceil_div(a.n_tasks, 4), 256, 0, c->stream>>>(a);                \
+    } while (0)
+        if (units <= 1) SPQ(1); else if (units <= 2) SPQ(2); else if (units <= 4) SPQ(4); else if (units <= 8) SPQ(8); else SPQ(16);
+#undef SPQ
+    } else {
+#define SPB2(L_, V_)                                                                                        \
+    do {                                                                                                    \
+        if (f->bwd_nw == 16) spmm_csc_bwd_kernel<L_, V_, 16><<<a.n_tasks, 1024, 0, c->stream>>>(a);         \
+        else if (f->bwd_nw == 4) spmm_csc_bwd_kernel<L_, V_, 4><<<a.n_tasks, 256, 0, c->stream>>>(a);       \
+        else spmm_csc_bwd_kernel<L_, V_, 1><<<ceil_div(a.n_tasks, 4), 256, 0, c->stream>>>(a);              \
+    } while (0)
 #define SPB(L_)                                                                           \
     do {                                                                                  \
-        if (vec) spmm_csc_bwd_kernel<L_, true><<<grid, 256, 0, c->stream>>>(a);           \
-        else spmm_csc_bwd_kernel<L_, false><<<grid, 256, 0, c->stream>>>(a);              \
+        if (vec) SPB2(L_, true); else SPB2(L_, false);                                    \
     } while (0)
     if (units <= 1) SPB(1); else if (units <= 2) SPB(2); else if (units <= 4) SPB(4);
     else if (units <= 8) SPB(8); else if (units <= 16) SPB(16); else if (units <= 32) SPB(32); else SPB(64);
 #undef SPB
+#undef SPB2
+    }
     GCNHIP_LAUNCH_CHECK();
+    if (f->n_bwd_split) {
+        spmm_bwd_fold_kernel<<<ceil_div((int64_t)f->n_bwd_split * p, 256), 256, 0, c->stream>>>(f->bwd_split, f->n_bwd_split, f->bwd_partials,
+                                                                                                f->bwd_part_ld, dw, ld_dw, p);
+        GCNHIP_LAUNCH_CHECK();
+    }
     return 0;
 }
 

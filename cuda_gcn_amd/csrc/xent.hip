@@ -306,8 +306,8 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
     if (a.n_rows == 0) blocks = 1;                      // a rank that owns no rows still reports zeros
     a.part_f = c->red_f + 2048;
     a.part_i = c->red_i;
-    // the final reduction (and an armed metrics record) ride in the loss launch; GCNHIP_XENT_FINALIZE keeps the second launch
-    const bool two_launches = getenv("GCNHIP_XENT_FINALIZE") != nullptr;
+    // the final reduction (and an armed metrics record) ride in the loss launch; the context option xent_finalize keeps the second launch
+    const bool two_launches = c->opt.xent_finalize != 0;
     a.ticket = two_launches ? nullptr : c->ticket;
     a.res = d_result; a.res_i = d_result_i;
     a.ring = nullptr; a.ring_capacity = 1; a.ring_slot = 0; a.ring_epoch = nullptr; a.ring_sumsq = nullptr;
@@ -328,7 +328,7 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
     }
     // a lane per row when the rows are whole, aligned float4 pieces of at most 64 classes
     const int nv4 = (a.C + 3) / 4;
-    static const bool force_wave = getenv("GCNHIP_XENT_WAVE") != nullptr;     // A/B aid
+    const bool force_wave = c->opt.xent_wave != 0;                            // A/B aid
     const bool lanes = !force_wave && a.C <= 64 && a.n_rows > 0 && a.ld % 4 == 0 && a.ld >= 4 * nv4 && aligned16(a.logits) &&
                        (!a.grad || (a.ld_grad % 4 == 0 && a.ld_grad >= 4 * nv4 && aligned16(a.grad)));
     if (lanes) {

@@ -85,6 +85,15 @@ class Device:
     def sync(self):
         _ck(self.lib, self.lib.gcnhip_ctx_sync(self.ctx), "sync")
 
+    def set_option(self, name: str, value: int):
+        """gcnhip_ctx_set_option: a named option of this context (read by the ops at call time from the context, never from the environment)"""
+        _ck(self.lib, self.lib.gcnhip_ctx_set_option(self.ctx, name.encode(), int(value)), f"gcnhip_ctx_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        _ck(self.lib, self.lib.gcnhip_ctx_get_option(self.ctx, name.encode(), C.byref(v)), f"gcnhip_ctx_get_option({name})")
+        return v.value
+
     def buf(self, arr_or_shape, dtype=np.float32):
         if isinstance(arr_or_shape, np.ndarray):
             return Buf(self, arr_or_shape.shape, arr_or_shape.dtype).upload(arr_or_shape)

@@ -60,6 +60,18 @@ int  gcnhip_ctx_destroy(gcnhip_ctx *ctx);
  * neighbour: measured on the two-stream epoch, 294 epochs/s with the persistent form on the lane against 297 with tiles.
  * Results do not depend on the hint beyond the order of floating-point sums of the two forms (each within the tested bound). */
 int gcnhip_ctx_set_corun(gcnhip_ctx *ctx, int on);
+/* Options of a context, by name (argument error -1 for an unknown name; gcnhip_last_error() says so).  Every option starts
+ * from the environment variable GCNHIP_<NAME IN CAPITALS>, which is read ONCE, when the context is created: no entry point
+ * consults the environment at call time, so a call's behaviour is a function of its arguments and its context.  Most are
+ * A/B aids behind measurements DESIGN.md records; results are the same bits unless the option's line says otherwise:
+ *   gs_u (0: by table size; 1/2/4 row loads in flight per lane group of the aggregation), gs_fold (1: split rows summed inside
+ *   the aggregation launch), gs_pipe, gs_nt (measured-slower aggregation variants), gemm_tiles / gemm_w4 / gemm_persist_bwd
+ *   (first-layer GEMM forms), xent_finalize / adam_sum_launch (final reductions as their own launches), xent_wave,
+ *   atb_cap_mb, rs_wgs, spmm_lds (1: the sparse forward stages W in LDS whenever
+ *   it fits — measured slower, opt-in), spmm_rows (rows per wave of the sparse forward; 0: by row count), spmm_general (1: narrow
+ *   rows take the general sparse kernels too — a differently associated f32 sum), spmm_nw and split_edges (read by gcnhip_feat_create / gcnhip_graph_create*: set them BEFORE building objects). */
+int  gcnhip_ctx_set_option(gcnhip_ctx *ctx, const char *name, int value);
+int  gcnhip_ctx_get_option(const gcnhip_ctx *ctx, const char *name, int *value);
 int  gcnhip_ctx_sync(gcnhip_ctx *ctx);                 /* synchronises the stream */
 void *gcnhip_ctx_stream(gcnhip_ctx *ctx);
 const char *gcnhip_error_string(int code);

@@ -162,7 +162,7 @@ def test_wide_aggregation_on_split_rows_needs_reserve_width(oracle):
 @pytest.mark.parametrize("dim", [128, 41, 256])
 def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
     """split (hub) rows: the wave that finishes a row's last segment adds the partials itself (graphsum.hip, Guideline 16
-    hand-off; opt-in, GCNHIP_GS_FOLD=1).  Same bits as the default graphsum_finalize launch, launch after launch on CHANGING inputs —
+    hand-off; opt-in, context option gs_fold).  Same bits as the default graphsum_finalize launch, launch after launch on CHANGING inputs —
     a partial served from a stale cache line of the previous launch would show here — and with the ReLU+dropout+bits
     epilogue on the same rows"""
     import os
@@ -180,7 +180,6 @@ def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
     g = dev.graph(gp, gi)
     ld = (dim + 15) // 16 * 16
     xin, out = dev.buf(np.zeros((n, ld), np.float32)), dev.buf(np.zeros((n, ld), np.float32))
-    os.environ.pop("GCNHIP_GS_FOLD", None)
     try:
         for it in range(6):
             x = np.zeros((n, ld), np.float32)
@@ -188,10 +187,7 @@ def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
             xin.upload(x)
             got = []
             for two_launch in (False, True, False):
-                if two_launch:
-                    os.environ.pop("GCNHIP_GS_FOLD", None)
-                else:
-                    os.environ["GCNHIP_GS_FOLD"] = "1"
+                dev.set_option("gs_fold", 0 if two_launch else 1)
                 out.upload(np.full((n, ld), 7.0, np.float32))
                 _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim), "graphsum")
                 got.append(out.download()[:, :dim].copy())
@@ -202,9 +198,7 @@ def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
                 ep = dev.buf(np.array([it + 1], np.uint32))
                 eb = []
                 for two_launch in (False, True):
-                    os.environ.pop("GCNHIP_GS_FOLD", None)
-                    if not two_launch:
-                        os.environ["GCNHIP_GS_FOLD"] = "1"
+                    dev.set_option("gs_fold", 0 if two_launch else 1)
                     out.upload(np.full((n, ld), 7.0, np.float32)); bits.upload(np.zeros((n, wpr), np.uint32))
                     _ck(lib, lib.gcnhip_graphsum_relu_dropout_bits(dev.ctx, g.h, xin.ptr, ld, out.ptr, ld, dim, 1, 0.5, 99, ep.ptr, 0, None,
                                                                    bits.ptr, wpr), "graphsum_relu_dropout_bits")
@@ -215,6 +209,6 @@ def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
             if it == 0:
                 close_mag(got[0], oracle.graphsum(gp, gi, x[:, :dim].copy(), dim), oracle.graphsum(gp, gi, np.abs(x[:, :dim]).copy(), dim))
     finally:
-        os.environ.pop("GCNHIP_GS_FOLD", None)
+        dev.set_option("gs_fold", 0)
     g.free()
     dev.close()

@@ -500,6 +500,86 @@ def test_spmm_sparse_vs_oracle(dev, oracle, name, p):
     f.free()
 
 
+def _skewed_sparse_x(rng, n, f, nnz_row, hot_cols, hot_share):
+    """n rows of nnz_row distinct sorted columns, a share of them drawn from the first hot_cols columns: a few very long
+    columns (bag-of-words stop words) beside many short ones, some empty rows and empty columns"""
+    rows = []
+    for i in range(n):
+        if i % 97 == 5:
+            rows.append(np.zeros(0, np.int64))                  # an empty row
+            continue
+        k_hot = int(rng.binomial(nnz_row, hot_share))
+        hot = rng.choice(hot_cols, min(k_hot, hot_cols), replace=False)
+        cold = hot_cols + rng.choice(f - hot_cols - 3, nnz_row - hot.size, replace=False)     # the last 3 columns stay empty
+        rows.append(np.sort(np.concatenate([hot, cold])))
+    fp = np.zeros(n + 1, np.int64)
+    fp[1:] = np.cumsum([r.size for r in rows])
+    return fp.astype(np.int32), np.concatenate(rows).astype(np.int32)
+
+
+@pytest.mark.parametrize("p", [16, 41, 128, 4, 8, 32, 64])
+@pytest.mark.parametrize("nw,general", [(0, -1), (1, -1), (4, -1), (16, -1), (0, 1), (16, 1)])
+def test_spmm_sparse_long_columns_every_task_width(oracle, p, nw, general):
+    """the weight gradient's task list (spmm_sparse.h): columns of 6 000+ entries are cut into segments whose partial rows
+    the fold launch adds in order, the rest are single tasks of 1, 4 or 16 waves (option spmm_nw; 0 = by mean column
+    length) — against the oracle within the summation-order bound, and bit-identical run to run (no atomics)"""
+    from cuda_gcn_amd.ops import Device
+    rng = np.random.default_rng(100 + p)
+    N, F = 9000, 700
+    fp, fi = _skewed_sparse_x(rng, N, F, 24, 4, 0.12)
+    cnt = np.bincount(fi, minlength=F)
+    assert cnt.max() > 4096 and cnt.min() == 0 and cnt[4:].max() < 1024        # cut columns, empty columns, short columns
+    vals = rng.standard_normal(fi.size).astype(np.float32)
+    w = rng.standard_normal((F, p)).astype(np.float32)
+    dout = rng.standard_normal((N, p)).astype(np.float32)
+    d = Device(0)
+    d.set_option("spmm_nw", nw)                                  # read by gcnhip_feat_create
+    d.set_option("spmm_general", general)                        # 1: the shuffle-based kernels for narrow rows too
+    f = d.feat(fp, fi, vals, F)
+    seed, epoch = 5, 2
+    k = philox_keep(seed, epoch, np.arange(fi.size, dtype=np.uint64), thr_of(0.5))
+    vd = (vals * np.where(k, np.float32(2), np.float32(0))).astype(np.float32)
+    for v, kw in ((vals, {}), (vd, dict(p_drop=0.5, seed=seed, epoch=epoch))):
+        a = d.spmm_bwd(f, dout, **kw)
+        close_mag(a, oracle.spmm_bwd(fp, fi, v, dout, F, p), oracle.spmm_bwd(fp, fi, np.abs(v), np.abs(dout), F, p))
+        assert np.all(a[-3:] == 0)                               # empty columns are written (dW is assigned, module.cpp:66)
+        assert np.array_equal(a.view(np.uint32), d.spmm_bwd(f, dout, **kw).view(np.uint32))
+        b = d.spmm_fwd(f, w, **kw)
+        close_mag(b, oracle.spmm_fwd(fp, fi, v, w, p), oracle.spmm_fwd(fp, fi, np.abs(v), np.abs(w), p))
+        assert np.all(b[5] == 0)                                 # an empty row of X
+    f.free()
+    d.close()
+
+
+@pytest.mark.parametrize("name,p", [("pubmed-syn", 16), ("cora-syn", 16), ("cora-syn", 7), ("tiny-syn", 64)])
+def test_spmm_forward_from_lds_gives_the_same_bits(name, p):
+    """W staged in LDS (spmm_csr_fwd_lds_kernel, option spmm_lds = 1) against the general kernel gathering rows from global
+    memory (spmm_general = 1): the same lane groups add the same products in the same order — equal bit for bit, with dropout
+    and with the ReLU epilogue; the default narrow-row kernel associates the sum differently: equal within the f32 bound"""
+    from cuda_gcn_amd.ops import Device
+    ds = datagen.make_dataset(name)
+    fp, fi, F = ds["f_indptr"], ds["f_indices"], ds["input_dim"]
+    rng = np.random.default_rng(p)
+    w = rng.standard_normal((F, p)).astype(np.float32)
+    d = Device(0)
+    f = d.feat(fp, fi, ds["f_val"], F)
+    got = {}
+    for tag, lds, general in (("narrow", 0, -1), ("general", 0, 1), ("lds", 1, 1), ("narrow-lds", 1, -1)):
+        d.set_option("spmm_lds", lds)
+        d.set_option("spmm_general", general)
+        got[tag] = (d.spmm_fwd(f, w), d.spmm_fwd(f, w, p_drop=0.5, seed=3, epoch=9), d.spmm_fwd_relu(f, w))
+    for a, b in zip(got["general"], got["lds"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    mag = np.abs(got["general"][0]).max()
+    for a, b in zip(got["narrow"], got["narrow-lds"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(got["narrow"], got["general"]):
+        assert np.abs(a - b).max() <= 64 * EPS * mag                              # same terms, another association
+    assert mag > 0
+    f.free()
+    d.close()
+
+
 @pytest.mark.parametrize("N,F,p", [(300, 50, 16), (257, 602, 128), (130, 36, 41), (64, 33, 7),
                                    (100100, 70, 128)])    # more row tiles than resident workgroups
 def test_spmm_dense_vs_oracle(dev, oracle, N, F, p):
@@ -707,7 +787,7 @@ def test_xent_vs_oracle(dev, oracle, n, c, ld):
 @pytest.mark.parametrize("n,c,ld", [(153756, 41, 48), (700, 7, 8), (64, 100, 100), (1, 3, 4)])
 def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, ld):
     """the block that finishes last adds the block partials (xent.hip, xent_block_tail): same bits as xent_finalize_kernel
-    (GCNHIP_XENT_FINALIZE=1), launch after launch on changing inputs; the armed metrics row
+    (context option xent_finalize), launch after launch on changing inputs; the armed metrics row
     (gcnhip_metrics_record_with_next_loss) equals what gcnhip_metrics_record copies, once, and does not fire again"""
     import os
     from cuda_gcn_amd.ops import _ck
@@ -726,9 +806,7 @@ def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, 
             lb = dev.padded((rng.standard_normal((n, c)) * 3).astype(np.float32), ld)
             got = []
             for two in (False, True, False):
-                os.environ.pop("GCNHIP_XENT_FINALIZE", None)
-                if two:
-                    os.environ["GCNHIP_XENT_FINALIZE"] = "1"
+                dev.set_option("xent_finalize", 1 if two else 0)
                 res.upload(np.zeros(4, np.float32)); resi.upload(np.zeros(2, np.int32))
                 if it % 2:
                     _ck(lib, lib.gcnhip_xent_fwd_rows(dev.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, rb.ptr, int(rows.size), c, 1, int(rows.size), 0, res.ptr, resi.ptr), "xent rows")
@@ -740,9 +818,7 @@ def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, 
             assert got[0][1][1] == rows.size
             # the armed record, with and without the second launch
             for two in (False, True):
-                os.environ.pop("GCNHIP_XENT_FINALIZE", None)
-                if two:
-                    os.environ["GCNHIP_XENT_FINALIZE"] = "1"
+                dev.set_option("xent_finalize", 1 if two else 0)
                 ring.upload(np.full((4, 4, 8), -1.0, np.float32))
                 _ck(lib, lib.gcnhip_metrics_record_with_next_loss(dev.ctx, ring.ptr, 4, 2, ep.ptr, sq.ptr), "arm")
                 _ck(lib, lib.gcnhip_xent_fwd(dev.ctx, lb.ptr, ld, gb.ptr, ld, tb.ptr, n, c, 1, int(rows.size), 0, res.ptr, resi.ptr), "xent")
@@ -756,11 +832,11 @@ def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, 
                 r = want[6 % 4, 2]
                 assert r[0] == got[0][0][0] and r[2] == got[0][1][0] and r[3] == rows.size and r[4] == 2.5 and r[5] == 6.0
     finally:
-        os.environ.pop("GCNHIP_XENT_FINALIZE", None)
+        dev.set_option("xent_finalize", 0)
 
 
 def test_adam_sum_of_squares_in_the_launch_equals_the_second_launch(dev):
-    """gcnhip_adam_step's sum(w0^2): last-block sum inside the Adam launch == sum_partials_kernel (GCNHIP_ADAM_SUM_LAUNCH=1)"""
+    """gcnhip_adam_step's sum(w0^2): last-block sum inside the Adam launch == sum_partials_kernel (context option adam_sum_launch)"""
     import os
     rng = np.random.default_rng(5)
     try:
@@ -769,15 +845,13 @@ def test_adam_sum_of_squares_in_the_launch_equals_the_second_launch(dev):
             gs = rng.standard_normal((3, n)).astype(np.float32)
             out = []
             for two in (False, True, False):
-                os.environ.pop("GCNHIP_ADAM_SUM_LAUNCH", None)
-                if two:
-                    os.environ["GCNHIP_ADAM_SUM_LAUNCH"] = "1"
+                dev.set_option("adam_sum_launch", 1 if two else 0)
                 (wn,), sq = dev.adam_steps([w], [[g] for g in gs], [1], 0.01, 5e-4)
                 out.append((wn, sq))
             assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] == out[2][1]
             assert abs(out[0][1] - float((out[0][0].astype(np.float64) ** 2).sum())) <= 1e-5 * out[0][1]
     finally:
-        os.environ.pop("GCNHIP_ADAM_SUM_LAUNCH", None)
+        dev.set_option("adam_sum_launch", 0)
 
 
 def test_xent_golden(dev, mods):

@@ -6,11 +6,12 @@ guide asks for on one's own access pattern: TCC_MISS_sum x 128 B (every L2 miss 
 2 x FETCH_SIZE.  `_meta` ties the file to the tree it was taken on (bench.py refuses a profile whose kernel name or
 duration does not match the launch it has just timed).
 
-    python3 tools/pmc_summary.py <dir> [commit] [what was run]
+    python3 tools/pmc_summary.py <dir> [commit] [what was run] [kernel-name substring, default graphsum]
 """
 import collections, csv, glob, json, os, statistics, sys
 
 root = sys.argv[1]
+match = sys.argv[4] if len(sys.argv) > 4 else "graphsum"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 
@@ -28,7 +29,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*_kernel_trace.csv"), recursiv
 out = {"_meta": {"commit": sys.argv[2] if len(sys.argv) > 2 else None, "what": sys.argv[3] if len(sys.argv) > 3 else None,
                  "counters": "median per launch; one rocprofv3 --pmc pass per counter group, --kernel-trace only"}}
 for k, cs in agg.items():
-    if "graphsum" not in k:
+    if match not in k:
         continue
     d = {c: statistics.median(v) for c, v in cs.items()}
     d["launches"] = max(len(v) for v in cs.values())
@@ -40,5 +41,9 @@ for k, cs in agg.items():
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
         if "FETCH_SIZE" in d:
             d["fetch_crosscheck_TCC_MISS_x128_over_2xFETCH_SIZE"] = d["TCC_MISS_sum"] * 128 / (2 * d["FETCH_SIZE"] * 1024)
+    if d.get("SQ_BUSY_CU_CYCLES") and d.get("median_duration_us_under_pmc"):
+        d["clock_GHz_from_busy_cu_cycles"] = d["SQ_BUSY_CU_CYCLES"] / 256.0 / (d["median_duration_us_under_pmc"] * 1e3)
+    if d.get("SQ_WAVE_CYCLES") and d.get("SQ_WAIT_ANY") is not None:
+        d["wave_cycles_waiting_share"] = d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]
     out[k] = d
 print(json.dumps(out, indent=1, sort_keys=True))
