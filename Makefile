@@ -45,6 +45,12 @@ $(BINDIR)/gcn-hip: $(PKG)/host/main.cpp $(HOBJ) $(LIBDIR)/libgcnhip.so
 oracle:
 	$(MAKE) -s -C oracle
 
+# measurement tools that are HIP programs of their own (not part of the product): the gather-ceiling microbenchmark
+tools: build/libgatherpeak.so
+build/libgatherpeak.so: tools/gather_peak.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -shared -fPIC $< -o $@
+
 # CPU sanitizer build of the host logic and the oracle (the GPU box cannot run ASan; the reference has no
 # sanitizer target at all, /root/reference/Makefile:6-7).  `make asan-test` runs the CPU tests of the parser,
 # partition, RNG replay, R-MAT generator, C-ABI tables and the oracle pin against the instrumented libraries.
@@ -66,4 +72,4 @@ clean:
 	rm -rf build $(LIBDIR) $(BINDIR)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all kernels host oracle clean asan asan-test
+.PHONY: all kernels host oracle tools clean asan asan-test

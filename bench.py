@@ -50,8 +50,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
 L2_AGG_GBPS = 34500.0         # "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
 MALL_GATHER_GBPS = 8600.0     # "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache: 33.5 GB/s per CU = 8.6 TB/s
-PMC_FILES = ["r03_graphsum_pmc.json", "r02_graphsum_pmc.json"]           # newest first (profiles/)
-PMC_RMAT_FILES = ["r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
+PMC_FILES = ["r04_graphsum_pmc.json", "r03_graphsum_pmc.json", "r02_graphsum_pmc.json"]           # newest first (profiles/)
+PMC_RMAT_FILES = ["r04_graphsum_pmc_rmat.json", "r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
+PMC_RMAT22_FILES = ["r04_graphsum_pmc_rmat22.json"]                      # the in-model launch of BASELINE configs[4] (scale 22, 2 GiB table)
+GATHER_PEAK_FILES = ["r04_gather_peak.json"]                             # measured ceiling of the cache-regime gather (tools/gather_peak.py)
 GS_KERNEL = "graphsum_vec_kernel<16, 4, true, false>"       # the hidden-width launch on a cache-resident table (graphsum.hip, launch_vec)
 GS_KERNEL_HBM = "graphsum_vec_kernel<16, 2, true, false>"   # ... past the Infinity Cache (two row loads in flight)
 
@@ -247,6 +249,20 @@ def _pmc(files, kernel, avg_launch_ms=None, tol=0.10):
         k = dict(k, commit=doc.get("_meta", {}).get("commit"), duration_checked=bool(avg_launch_ms is not None and ref_us))
         return k, "profiles/" + f, None
     return None, None, why
+
+
+def measured_gather_ceiling(dataset, dim):
+    """GB/s of the best gather+sum+store microbenchmark on this dataset's own index stream, task order and XCD slicing
+    (tools/gather_peak.hip, swept over loads in flight and resident waves; profiles/r04_gather_peak.json) -> (GB/s, source, entry)"""
+    for f in GATHER_PEAK_FILES:
+        p = os.path.join(ROOT, "profiles", f)
+        if not os.path.exists(p):
+            continue
+        doc = json.load(open(p))
+        key = f"d={dim}"
+        if doc.get("dataset") == dataset and key in doc.get("ceiling_GBps", {}):
+            return doc["ceiling_GBps"][key], "profiles/" + f, doc
+    return None, None, None
 
 
 def hbm_regime_leg(scale, dim, device, launches=10):
@@ -482,7 +498,7 @@ def main():
         algorithmic = bytes_per_launch / avg_s / 1e9
         gathered = ib * info["local_edges"] * d_eff / avg_s / 1e9
         kernel = ("graphsum_bf16_kernel<16> (bf16 table; timer includes the f32->bf16 conversion)" if args.bf16_tables else
-                  f"{GS_KERNEL}, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
+                  f"{GS_KERNEL if ds['num_nodes'] * args.hidden * 4 <= 256 * 2**20 else GS_KERNEL_HBM}, 64-float column slices per XCD group (GraphSum d={args.hidden})" if args.hidden > 64 else
                   f"graphsum_vec_kernel (GraphSum, d={args.hidden} and d={ds['output_dim']} launches averaged)")
         if overlap_on and args.hidden > 64:
             kernel += "; --overlap on: a launch pair per aggregation (own-column edges, then the rest), timed together incl. any exposed wait for the exchange"
@@ -492,26 +508,44 @@ def main():
         pmc, pmc_src, pmc_why = (None, None, "no PMC profile is committed for this configuration")
         if args.dataset == "reddit-syn" and args.hidden == 128 and not args.bf16_tables and not args.no_row_groups and world == 1:
             pmc, pmc_src, pmc_why = _pmc(PMC_FILES, GS_KERNEL, 1e3 * avg_s)
+        elif args.dataset.startswith("rmat-22") and args.hidden == 128 and not args.bf16_tables and world == 1:
+            pmc, pmc_src, pmc_why = _pmc(PMC_RMAT22_FILES, GS_KERNEL_HBM, 1e3 * avg_s, tol=0.15)      # BASELINE configs[4]'s own launch
         traffic = pmc.get("traffic_bytes_per_launch") if pmc else None
         cache_resident = table_mb * 1e6 <= 256 * 2**20
+        ceil_gbps, ceil_src, ceil_doc = (None, None, None)
+        if cache_resident and world == 1 and not args.bf16_tables and not args.no_row_groups and args.hidden > 64:
+            ceil_gbps, ceil_src, ceil_doc = measured_gather_ceiling(args.dataset, args.hidden)
+        guide = None
         if cache_resident and pmc and "traffic_bytes_per_launch" in pmc:
-            # The gathered table sits in the Infinity Cache: HBM is not what bounds the kernel (B_gs / t exceeds the HBM
-            # peak).  Two resources do: every gathered byte crosses an XCD's L2 (34.5 TB/s aggregate, MI355X_MICROARCH.md
-            # "L2"), and the bytes that miss L2 (PMC: 2*FETCH_SIZE + WRITE_SIZE per launch) come from the Infinity Cache,
-            # for which the highest row-gather rate the guide RECORDS is 8.6 TB/s ("Indexed rows", 38 MB table; the guide
-            # labels its per-CU rates lower bounds, so this is the best gather rate on record, not a hardware limit).  The
-            # launch cannot be shorter than the longer of the two transfers; peak = gathered bytes / that floor.
+            # The guide-derived two-resource ceiling of rounds 2-3, kept as `frac_vs_guide`: every gathered byte crosses an XCD's
+            # L2 (34.5 TB/s aggregate, MI355X_MICROARCH.md "L2") and the bytes that miss it (PMC: 2*FETCH_SIZE + WRITE_SIZE per
+            # launch) come from the Infinity Cache, for which the best row-gather rate the guide RECORDS is 8.6 TB/s.
             gathered_bytes = ib * info["local_edges"] * d_eff
             fabric = pmc["traffic_bytes_per_launch"]
             t_l2, t_fabric = gathered_bytes / (L2_AGG_GBPS * 1e9), fabric / (MALL_GATHER_GBPS * 1e9)
-            t_floor = max(t_l2, t_fabric)
-            peak = gathered_bytes / t_floor / 1e9
-            roof = {"bound": "cache-gather", "kernel": kernel, "achieved": gathered, "peak": peak, "unit": "GB/s", "frac": gathered / peak,
+            guide = {"peak": gathered_bytes / max(t_l2, t_fabric) / 1e9, "floor_ms_l2": 1e3 * t_l2, "floor_ms_infinity_cache": 1e3 * t_fabric}
+        if ceil_gbps:
+            # The table sits in the Infinity Cache: HBM is not what bounds the kernel (B_gs / t exceeds the HBM peak).  The ceiling is
+            # MEASURED on this chip: the best rate of a kernel that only gathers, sums and stores — no coefficient stream, no multiply, no
+            # epilogue — on this dataset's own index stream, task order and XCD slicing, swept over loads in flight and resident waves.
+            roof = {"bound": "cache-gather", "kernel": kernel, "achieved": gathered, "peak": ceil_gbps, "unit": "GB/s", "frac": gathered / ceil_gbps,
+                    "traffic": traffic, "l2_hit_rate": pmc.get("l2_hit_rate") if pmc else None,
+                    "peak_source": ceil_src, "peak_without_store": ceil_doc.get("ceiling_without_store_GBps", {}).get(f"d={args.hidden}"),
+                    "peak_uniform_random_rows": ceil_doc.get("ceiling_uniform_random_GBps", {}).get(f"d={args.hidden}"),
+                    "frac_vs_guide": gathered / guide["peak"] if guide else None, "peak_guide": guide["peak"] if guide else None,
+                    "floor_ms_l2": guide["floor_ms_l2"] if guide else None, "floor_ms_infinity_cache": guide["floor_ms_infinity_cache"] if guide else None,
+                    "what": "achieved = gathered neighbour-row bytes (4*nnz*d) / HIP-event launch time; peak = the same bytes per second of the best "
+                            f"gather+sum+store microbenchmark on this dataset's own index stream, row schedule and XCD slicing ({ceil_src}: "
+                            "tools/gather_peak.hip swept over 1-8 row loads in flight and 4-8 waves per SIMD on this chip).  frac_vs_guide keeps "
+                            "rounds 2-3's ceiling assembled from MI355X_MICROARCH.md figures (34.5 TB/s L2, 8.6 TB/s Infinity-Cache gather)"}
+        elif guide:
+            roof = {"bound": "cache-gather", "kernel": kernel, "achieved": gathered, "peak": guide["peak"], "unit": "GB/s", "frac": gathered / guide["peak"],
                     "traffic": traffic, "l2_hit_rate": pmc.get("l2_hit_rate"),
-                    "floor_ms_l2": 1e3 * t_l2, "floor_ms_infinity_cache": 1e3 * t_fabric,
+                    "floor_ms_l2": guide["floor_ms_l2"], "floor_ms_infinity_cache": guide["floor_ms_infinity_cache"],
                     "what": "achieved = gathered neighbour-row bytes (4*nnz*d) / HIP-event launch time; peak = the same bytes / max(bytes / 34.5 TB/s "
                             "L2 aggregate, PMC fabric bytes / 8.6 TB/s) - 8.6 TB/s is the best Infinity-Cache row-gather rate MI355X_MICROARCH.md records "
-                            "('Indexed rows', per-CU rates labelled lower bounds): a fraction of the best rate on record, not of a hardware limit"}
+                            "('Indexed rows', per-CU rates labelled lower bounds): a fraction of the best rate on record, not of a hardware limit "
+                            "(no measured ceiling is committed for this configuration: tools/gather_peak.py)"}
         else:
             roof = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": algorithmic / HBM_PEAK_GBPS, "traffic": traffic,

@@ -1,0 +1,173 @@
+// gather_peak.hip — what can a row gather deliver on THIS chip, for THIS table and THIS index stream?
+//
+// The aggregation (csrc/graphsum.hip; reference: src/seq/module.cpp:83-119) is bound by gathering one d-float row per edge.
+// For a table that sits in the Infinity Cache (reddit-syn: 119 MB at d = 128, 45 MB at 48-float rows) no datasheet number is
+// its ceiling, and until round 3 bench.py priced the kernel against a figure assembled from MI355X_MICROARCH.md (8.6 TB/s,
+// which the guide itself calls the best rate on record for a 38 MB uniformly random gather, not a limit).  This tool
+// MEASURES the ceiling: a kernel with graphsum_vec_kernel's memory behaviour and nothing else —
+//   * one wave per task (row, or <= 1024-edge segment), 4 tasks per workgroup, tasks dealt to the 8 XCDs in contiguous
+//     equal-work ranges, 256-byte column slices bound to XCD groups (blockIdx % 8) exactly as the product kernel does;
+//   * 64 indices per coalesced load, handed to lane groups by shuffle; U row loads of 16 bytes per lane in flight;
+//   * NO coefficient stream, NO multiply, no epilogue: the only arithmetic is the sum that keeps the loads alive, and the
+//     result row is stored only when `store` is set;
+// swept over U, resident waves per SIMD (capped with a dummy LDS allocation) and the index stream: the caller passes the
+// product's own task list and index array (reddit-syn in its label-major schedule) or a uniformly random one.
+// Built as a small shared library driven by tools/gather_peak.py (ctypes); nothing here is part of the product.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <algorithm>
+#include <vector>
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "gather_peak: %s at %d\n", hipGetErrorString(_e), __LINE__); return -1; } } while (0)
+
+struct GpArgs {
+    const int2 *tasks;       // {e_begin, e_end}
+    const int *task_row;
+    const int *indices;
+    const float *table;
+    float *out;
+    int ld, dim, n_slices, store;
+    int bounds[9];
+};
+
+template <int U>
+__global__ __launch_bounds__(256) void gather_peak_kernel(GpArgs a) {
+    extern __shared__ float pad[];                      // occupancy cap only
+    constexpr int L = 16, G = 4;
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int cslice = a.n_slices > 1 ? xcd % a.n_slices : 0;
+    const int g_id = a.n_slices > 1 ? xcd / a.n_slices : xcd;
+    const int t = a.bounds[g_id] + q * 4 + (threadIdx.x >> 6);
+    if (t >= a.bounds[g_id + 1]) return;
+    const int2 tk = a.tasks[t];
+    const int g = lane / L, l = lane % L;
+    const int col0 = (cslice * L + l) * 4;
+    const float *in = a.table + (col0 < a.dim ? col0 : 0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = tk.x; base < tk.y; base += 64) {
+        const int cnt = min(64, tk.y - base);
+        const int my_idx = lane < cnt ? a.indices[base + lane] : a.indices[base];
+        const int iters = (cnt + G - 1) / G;
+        for (int k = 0; k < iters; k += U) {            // idle lanes re-read the chunk's first row (the product kernel's tail does the same)
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int src = (k + u) * G + g;
+                const int j = __shfl(my_idx, src < cnt ? src : 0, 64);
+                v[u] = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+#pragma unroll
+    for (int m = L; m < 64; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, 64); acc.y += __shfl_xor(acc.y, m, 64);
+        acc.z += __shfl_xor(acc.z, m, 64); acc.w += __shfl_xor(acc.w, m, 64);
+    }
+    // the sum must be observable; with store == 0 the branch is never taken at run time (finite inputs), so nothing is written
+    if (g == 0 && col0 < a.dim && (a.store || acc.x != acc.x))
+        *reinterpret_cast<float4 *>(a.out + (size_t)a.task_row[t] * a.ld + col0) = acc;
+    if (threadIdx.x == 9999) pad[0] = acc.x;            // (never true: keeps the allocation referenced)
+}
+
+struct Handle {
+    int2 *tasks = nullptr; int *task_row = nullptr; int *indices = nullptr; float *table = nullptr, *out = nullptr;
+    int n_tasks = 0; long nnz = 0; size_t table_floats = 0;
+    std::vector<int2> h_tasks;
+    int n_cu = 256;
+};
+
+extern "C" {
+
+// tasks in the order the product would run them; indices as the product stores them
+int gp_create(void **out, const int *h_e0, const int *h_e1, const int *h_row, int n_tasks, const int *h_indices, long nnz, long table_floats) {
+    Handle *h = new Handle();
+    h->n_tasks = n_tasks; h->nnz = nnz; h->table_floats = (size_t)table_floats;
+    h->h_tasks.resize(n_tasks);
+    for (int i = 0; i < n_tasks; i++) h->h_tasks[i] = make_int2(h_e0[i], h_e1[i]);
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    h->n_cu = prop.multiProcessorCount;
+    CK(hipMalloc((void **)&h->tasks, (size_t)n_tasks * sizeof(int2)));
+    CK(hipMalloc((void **)&h->task_row, (size_t)n_tasks * sizeof(int)));
+    CK(hipMalloc((void **)&h->indices, (size_t)nnz * sizeof(int)));
+    CK(hipMalloc((void **)&h->table, h->table_floats * sizeof(float)));
+    CK(hipMalloc((void **)&h->out, h->table_floats * sizeof(float)));
+    CK(hipMemcpy(h->tasks, h->h_tasks.data(), (size_t)n_tasks * sizeof(int2), hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->task_row, h_row, (size_t)n_tasks * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<float> ones(h->table_floats, 1.0f);
+    CK(hipMemcpy(h->table, ones.data(), h->table_floats * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemset(h->out, 0, h->table_floats * sizeof(float)));
+    *out = h;
+    return 0;
+}
+
+int gp_destroy(void *p) {
+    Handle *h = (Handle *)p;
+    if (!h) return 0;
+    hipFree(h->tasks); hipFree(h->task_row); hipFree(h->indices); hipFree(h->table); hipFree(h->out);
+    delete h;
+    return 0;
+}
+
+// one configuration: average launch time over `iters` launches (after 2 warm-up launches), HIP events on the null stream
+int gp_run(void *p, int ld, int dim, int U, int waves_per_simd, int store, int iters, float *ms_out) {
+    Handle *h = (Handle *)p;
+    if (!h || (size_t)ld * 1 > h->table_floats) return -1;
+    GpArgs a;
+    a.tasks = h->tasks; a.task_row = h->task_row; a.indices = h->indices; a.table = h->table; a.out = h->out;
+    a.ld = ld; a.dim = dim; a.store = store;
+    const int ychunks = (dim + 63) / 64;
+    a.n_slices = (ychunks > 1 && 8 % ychunks == 0) ? ychunks : 1;
+    if (ychunks > 1 && a.n_slices == 1) return -1;      // only the shapes the product slices (d = 128, 256) or single-slice rows
+    const int groups = 8 / a.n_slices;
+    // equal-work contiguous task ranges per XCD group, each starting on a multiple of 4 tasks (csrc/ctx.hip, xcd_bounds)
+    std::vector<int64_t> prefix((size_t)h->n_tasks + 1, 0);
+    for (int t = 0; t < h->n_tasks; t++) prefix[t + 1] = prefix[t] + (h->h_tasks[t].y - h->h_tasks[t].x) + 8;
+    a.bounds[0] = 0;
+    for (int k = 1; k < groups; k++) {
+        int t = (int)(std::lower_bound(prefix.begin(), prefix.end(), prefix[h->n_tasks] * k / groups) - prefix.begin());
+        t = std::min(h->n_tasks, (t + 3) / 4 * 4);
+        a.bounds[k] = std::max(t, a.bounds[k - 1]);
+    }
+    for (int k = groups; k <= 8; k++) a.bounds[k] = h->n_tasks;
+    int max_blocks = 1;
+    for (int k = 0; k < groups; k++) max_blocks = std::max(max_blocks, (a.bounds[k + 1] - a.bounds[k] + 3) / 4);
+    const dim3 grid(max_blocks * 8);
+    size_t lds = 0;
+    if (waves_per_simd > 0 && waves_per_simd < 8) lds = (size_t)(160 * 1024 / waves_per_simd) - 1024;
+    auto launch = [&]() {
+        switch (U) {
+            case 1: hipLaunchKernelGGL(gather_peak_kernel<1>, grid, dim3(256), lds, 0, a); break;
+            case 2: hipLaunchKernelGGL(gather_peak_kernel<2>, grid, dim3(256), lds, 0, a); break;
+            case 4: hipLaunchKernelGGL(gather_peak_kernel<4>, grid, dim3(256), lds, 0, a); break;
+            default: hipLaunchKernelGGL(gather_peak_kernel<8>, grid, dim3(256), lds, 0, a); break;
+        }
+    };
+    if (lds > 64 * 1024) {
+        CK(hipFuncSetAttribute((const void *)gather_peak_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void *)gather_peak_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void *)gather_peak_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void *)gather_peak_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; i++) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return 0;
+}
+
+}  // extern "C"
