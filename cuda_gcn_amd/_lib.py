@@ -201,6 +201,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_dataset_free": (I, [P]),
     "gcnhost_rccl_selftest": (I, [I]),
     "gcnhost_rccl_selftest_world": (I, [I, I, I, C.c_char_p]),
+    "gcnhost_rccl_collective_us": (I, [I, I, I, C.c_char_p, C.c_long, C.c_long, I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gcnhost_halo_selftest_host": (I, [I, I, I, ALLGATHER_FN, ALLREDUCE_FN, P]),
     "gcnhost_partition": (I, [P, I, I, P, C.POINTER(I)]),
     "gcnhost_local_graph": (I, [P, P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),

@@ -15,8 +15,11 @@
 //    chunk travelling through the same ring.
 // Exact f32 (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  Within an 8-wide k group the forward visits k in the order
 // 0,4,1,5,2,6,3,7 (a lane's 16-byte LDS read supplies four MFMA steps); dense_tile128.h's forward kernels walk their LDS
-// tiles in the same order (T_KO), so both forms give the same bits (tests/test_ops_gpu.py,
-// test_dense_forward_persistent_and_tile_kernels_give_the_same_bits) — the validation lane launches the tile kernel.
+// tiles in the same order (T_KO), so both forms give the same bits WITHOUT dropout and at dropout 0.5 (scale 2 is exact
+// in either operand); at any other dropout rate this form multiplies (x . m) by (scale * w) where the tiles multiply
+// (x * scale) by w — one rounding apart per product, tested at 0.3 with that tolerance (tests/test_ops_gpu.py,
+// test_dense_forward_persistent_and_tile_kernels_give_the_same_bits).  The validation lane launches the tile kernel, and an
+// evaluation forward has no dropout: the two-stream epoch reproduces the one-stream epoch's validation losses exactly.
 #pragma once
 #include "dense_tile128.h"
 

@@ -169,13 +169,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         __shared__ int sh_last;
         if (threadIdx.x == 0) {
             __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // release / acquire: see xent_block_tail
             sh_last = prev == gridDim.x - 1;
             if (sh_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (!sh_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float acc = 0.f;
         for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float tot = block_sum(acc, sh);

@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         const int2 info = a.slot_info[slot];
         uint32_t *cnt = a.seg_count + (size_t)info.x * 8 + cslice;
         unsigned prev = 0;
-        if (lane == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (the write-through store + drain above
+                                                                                                              //  make the release cheap: nothing of this wave is left dirty)
         prev = __builtin_amdgcn_readfirstlane(prev);
         if ((int)prev != info.y - 1) return;                // other segments of this row are still on their way
         if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it

@@ -53,13 +53,15 @@ __device__ inline void xent_block_tail(const XentArgs &a, float bl, int bc, int 
         __hip_atomic_store(a.part_f + blockIdx.x, bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.part_i + blockIdx.x * 2, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.part_i + blockIdx.x * 2 + 1, bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // RELEASE on the ticket (the partial stores above happen-before whoever reads the ticket's last value) and an
+        // ACQUIRE fence in the reader below: the hand-off rests on the memory model, not on the vmcnt ordering of gfx9
+        const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         sh_last = prev == gridDim.x - 1;
         if (sh_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it
     }
     __syncthreads();
     if (!sh_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float l = 0.f;
     int c = 0, t = 0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {

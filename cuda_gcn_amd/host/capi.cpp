@@ -294,6 +294,44 @@ int gcnhost_halo_selftest_host(int device, int rank, int world, gcnhost_allgathe
     })
 }
 
+// Device time per collective on the stream, HIP events around `iters` back-to-back calls (after two warm-up calls): the
+// in-place all-gather of `block_floats` floats per rank and the all-reduce of `reduce_floats` floats, as the epoch issues
+// them.  With one rank (what a single-GPU box can run) this is the launch + kernel floor of a collective — a LOWER bound on
+// what a peer adds; tools/comm_model.py takes it instead of an assumed latency.
+int gcnhost_rccl_collective_us(int device, int rank, int world, const char *nccl_id, long block_floats, long reduce_floats, int iters,
+                               double *us_allgather, double *us_allreduce) {
+    if (world < 1 || rank < 0 || rank >= world || !nccl_id || block_floats < 1 || reduce_floats < 1 || iters < 1) { g_err = "bad arguments"; return -1; }
+    API_TRY({
+        gcnhip_ctx *ctx = nullptr;
+        GCNHIP_CHECK(gcnhip_ctx_create(&ctx, device, nullptr));
+        {
+            std::unique_ptr<Comm> comm(make_rccl_comm(ctx, rank, world, nccl_id));
+            void *d = nullptr, *e0 = nullptr, *e1 = nullptr;
+            const size_t n = std::max((size_t)block_floats * world, (size_t)reduce_floats);
+            GCNHIP_CHECK(gcnhip_malloc(ctx, &d, n * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_memset_async(ctx, d, 0, n * sizeof(float)));
+            GCNHIP_CHECK(gcnhip_event_create(&e0));
+            GCNHIP_CHECK(gcnhip_event_create(&e1));
+            float ms = 0.f;
+            for (int which = 0; which < 2; which++) {
+                for (int i = 0; i < 2 + iters; i++) {
+                    if (i == 2) GCNHIP_CHECK(gcnhip_event_record(ctx, e0));
+                    if (which == 0) comm->allgather_rows((float *)d, (size_t)block_floats);
+                    else comm->allreduce_sum((float *)d, (size_t)reduce_floats);
+                }
+                GCNHIP_CHECK(gcnhip_event_record(ctx, e1));
+                GCNHIP_CHECK(gcnhip_event_elapsed_ms(e0, e1, &ms));
+                if (which == 0 && us_allgather) *us_allgather = 1e3 * ms / iters;
+                if (which == 1 && us_allreduce) *us_allreduce = 1e3 * ms / iters;
+            }
+            gcnhip_event_destroy(e0);
+            gcnhip_event_destroy(e1);
+            gcnhip_free(ctx, d);
+        }
+        gcnhip_ctx_destroy(ctx);
+    })
+}
+
 int gcnhost_rccl_selftest(int device) {
     char id[GCN_NCCL_ID_BYTES];
     const int rc = rccl_get_unique_id(id);

@@ -200,7 +200,10 @@ struct HostComm : Comm {
         stage.resize(block * w);
         GCNHIP_CHECK(gcnhip_d2h(ctx, stage.data() + block * r, base + block * r, block * sizeof(float)));
         ag(user, stage.data(), block);
-        GCNHIP_CHECK(gcnhip_h2d(ctx, base, stage.data(), block * w * sizeof(float)));
+        // the other ranks' blocks only: this rank's own block is what it sent, and another stream of this rank may be
+        // reading it right now (the exchange lane runs beside the aggregation of the own columns) — do not rewrite it
+        if (r > 0) GCNHIP_CHECK(gcnhip_h2d(ctx, base, stage.data(), block * r * sizeof(float)));
+        if (r + 1 < w) GCNHIP_CHECK(gcnhip_h2d(ctx, base + block * (r + 1), stage.data() + block * (r + 1), block * (size_t)(w - r - 1) * sizeof(float)));
     }
     // HALO through a host-staged all-gather of whole (padded) blocks: every rank's block reaches the host, the rows
     // of the plan's peer segments are picked from it.  Same table as the point-to-point exchange, so the layout,

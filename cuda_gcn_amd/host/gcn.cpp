@@ -90,7 +90,27 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // ---- node order (several GPUs: by structure when the ids carry no locality), row partition, this rank's slice
     if (getenv("HIPGCN_STRUCTURE_PARTITION")) flags |= HIPGCN_STRUCTURE_PARTITION;
     if (getenv("HIPGCN_ID_PARTITION")) flags |= HIPGCN_ID_PARTITION;
-    if (world > 1 && !(flags & HIPGCN_ID_PARTITION)) renumber_nodes(world);
+    // How remote rows will arrive is decided BEFORE the node order: renumbering exists to turn an all-gather into halo
+    // lists, so a run whose exchange is pinned to the all-gather (the flag, HIPGCN_EXCHANGE=allgather, or the default over
+    // RCCL until the halo exchange has met a peer) keeps its ids — no second host copy of X, no group search, and rows,
+    // dropout decisions and get_var() stay in the dataset's order.
+    int exchange_mode = (flags & HIPGCN_EXCHANGE_HALO) ? 2 : ((flags & HIPGCN_EXCHANGE_ALLGATHER) ? 1 : 0);
+    {
+        const char *e = getenv("HIPGCN_EXCHANGE");
+        if (e) exchange_mode = !strcmp(e, "halo") ? 2 : (!strcmp(e, "allgather") ? 1 : (!strcmp(e, "auto") ? 0 : exchange_mode));
+        // Over RCCL the per-graph decision is opt-in (HIPGCN_EXCHANGE=auto|halo, or the flag): the halo exchange is a grouped
+        // ncclSend/ncclRecv that has run against real peers only in gcnhost_rccl_selftest_world, so an unasked-for run takes
+        // the in-place all-gather.  bench.py's launcher runs that self-test as a throw-away group of ranks and then asks
+        // for `auto`.  (Host-staged transports and tests decide per graph as before.)
+        const bool over_rccl = world > 1 && !opt.comm && !opt.host_allgather && !(flags & HIPGCN_NULL_COMM);
+        if (over_rccl && exchange_mode == 0 && !(e && !strcmp(e, "auto"))) exchange_mode = 1;
+    }
+    // Parity mode (HIPGCN_HOST_MASKS) replays the reference's RNG stream in the DATASET's element order
+    // (host_masks_for_epoch): a renumbered run would hand node k's decisions to another node, so it keeps its ids too
+    // (HIPGCN_STRUCTURE_PARTITION still forces the renumbering; the run is then the parity run of the renumbered dataset).
+    const bool may_renumber = world > 1 && !(flags & HIPGCN_ID_PARTITION) &&
+                              ((flags & HIPGCN_STRUCTURE_PARTITION) || (exchange_mode != 1 && !(flags & HIPGCN_HOST_MASKS)));
+    if (may_renumber) renumber_nodes(world);
     const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
     part = make_partition(gp.data(), N, world);
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
@@ -104,20 +124,9 @@ void HipGCN::init(const HipGCNOptions &opt) {
         StructureGroups sg = structure_groups(gp.data(), gi.data(), N);
         if (sg.useful) { structure_group = std::move(sg.group); structure_n_groups = sg.n_groups; }
     }
-    {
-        int mode = (flags & HIPGCN_EXCHANGE_HALO) ? 2 : ((flags & HIPGCN_EXCHANGE_ALLGATHER) ? 1 : 0);
-        const char *e = getenv("HIPGCN_EXCHANGE");
-        if (e) mode = !strcmp(e, "halo") ? 2 : (!strcmp(e, "allgather") ? 1 : (!strcmp(e, "auto") ? 0 : mode));
-        // Over RCCL the per-graph decision is opt-in (HIPGCN_EXCHANGE=auto|halo, or the flag): the halo exchange is a grouped
-        // ncclSend/ncclRecv that has run against real peers only in gcnhost_rccl_selftest_world, so an unasked-for run takes
-        // the in-place all-gather.  bench.py's launcher runs that self-test as a throw-away group of ranks and then asks
-        // for `auto`.  (Host-staged transports and tests decide per graph as before.)
-        const bool over_rccl = world > 1 && !opt.comm && !opt.host_allgather && !(flags & HIPGCN_NULL_COMM);
-        if (over_rccl && mode == 0 && !(e && !strcmp(e, "auto"))) mode = 1;
-        xplan = make_exchange_plan(gp.data(), gi.data(), N, part, rank, mode);
-        env.plan = &xplan;
-        env.xbuf = &xbuf;
-    }
+    xplan = make_exchange_plan(gp.data(), gi.data(), N, part, rank, exchange_mode);
+    env.plan = &xplan;
+    env.xbuf = &xbuf;
     if (world > 1) {
         const LocalGraph lg = build_table_graph(gp.data(), gi.data(), N, part, xplan);
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
@@ -270,7 +279,9 @@ void HipGCN::init(const HipGCNOptions &opt) {
     if (!(flags & HIPGCN_MASKED_BWD) && n_local > 0)
         GCNHIP_CHECK(gcnhip_graph_create_restricted(env.ctx, &graph_bwd_out, graph, h_train_bits.data()));
     if (getenv("HIPGCN_OVERLAP_EXCHANGE")) flags |= HIPGCN_OVERLAP_EXCHANGE;
-    if ((flags & HIPGCN_OVERLAP_EXCHANGE) && world > 1 && !env.bf16_tables && n_local > 0) build_overlap();
+    // decided from world, flags and the storage format only — the same on every rank: the exchange lane's communicator is
+    // an ncclCommSplit, a collective over the parent; a rank that owns no rows still creates it (and skips only the cuts)
+    if ((flags & HIPGCN_OVERLAP_EXCHANGE) && world > 1 && !env.bf16_tables) build_overlap();
     build_modules();
     if (getenv("HIPGCN_NO_AGG_FIRST_EVAL")) flags |= HIPGCN_NO_AGG_FIRST_EVAL;
     if (!(flags & (HIPGCN_NO_AGG_FIRST_EVAL | HIPGCN_MODULAR)) && gcnhip_feat_is_dense(feat) && n_local > 0) build_agg_first_eval();
@@ -404,6 +415,9 @@ void HipGCN::build_overlap() {
         const bool mine = (int)t >= xplan.own_offset && (int)t < xplan.own_offset + n_local;
         (mine ? own : other)[t >> 5] |= 1u << (t & 31);
     }
+    xlane.reset(new ExchangeLane(env.ctx, device_, env.comm, xplan, (int)xbuf.max_ld_words, timers->enabled));     // collective: every rank
+    env.xlane = xlane.get();
+    if (n_local == 0) return;             // no rows, no operators to cut: the modules see no split_loc and aggregate nothing
     GCNHIP_CHECK(gcnhip_graph_create_restricted(env.ctx, &graph_loc, graph, own.data()));
     GCNHIP_CHECK(gcnhip_graph_create_restricted(env.ctx, &graph_rem, graph, other.data()));
     if (graph_bwd_out) {
@@ -414,8 +428,6 @@ void HipGCN::build_overlap() {
         add_split_rowsets(env.ctx, graph_loc, split_rows_loc);
         add_split_rowsets(env.ctx, graph_rem, split_rows_rem);
     }
-    xlane.reset(new ExchangeLane(env.ctx, device_, env.comm, xplan, (int)xbuf.max_ld_words, timers->enabled));
-    env.xlane = xlane.get();
 }
 
 // hand the halves of the cut operator to an aggregation (output_layer: also the halves of its restricted backward

@@ -176,19 +176,23 @@ void HipGraphSum::forward(bool training) {
                                           training ? env->keep_hidden : nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_FW);
-    } else if (env->xlane && split_loc && !replicated && world > 1) {
-        // exchange on its own stream; meanwhile the edges that point at this rank's own rows, then the others on top
+    } else if (env->xlane && !replicated && world > 1) {
+        // exchange on its own stream; meanwhile the edges that point at this rank's own rows, then the others on top.
+        // (A rank that owns no rows has no operators to cut — split_loc is NULL — but takes part in the exchange all the same:
+        // it runs on the lane's communicator on EVERY rank.)
         void *ev = env->xlane->begin(*env->plan, in->full, in->ld);
         const gcnhip_rowset *rows_loc = fwd_out_rows_loc ? *fwd_out_rows_loc : nullptr, *rows_rem = fwd_out_rows_rem ? *fwd_out_rows_rem : nullptr;
         const bool fused = fused_relu_dropout >= 0.f;
         env->timers->start(TMR_GRAPHSUM_FW);
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_loc, rows_loc, in->full, in->ld, out->data, out->ld, dim, nullptr, 0,
-                                          0, 0, 0.f, 0, nullptr, 0, nullptr));
+        if (split_loc)
+            GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_loc, rows_loc, in->full, in->ld, out->data, out->ld, dim, nullptr, 0,
+                                              0, 0, 0.f, 0, nullptr, 0, nullptr));
         env->xlane->wait(ev);
-        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_rem, rows_rem, in->full, in->ld, out->data, out->ld, dim, nullptr, 1,
-                                          fused ? 1 : 0, training ? 1 : 0, fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT,
-                                          env->d_epoch, elem_offset, training ? env->keep_hidden : nullptr));
+        if (split_loc)
+            GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_rem, rows_rem, in->full, in->ld, out->data, out->ld, dim, nullptr, 1,
+                                              fused ? 1 : 0, training ? 1 : 0, fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT,
+                                              env->d_epoch, elem_offset, training ? env->keep_hidden : nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_FW);
     } else {
@@ -262,15 +266,15 @@ void HipGraphSum::backward() {
         env->timers->stop(TMR_GRAPHSUM_BW);
         return;
     }
-    if (world > 1 && !out_grad_complete && env->xlane && split_loc) {
+    if (world > 1 && !out_grad_complete && env->xlane) {
         const gcnhip_graph *loc = bwd_split_loc ? bwd_split_loc : split_loc, *rem = bwd_split_rem ? bwd_split_rem : split_rem;
         const uint32_t *bits = bwd_split_loc ? nullptr : row_bits;      // the restricted operators have lost the known-zero rows already
         void *ev = env->xlane->begin(*env->plan, out->full_grad, out->ld);
         env->timers->start(TMR_GRAPHSUM_BW);
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, loc, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 0, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        if (loc) GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, loc, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 0, 0, 0, 0.f, 0, nullptr, 0, nullptr));
         env->xlane->wait(ev);
-        GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, rem, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 1, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        if (rem) GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, rem, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 1, 0, 0, 0.f, 0, nullptr, 0, nullptr));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_BW);
         return;

@@ -136,6 +136,10 @@ int gcnhost_rccl_selftest(int device);
  * in-place all-gather of distinct blocks, all-reduce, the halo exchange (an ExchangePlan's send lists moved by grouped
  * ncclSend/ncclRecv, every table row checked), split communicator, alternating lanes — values checked */
 int gcnhost_rccl_selftest_world(int device, int rank, int world, const char *nccl_id);
+/* device time (microseconds, HIP events) per in-place all-gather of block_floats floats per rank and per all-reduce of
+ * reduce_floats floats, back to back on the stream; with world == 1 the launch + kernel floor of a collective */
+int gcnhost_rccl_collective_us(int device, int rank, int world, const char *nccl_id, long block_floats, long reduce_floats, int iters,
+                               double *us_allgather, double *us_allreduce);
 /* the halo round trip of that self-test through the host-staged transport (the callbacks of gcnhost_model_create) */
 int gcnhost_halo_selftest_host(int device, int rank, int world, gcnhost_allgather_fn host_allgather,
                                gcnhost_allreduce_fn host_allreduce, void *host_user);

@@ -218,6 +218,26 @@ def test_structure_partition_shuffled_communities(world, dropout, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,flags", [(4, 2), (3, 2 | OVERLAP), (4, 2 | 16384)])
+def test_host_masks_keep_the_dataset_order_on_a_graph_that_would_be_renumbered(world, flags):
+    """parity mode (HOST_MASKS = 2) on the shuffled-communities graph, whose ids would otherwise be renumbered by structure:
+    the reference's dropout stream is replayed in the DATASET's element order, so the run keeps its ids (as does a run whose
+    exchange is pinned to the all-gather, 16384) and follows the CPU oracle on the dataset as given"""
+    from cuda_gcn_amd import datagen
+    from oracle.pyoracle import Oracle
+    from tests.mr_threads import run_ranks
+    ds = datagen.planted_communities()
+    epochs, hidden = 8, 16
+    got = run_ranks(ds, world, flags, epochs, hidden, 0.5, seed=3)
+    assert not got["renumbered"]
+    o = Oracle().model(ds, seed_time=3, hidden_dim=hidden, dropout=0.5)
+    want = np.array([o.train_epoch() + o.eval(2) for _ in range(epochs)], np.float32)
+    o.close()
+    assert np.abs(got["trace"][:, [0, 2]] - want[:, [0, 2]]).max() <= 2e-4, np.abs(got["trace"] - want).max(axis=0)
+    assert np.abs(got["trace"][:, [1, 3]] - want[:, [1, 3]]).max() <= 0.005
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_round_trip_selftest_host_transport(world):
     """the halo part of gcnhost_rccl_selftest_world (synthetic plan, pack kernel, per-peer segments, every table row

@@ -627,6 +627,13 @@ def test_dense_forward_persistent_and_tile_kernels_give_the_same_bits(dev, N, F)
         for a, b in zip(got[0], got[1]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         assert (got[0][2] >= 0).all() and np.array_equal(got[0][2], np.maximum(got[0][0], 0))
+        # any other dropout rate: the persistent form folds 1/(1-p) into W, the tiles into X — one rounding apart per product
+        odd = {}
+        for corun in (0, 1):
+            _ck(dev.lib, dev.lib.gcnhip_ctx_set_corun(dev.ctx, corun), "gcnhip_ctx_set_corun")
+            odd[corun] = dev.spmm_fwd(f, w, p_drop=0.3, seed=7, epoch=3)
+        mag = np.abs(vals).reshape(N, F) @ np.abs(w) / 0.7
+        assert np.all(np.abs(odd[0].astype(np.float64) - odd[1]) <= 4 * EPS * mag + 1e-30)
     finally:
         dev.lib.gcnhip_ctx_set_corun(dev.ctx, 0)
     f.free()

@@ -36,7 +36,9 @@ def main():
     ap.add_argument("--compute", required=True, help="P:ms,... per-rank compute per epoch (slowest rank, no-op collectives)")
     ap.add_argument("--agg-ms", default="0.75,0.28,0.27,0.10",
                     help="one-GPU times of the aggregations that follow an exchange: hidden fwd, class fwd (train), class bwd, class fwd (validation)")
-    ap.add_argument("--latency-us", type=float, default=20.0)
+    ap.add_argument("--latency-us", type=float, default=20.0,
+                    help="device time per collective; pass the one-rank figure tools/rccl_latency.py measures (a lower bound on what a peer adds)")
+    ap.add_argument("--latency-source", default="assumed", help="text for the report line: where --latency-us came from")
     ap.add_argument("--compute-overlap", default="", help="P:ms,... the same measurement with HIPGCN_OVERLAP_EXCHANGE (RANK_FLAGS=1048576): "
                                                           "the aggregations run as two launches over the cut operators, which has a cost of its own")
     a = ap.parse_args()
@@ -51,7 +53,7 @@ def main():
     N = gp.size - 1
     ldH, ldC, wpr = (a.hidden + 15) // 16 * 16, 48, (a.hidden + 31) // 32
     lat = a.latency_us * 1e-3
-    print(f"{a.dataset}: N={N}, stored edges={gi.size}; link {LINK_GBPS:.0f} GB/s per peer, {a.latency_us:.0f} us per collective (assumed)")
+    print(f"{a.dataset}: N={N}, stored edges={gi.size}; link {LINK_GBPS:.0f} GB/s per peer, {a.latency_us:.1f} us per collective ({a.latency_source})")
     print(f"{'P':>2} {'plan':>9} {'rows/exch':>10} {'MB/epoch':>9} {'own cols':>8} | {'compute':>7} | {'comm direct':>11} {'ring':>6} | "
           f"{'no overlap':>22} | {'overlap':>22}")
     base = comp[1]
