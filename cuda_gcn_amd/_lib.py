@@ -100,6 +100,11 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graphsum_rowset": (I, [P, P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_graphsum_relu_dropout_bits": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P, P, I]),
+    "gcnhip_graphsum_ex": (I, [P, P, P, P, I, P, I, I]),
+    "gcnhip_graph_scales": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]),
+    "gcnhip_feat_scale_rows": (I, [P, P, P]),
+    "gcnhip_xent_fwd_rows_scaled": (I, [P, P, I, P, I, P, P, I, I, I, I, I, P, P, P]),
+    "gcnhip_matmul_bwd_ex": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F, P, I, P]),
     "gcnhip_graphsum_part": (I, [P, P, P, P, I, P, I, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),
     "gcnhip_feat_create_aggregated": (I, [P, C.POINTER(P), P, P]),
@@ -190,6 +195,7 @@ GCNHOST_SYMBOLS = {
     "gcnhost_model_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "gcnhost_model_schedule": (I, [P, C.POINTER(I), C.POINTER(I)]),
     "gcnhost_model_row_ids": (I, [P, P, C.POINTER(I)]),
+    "gcnhost_model_row_scale": (I, [P, P, C.POINTER(I)]),
     "gcnhost_model_get_var": (I, [P, I, I, P, C.POINTER(I), C.POINTER(I)]),
     "gcnhost_model_set_weights": (I, [P, P, P]),
     "gcnhost_model_timer": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),

@@ -90,6 +90,10 @@ struct gcnhip_graph {
     int *indptr;        // [n_rows+1]
     int *indices;       // [nnz]
     float *coef;        // [nnz]
+    // Â = D^-1/2 (A+I) D^-1/2 factored instead of stored per edge (gcnhip_graphsum_ex, scaling != 0):
+    // dinv = (float)(1/sqrt(deg)), dinv2 = (float)(1/deg), deg = the FULL graph's degrees (a restricted object copies its parent's)
+    float *dinv_row, *dinv2_row;   // [n_rows]
+    float *dinv_col, *dinv2_col;   // [n_cols]
     // long-row splitting (rows above SPLIT_EDGES are cut into segments)
     int split_edges_opt; // the creating context's split_edges option (0: by size)
     int n_tasks;        // number of (row, e0, e1) tasks; 0 => one task per row

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <math.h>
 #include <vector>
 #include <algorithm>
 
@@ -432,6 +433,25 @@ static int graph_create_impl(gcnhip_ctx *c, gcnhip_graph *g, const int *h_indptr
     if (d_col_deg) { GCNHIP_TRY(hipFree(d_col_deg)); d_col_deg = nullptr; }
 
     g->h_indptr = new std::vector<int>(h_indptr, h_indptr + n_rows + 1);
+    {   // the factored form of the coefficients: per-row and per-column 1/sqrt(deg) and 1/deg
+        std::vector<float> dr((size_t)std::max(n_rows, 1)), dr2(dr.size()), dc((size_t)std::max(n_cols, 1)), dc2(dc.size());
+        for (int r = 0; r < n_rows; r++) {
+            const double d = (double)std::max(1, h_indptr[r + 1] - h_indptr[r]);
+            dr[r] = (float)(1.0 / sqrt(d)); dr2[r] = (float)(1.0 / d);
+        }
+        for (int j = 0; j < n_cols; j++) {
+            const double d = (double)std::max(1, h_col_deg ? h_col_deg[j] : h_indptr[j + 1] - h_indptr[j]);
+            dc[j] = (float)(1.0 / sqrt(d)); dc2[j] = (float)(1.0 / d);
+        }
+        GCNHIP_TRY(hipMalloc((void **)&g->dinv_row, dr.size() * sizeof(float)));
+        GCNHIP_TRY(hipMalloc((void **)&g->dinv2_row, dr.size() * sizeof(float)));
+        GCNHIP_TRY(hipMalloc((void **)&g->dinv_col, dc.size() * sizeof(float)));
+        GCNHIP_TRY(hipMalloc((void **)&g->dinv2_col, dc.size() * sizeof(float)));
+        GCNHIP_TRY(hipMemcpy(g->dinv_row, dr.data(), dr.size() * sizeof(float), hipMemcpyHostToDevice));
+        GCNHIP_TRY(hipMemcpy(g->dinv2_row, dr2.data(), dr.size() * sizeof(float), hipMemcpyHostToDevice));
+        GCNHIP_TRY(hipMemcpy(g->dinv_col, dc.data(), dc.size() * sizeof(float), hipMemcpyHostToDevice));
+        GCNHIP_TRY(hipMemcpy(g->dinv2_col, dc2.data(), dc.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return build_schedule(g, h_row_group);
 }
 
@@ -471,6 +491,13 @@ int gcnhip_graph_create_restricted(gcnhip_ctx *c, gcnhip_graph **out, const gcnh
     if (w && hipMemcpy(g->indices, idx.data(), w * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(-3);
     if (w && hipMemcpy(g->coef, cf.data(), w * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(-3);
     g->h_indptr = new std::vector<int>(std::move(ip));
+    {   // the parent's scale arrays: degrees of the FULL graph, not of the edges that are left
+        const size_t nr = (size_t)std::max(n_rows, 1) * sizeof(float), nc = (size_t)std::max(parent->n_cols, 1) * sizeof(float);
+        if (hipMalloc((void **)&g->dinv_row, nr) != hipSuccess || hipMalloc((void **)&g->dinv2_row, nr) != hipSuccess ||
+            hipMalloc((void **)&g->dinv_col, nc) != hipSuccess || hipMalloc((void **)&g->dinv2_col, nc) != hipSuccess) return fail(-2);
+        if (hipMemcpy(g->dinv_row, parent->dinv_row, nr, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(g->dinv2_row, parent->dinv2_row, nr, hipMemcpyDeviceToDevice) != hipSuccess ||
+            hipMemcpy(g->dinv_col, parent->dinv_col, nc, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(g->dinv2_col, parent->dinv2_col, nc, hipMemcpyDeviceToDevice) != hipSuccess) return fail(-3);
+    }
     // the parent's current row order (a split row appears once per segment, consecutively)
     std::vector<int> order;
     order.reserve((size_t)n_rows);
@@ -490,6 +517,10 @@ int gcnhip_graph_destroy(gcnhip_ctx *c, gcnhip_graph *g) {
     if (g->indices) hipFree(g->indices);
     if (g->coef) hipFree(g->coef);
     if (g->tmp_col_deg) hipFree(g->tmp_col_deg);
+    if (g->dinv_row) hipFree(g->dinv_row);
+    if (g->dinv2_row) hipFree(g->dinv2_row);
+    if (g->dinv_col) hipFree(g->dinv_col);
+    if (g->dinv2_col) hipFree(g->dinv2_col);
     delete g->h_indptr;
     delete g->h_tasks;
     delete g->h_srows;
@@ -565,6 +596,42 @@ int gcnhip_graph_reserve_width(gcnhip_ctx *c, gcnhip_graph *g, int max_dim) {
     if (g->partials) { GCNHIP_TRY(hipFree(g->partials)); g->partials = nullptr; }
     g->part_ld = want;
     if (g->n_slots) GCNHIP_TRY(hipMalloc((void **)&g->partials, (size_t)g->n_slots * g->part_ld * sizeof(float)));
+    return 0;
+}
+
+int gcnhip_graph_scales(const gcnhip_graph *g, const float **dinv_row, const float **dinv2_row, const float **dinv_col, const float **dinv2_col) {
+    if (!g) return -1;
+    if (dinv_row) *dinv_row = g->dinv_row;
+    if (dinv2_row) *dinv2_row = g->dinv2_row;
+    if (dinv_col) *dinv_col = g->dinv_col;
+    if (dinv2_col) *dinv2_col = g->dinv2_col;
+    return 0;
+}
+
+// values[e] *= scale[row of e]: the feature matrix of the factored first layer, (D^-1/2 X) — see gcnhip_graphsum_ex
+__global__ void feat_scale_rows_kernel(float *vals, float *vals_pad, int ld_pad, const int *indptr, const float *scale, int n_rows, int n_cols, int dense) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float s = scale[r];
+    const int lane = threadIdx.x & 63;
+    for (int e = indptr[r] + lane; e < indptr[r + 1]; e += 64) vals[e] *= s;
+    if (vals_pad && dense)
+        for (int k = lane; k < n_cols; k += 64) vals_pad[(size_t)r * ld_pad + k] *= s;
+}
+__global__ void feat_scale_csc_kernel(float *csc_val, const int *csc_row, const float *scale, int64_t nnz) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) csc_val[q] *= scale[csc_row[q]];
+}
+int gcnhip_feat_scale_rows(gcnhip_ctx *c, gcnhip_feat *f, const float *d_row_scale) {
+    if (!c || !f || !d_row_scale) return -1;
+    if (f->n_rows == 0) return 0;
+    feat_scale_rows_kernel<<<ceil_div(f->n_rows, 4), 256, 0, c->stream>>>(f->values, f->values_pad, f->ld_pad, f->indptr, d_row_scale, f->n_rows, f->n_cols, f->dense ? 1 : 0);
+    GCNHIP_LAUNCH_CHECK();
+    if (f->csc_val && f->nnz) {
+        feat_scale_csc_kernel<<<ceil_div(f->nnz, 256), 256, 0, c->stream>>>(f->csc_val, f->csc_row, d_row_scale, f->nnz);
+        GCNHIP_LAUNCH_CHECK();
+    }
+    GCNHIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -32,6 +32,7 @@ struct RowStreamArgs {
     int m, K, Nc;
     // epilogue: C = H > 0 ? scale*C : 0
     const float *H; int ldh; float scale;
+    const float *rowscale;                      // optional: row r's results are multiplied by scale * rowscale[r] (the factored aggregation's dinv^2)
     const uint32_t *hbits; int wpr;             // alternative mask source: bit (c & 31) of hbits[r*wpr + (c >> 5)] = (H[r,c] > 0)
     int vec_out;                                // C (and H) rows are 16-byte aligned: LDS-staged row stores
     // PACK: rows leave as packed half-row slots (rowpack.h) instead of dense rows; C receives only the rows that do not fit
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
             const int r = tile * 16 + li;
             if (r < a.m) {
                 float *crow = a.C + (size_t)r * a.ldc;
+                const float sc = (FUSE && a.rowscale) ? a.scale * a.rowscale[r] : a.scale;
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
                     const int col = c_base + t * 16 + 4 * kq;
@@ -217,12 +219,12 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                     if constexpr (FUSE && BITS) {             // col % 4 == 0: the quad's four bits sit in one word
                         const uint32_t kb = kbw[t >> 1] >> ((t & 1) * 16 + 4 * kq);
 #pragma unroll
-                        for (int q = 0; q < 4; q++) x[q] = ((kb >> q) & 1u) ? x[q] * a.scale : 0.f;
+                        for (int q = 0; q < 4; q++) x[q] = ((kb >> q) & 1u) ? x[q] * sc : 0.f;
                     }
                     if (a.vec_out && col + 4 <= a.Nc) {
                         if constexpr (FUSE && !BITS) {
-                            x[0] = hq[t].x > 0.f ? x[0] * a.scale : 0.f; x[1] = hq[t].y > 0.f ? x[1] * a.scale : 0.f;
-                            x[2] = hq[t].z > 0.f ? x[2] * a.scale : 0.f; x[3] = hq[t].w > 0.f ? x[3] * a.scale : 0.f;
+                            x[0] = hq[t].x > 0.f ? x[0] * sc : 0.f; x[1] = hq[t].y > 0.f ? x[1] * sc : 0.f;
+                            x[2] = hq[t].z > 0.f ? x[2] * sc : 0.f; x[3] = hq[t].w > 0.f ? x[3] * sc : 0.f;
                         }
                         *reinterpret_cast<float4 *>(crow + col) = make_float4(x[0], x[1], x[2], x[3]);
                     } else {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                         for (int q = 0; q < 4; q++) {           // fully unrolled: x[] stays in registers
                             if (col + q >= a.Nc) continue;
                             float y = x[q];
-                            if constexpr (FUSE && !BITS) y = a.H[(size_t)r * a.ldh + col + q] > 0.f ? y * a.scale : 0.f;
+                            if constexpr (FUSE && !BITS) y = a.H[(size_t)r * a.ldh + col + q] > 0.f ? y * sc : 0.f;
                             crow[col + q] = y;
                         }
                     }
@@ -299,16 +301,17 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                 if (lane < RPP * LPRW && rr < 16 && r < a.m && col < a.Nc) {
                     float4 v = *reinterpret_cast<const float4 *>(&Cs[rr * CLD + cc]);
                     float *cp = a.C + (size_t)r * a.ldc + col;
+                    const float sc = (FUSE && a.rowscale) ? a.scale * a.rowscale[r] : a.scale;
                     if (col + 4 <= a.Nc) {
                         if (FUSE) {
                             if (a.hbits) {                  // col % 4 == 0: the four bits sit in one word
                                 const uint32_t kb = a.hbits[(size_t)r * a.wpr + (col >> 5)] >> (col & 31);
-                                v.x = (kb & 1u) ? v.x * a.scale : 0.f; v.y = (kb & 2u) ? v.y * a.scale : 0.f;
-                                v.z = (kb & 4u) ? v.z * a.scale : 0.f; v.w = (kb & 8u) ? v.w * a.scale : 0.f;
+                                v.x = (kb & 1u) ? v.x * sc : 0.f; v.y = (kb & 2u) ? v.y * sc : 0.f;
+                                v.z = (kb & 4u) ? v.z * sc : 0.f; v.w = (kb & 8u) ? v.w * sc : 0.f;
                             } else {
                                 const float4 h = *reinterpret_cast<const float4 *>(a.H + (size_t)r * a.ldh + col);
-                                v.x = h.x > 0.f ? v.x * a.scale : 0.f; v.y = h.y > 0.f ? v.y * a.scale : 0.f;
-                                v.z = h.z > 0.f ? v.z * a.scale : 0.f; v.w = h.w > 0.f ? v.w * a.scale : 0.f;
+                                v.x = h.x > 0.f ? v.x * sc : 0.f; v.y = h.y > 0.f ? v.y * sc : 0.f;
+                                v.z = h.z > 0.f ? v.z * sc : 0.f; v.w = h.w > 0.f ? v.w * sc : 0.f;
                             }
                         }
                         *reinterpret_cast<float4 *>(cp) = v;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                                 const int cq = col + q;
                                 const bool pos = a.hbits ? ((a.hbits[(size_t)r * a.wpr + (cq >> 5)] >> (cq & 31)) & 1u) != 0
                                                          : a.H[(size_t)r * a.ldh + cq] > 0.f;
-                                y = pos ? y * a.scale : 0.f;
+                                y = pos ? y * sc : 0.f;
                             }
                             cp[q] = y;
                         }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(RowStreamArgs a) {
                     if (FUSE) {
                         const bool pos = a.hbits ? ((a.hbits[(size_t)r * a.wpr + (col >> 5)] >> (col & 31)) & 1u) != 0
                                                  : a.H[(size_t)r * a.ldh + col] > 0.f;
-                        v = pos ? v * a.scale : 0.f;
+                        v = pos ? v * ((a.rowscale ? a.rowscale[r] : 1.f) * a.scale) : 0.f;
                     }
                     a.C[(size_t)r * a.ldc + col] = v;
                 }
@@ -627,8 +630,11 @@ static int launch_atb(gcnhip_ctx *c, const float *A, int lda, const float *Bm, i
 // C[m x Nc] = A[m x K] . Bs  (Bs from B, optionally transposed), optional epilogue
 static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float *B, int ldb, int transB,
                             float *C, int ldc, int m, int K, int Nc, const float *H, int ldh, float scale,
-                            const uint32_t *hbits = nullptr, int wpr = 0, uint32_t *pack_slots = nullptr, int pack_halves = 0) {
+                            const uint32_t *hbits = nullptr, int wpr = 0, uint32_t *pack_slots = nullptr, int pack_halves = 0,
+                            const float *rowscale = nullptr) {
     RowStreamArgs a;
+    a.rowscale = rowscale;
+    if (rowscale && pack_slots) return -1;                       // the packed-row experiment has no row factor
     a.hbits = hbits; a.wpr = wpr;
     a.pack_slots = pack_slots; a.pack_halves = pack_halves;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.transB = transB; a.C = C; a.ldc = ldc;

@@ -59,6 +59,9 @@ struct GsArgs {
     int n_slots_bytes;          // size of `partials` in bytes (buffer descriptor of the write-through stores)
     int accumulate;             // 1: out[r,:] = out[r,:] + sum (the second of two operators that share the rows of `out`:
                                 // the remote-column part of a row-partitioned aggregation, gcnhip_graphsum_part)
+    // factored coefficients (gcnhip_graphsum_ex): coef == NULL -> every edge counts 1 and the row's total is multiplied by
+    // post[row] (NULL: by nothing) before the epilogue.  The input rows then hold dinv(col) * x.
+    const float *post;
 };
 
 __device__ inline bool row_wanted(const GsArgs &a, int row) {
@@ -107,7 +110,9 @@ constexpr int GS_U = 4;        // row loads in flight per lane group when the ta
 // One chunk of <= 64 edges whose (index, coef) pairs sit in the wave's lanes: acc += sum over the chunk, lane group g
 // taking edges g, g + G, ... in order (the order every form of the kernel keeps, so all of them agree bit for bit).
 // NT: the row loads carry the non-temporal hint (the line is not to be kept in L2 / Infinity Cache at the expense of others)
-template <int L, int GS_U, bool NT = false>
+// COEF == false (the factored operator): no coefficient is handed round or multiplied — every real edge counts 1; an edge
+// whose input row is known to be zero arrives with index -1.
+template <int L, int GS_U, bool NT = false, bool COEF = true>
 __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in, int my_idx, float my_c, int cnt, int g, float4 acc) {
     auto ldrow = [&](const float *p) __attribute__((always_inline)) -> float4 {
         if (NT) {
@@ -132,16 +137,17 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
             for (int u = 0; u < GS_U; u++) {
                 const int src = (k + u) * G + g;
                 const int j = __shfl(my_idx, src, WAVE);
-                cc[u] = __shfl(my_c, src, WAVE);
+                if (COEF) cc[u] = __shfl(my_c, src, WAVE);
                 v[u] = ldrow(in + (size_t)j * a.ld_in);
             }
 #pragma unroll
-            for (int u = 0; u < GS_U; u++) acc = f4_fma(cc[u], v[u], acc);
+            for (int u = 0; u < GS_U; u++) acc = COEF ? f4_fma(cc[u], v[u], acc) : f4_add(acc, v[u]);
         }
     }
     // the tail of a row, and rows read through an input mask: the same batches, with the lanes that have no edge
     // (or an edge whose row is known to be zero) reading the chunk's first neighbour instead and keeping their sum
-    const int j_safe = __shfl(my_idx, 0, WAVE);
+    int j_safe = __shfl(my_idx, 0, WAVE);
+    if (!COEF && j_safe < 0) j_safe = 0;               // (the chunk's first edge is itself a known-zero row: any row will do)
     for (; k < iters; k += GS_U) {
         float4 v[GS_U];
         float cc[GS_U];
@@ -150,13 +156,13 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
         for (int u = 0; u < GS_U; u++) {
             const int src = (k + u) * G + g;
             const int j = __shfl(my_idx, src & 63, WAVE);
-            cc[u] = __shfl(my_c, src & 63, WAVE);
-            on[u] = src < cnt && cc[u] != 0.f;         // padded lanes and known-zero rows contribute nothing
+            if (COEF) cc[u] = __shfl(my_c, src & 63, WAVE);
+            on[u] = src < cnt && (COEF ? cc[u] != 0.f : j >= 0);     // padded lanes and known-zero rows contribute nothing
             v[u] = ldrow(in + (size_t)(on[u] ? j : j_safe) * a.ld_in);
         }
 #pragma unroll
         for (int u = 0; u < GS_U; u++) {
-            const float4 n = f4_fma(cc[u], v[u], acc);
+            const float4 n = COEF ? f4_fma(cc[u], v[u], acc) : f4_add(acc, v[u]);
             acc.x = on[u] ? n.x : acc.x; acc.y = on[u] ? n.y : acc.y; acc.z = on[u] ? n.z : acc.z; acc.w = on[u] ? n.w : acc.w;
         }
     }
@@ -166,7 +172,7 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
 // L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
 // SLICED: the launch binds one column slice to each XCD group (it only changes the block -> (tasks, columns) mapping; the
 // flag is a template argument so that profiles name the hidden-width launches apart from the class-width ones).
-template <int L, int U = GS_U, bool SLICED = false, bool NT = false>
+template <int L, int U = GS_U, bool SLICED = false, bool NT = false, bool COEF = true>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         float my_c = 0.f;
         if (lane < cnt) {
             my_idx = a.indices[base + lane];
-            my_c = a.coef[base + lane];                    // > 0 for every real edge
-            if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
+            if (COEF) my_c = a.coef[base + lane];          // > 0 for every real edge
+            if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) { my_c = 0.f; if (!COEF) my_idx = -1; }
         }
-        acc = gather_chunk<L, U, NT>(a, in, my_idx, my_c, cnt, g, acc);
+        acc = gather_chunk<L, U, NT, COEF>(a, in, my_idx, my_c, cnt, g, acc);
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
                 acc = make_float4(x[0], x[1], x[2], x[3]);
             }
         }
+        if (a.post) { const float ps = a.post[row]; acc.x *= ps; acc.y *= ps; acc.z *= ps; acc.w *= ps; }
         if (a.fuse) acc = relu_dropout4(acc, a, row, col0);
         if (col0 + 4 <= a.dim) {
             *reinterpret_cast<float4 *>(o) = acc;
@@ -719,6 +726,7 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
                 if (k + 1 < ns) v += p1;
                 if (k + 2 < ns) v += p2;
             }
+            if (a.post) v *= a.post[row];
             if (a.fuse) {
                 v = v > 0.f ? v : 0.f;
                 if (a.training) {
@@ -755,7 +763,7 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], const gcnhip_ctx *c) {
     // than a wave per task once the row loads are batched (1.15 vs 0.85 ms at Reddit scale): fresh waves arriving in
     // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
     const bool pipe = c->opt.gs_pipe != 0;
-    if (pipe && a.n_tasks && !a.out_bits && !a.accumulate && !a.pos_bits) {
+    if (pipe && a.n_tasks && !a.out_bits && !a.accumulate && !a.pos_bits && a.coef) {
         a.seg_count = nullptr; a.slot_info = nullptr;      // the experiment keeps the finalize launch
         const int per_xcd = std::min(max_blocks, 32 * 8);
         graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
@@ -768,7 +776,17 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], const gcnhip_ctx *c) {
     const int u = force_u ? force_u : (a.table_bytes > ((size_t)256 << 20) ? 2 : 4);
     const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
     const bool nt_all = c->opt.gs_nt != 0;                            // EXPERIMENT: every row load non-temporal
-    if (sliced && nt_all && L == 16) { graphsum_vec_kernel<16, 4, true, true><<<grid, 256, 0, s>>>(a); return; }
+    if (sliced && nt_all && L == 16 && a.coef) { graphsum_vec_kernel<16, 4, true, true><<<grid, 256, 0, s>>>(a); return; }
+    if (!a.coef) {                                          // the factored operator: its own instantiations (no coefficient hand-out)
+        if (sliced) {
+            if (u >= 4) graphsum_vec_kernel<L, 4, true, false, false><<<grid, 256, 0, s>>>(a);
+            else graphsum_vec_kernel<L, 2, true, false, false><<<grid, 256, 0, s>>>(a);
+        } else {
+            if (u >= 4) graphsum_vec_kernel<L, 4, false, false, false><<<grid, 256, 0, s>>>(a);
+            else graphsum_vec_kernel<L, 2, false, false, false><<<grid, 256, 0, s>>>(a);
+        }
+        return;
+    }
     if (sliced) {
         if (u >= 4) graphsum_vec_kernel<L, 4, true><<<grid, 256, 0, s>>>(a);
         else if (u >= 2) graphsum_vec_kernel<L, 2, true><<<grid, 256, 0, s>>>(a);
@@ -788,8 +806,9 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
                          const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr,
-                         const gcnhip_rowset *rs = nullptr, int accumulate = 0, uint32_t *pos_bits = nullptr, int wpr = 0) {
+                         const gcnhip_rowset *rs = nullptr, int accumulate = 0, uint32_t *pos_bits = nullptr, int wpr = 0, int scaling = 0) {
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
+    if (scaling < 0 || scaling > 3) return -1;
     if (accumulate && in_bf) return -1;                     // the bf16 kernel has no accumulating store
     if (rs && rs->owner != g)                                // a subset brings task lists and segment slots of ITS adjacency object
         return gcnhip_fail("gcnhip_graphsum*: the row subset was registered on another adjacency object");
@@ -818,8 +837,15 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.accumulate = accumulate;
     a.pos_bits = pos_bits; a.wpr = wpr;
     a.slot_info = nullptr; a.seg_count = nullptr; a.n_slots_bytes = 0;
+    a.post = nullptr;
     const int nt = a.n_tasks ? a.n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
+    if (scaling) {
+        // the factored operator runs in the 16-byte-row f32 kernel only (what the model's layouts always are)
+        if (in_bf || !vec) return gcnhip_fail("gcnhip_graphsum_ex: scaling != 0 needs f32 rows that are 16-byte aligned (ld % 4 == 0)");
+        a.coef = nullptr;
+        a.post = scaling == 1 ? g->dinv_row : (scaling == 2 ? g->dinv2_row : nullptr);
+    }
     if (pos_bits && !(fuse && !in_bf && vec && dim % 32 == 0 && wpr * 32 >= dim))
         return gcnhip_fail("gcnhip_graphsum_relu_dropout_bits: needs the fused epilogue, 16-byte aligned rows, dim % 32 == 0 and words_per_row * 32 >= dim");
     const int d4 = (dim + 3) / 4;
@@ -921,6 +947,15 @@ int gcnhip_graphsum_part(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_rows
     if (relu_dropout && training && !(p >= 0.f && p < 1.f)) return -1;
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, relu_dropout ? 1 : 0, relu_dropout ? training : 0, relu_dropout ? p : 0.f,
                          seed, d_epoch, elem_offset, keep_mask, in_row_bits, nullptr, nullptr, rows, accumulate ? 1 : 0);
+}
+
+int gcnhip_graphsum_ex(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_gs_opts *o, const float *in, int ld_in, float *out, int ld_out, int dim) {
+    if (!o) return -1;
+    if (o->relu_dropout && o->training && !(o->p >= 0.f && o->p < 1.f)) return -1;
+    if (o->pos_bits && !o->relu_dropout) return -1;
+    return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, o->relu_dropout ? 1 : 0, o->relu_dropout ? o->training : 0, o->relu_dropout ? o->p : 0.f,
+                         o->seed, o->d_epoch, o->elem_offset, o->keep_mask, o->in_row_bits, nullptr, nullptr, o->rows, o->accumulate ? 1 : 0,
+                         o->pos_bits, o->words_per_row, o->scaling);
 }
 
 int gcnhip_rowpack_create(gcnhip_ctx *c, gcnhip_rowpack **out, int rows, int cols) {

@@ -78,6 +78,30 @@ int gcnhip_matmul_bwd_packed(gcnhip_ctx *c, const float *a, int lda, const float
     return launch_rowstream(c, dc, lddc, b, ldb, 1, da_dense, ldda, m, p, n, a, lda, relu_dropout_scale, nullptr, 0, pack->slots, pack->halves);
 }
 
+// Every form of the fused backward behind one call, with an optional factor per row of da (the factored aggregation,
+// gcnhip_graphsum_ex: dH1' = dinv^2 . dH1):  db = a^T . dc when db != NULL (a is then required);
+// da[r, :] = mask . (relu_dropout_scale * da_row_scale[r]) . (dc . b^T)[r, :], mask = pos_bits when given, else a > 0.
+int gcnhip_matmul_bwd_ex(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
+                         const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                         int m, int n, int p, float relu_dropout_scale, const uint32_t *pos_bits, int words_per_row,
+                         const float *d_da_row_scale) {
+    if (!c || !b || !dc || !da || m < 0 || n <= 0 || p <= 0 || ldb < p || lddc < p || ldda < n) return -1;
+    if ((db || !pos_bits) && (!a || lda < n)) return -1;
+    if (db && lddb < p) return -1;
+    if (pos_bits && words_per_row * 32 < n) return -1;
+    if (!(relu_dropout_scale > 0.f)) return -1;
+    if (m == 0) {
+        if (db) for (int j = 0; j < n; j++) GCNHIP_TRY(hipMemsetAsync(db + (size_t)j * lddb, 0, p * sizeof(float), c->stream));
+        return 0;
+    }
+    if (db) {
+        const int rc = launch_atb(c, a, lda, dc, lddc, db, lddb, m, n, p, 0, 0.f, 0, nullptr, 0, nullptr);
+        if (rc) return rc;
+    }
+    return launch_rowstream(c, dc, lddc, b, ldb, 1, da, ldda, m, p, n, pos_bits ? nullptr : a, lda, relu_dropout_scale, pos_bits, words_per_row,
+                            nullptr, 0, d_da_row_scale);
+}
+
 // da for ALL m rows from a bit mask instead of the forward activations (multi-GPU: every rank rebuilds the
 // whole dH1 from the gathered dZ0 and 1 bit per element of H1, instead of gathering dH1 itself)
 int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *c, const float *b, int ldb, const float *dc, int lddc,

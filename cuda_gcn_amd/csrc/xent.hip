@@ -17,6 +17,7 @@ struct XentArgs {
     int count;                 // > 0: known number of labelled rows
     const int32_t *d_count;    // else read here
     const int32_t *rows;       // optional: only these rows (all labelled) are visited, n_rows = their number
+    const float *grad_row_scale; // optional: row r of grad is multiplied by grad_row_scale[r] (the factored aggregation wants dinv . dZ)
     float *part_f;             // [blocks] loss partials
     int32_t *part_i;           // [blocks*2] {correct, total}
     // in-launch final reduction (xent_block_tail): the block that arrives last at `ticket` adds the partials in block order
@@ -53,9 +54,14 @@ __device__ inline void xent_block_tail(const XentArgs &a, float bl, int bc, int 
         __hip_atomic_store(a.part_f + blockIdx.x, bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.part_i + blockIdx.x * 2, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.part_i + blockIdx.x * 2 + 1, bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // RELEASE on the ticket (the partial stores above happen-before whoever reads the ticket's last value) and an
-        // ACQUIRE fence in the reader below: the hand-off rests on the memory model, not on the vmcnt ordering of gfx9
-        const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // The three agent-scope stores above are write-through; the drain below completes them before the ticket is taken,
+        // and the reader starts with an ACQUIRE fence.  A RELEASE on the ticket itself (what the C++ memory model would ask
+        // for; tried in round 4) makes every block write back this XCD's whole dirty L2 — the gradient rows this very
+        // launch has just stored: +17 us per training loss launch at Reddit scale (0.046 -> 0.080 ms per epoch) for an
+        // ordering the write-through stores already give on gfx9.  Adam's hand-off (elementwise.hip), whose launch leaves
+        // ~1 MB dirty, does carry the release.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh_last = prev == gridDim.x - 1;
         if (sh_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it
     }
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void xent_kernel(XentArgs a) {
                 if (j < a.C) {
                     float p = ex[q] / se;              // module.cpp:147
                     if (j == t) p = (float)((double)p - 1.0);
-                    gr[j] = p / cnt;                   // module.cpp:157
+                    gr[j] = a.grad_row_scale ? (p / cnt) * a.grad_row_scale[r] : p / cnt;   // module.cpp:157
                 }
             }
         }
@@ -231,11 +237,12 @@ __global__ __launch_bounds__(256) void xent_lane_kernel(XentArgs a) {
         }
         loss += logf(se) - (tv - mx);                  // module.cpp:143
         if (a.training && gr) {
+            const float gs = a.grad_row_scale ? a.grad_row_scale[r] : 1.f;
 #pragma unroll
             for (int j = 0; j < 4 * NV4; j++) {
                 float p = v[j] / se;                   // module.cpp:147
                 if (j == t) p = (float)((double)p - 1.0);
-                v[j] = j < a.C ? p / cnt : 0.f;        // module.cpp:157; the padding columns stay zero
+                v[j] = j < a.C ? (a.grad_row_scale ? (p / cnt) * gs : p / cnt) : 0.f;        // module.cpp:157; the padding columns stay zero
             }
 #pragma unroll
             for (int k = 0; k < NV4; k++)
@@ -365,13 +372,20 @@ int gcnhip_xent_fwd(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_gr
     a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_rows; a.C = num_classes;
     a.training = training; a.shift = shift_in_place; a.acc_only = 0;
-    a.count = count; a.d_count = nullptr; a.rows = nullptr;
+    a.count = count; a.d_count = nullptr; a.rows = nullptr; a.grad_row_scale = nullptr;
     return xent_launch(c, a, d_result, d_result_i);
 }
 
 int gcnhip_xent_fwd_rows(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_grad,
                          const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
                          int count, int shift_in_place, float *d_result, int32_t *d_result_i) {
+    return gcnhip_xent_fwd_rows_scaled(c, logits, ld, grad, ld_grad, truth, d_rows, n_listed, num_classes, training, count, shift_in_place,
+                                       d_result, d_result_i, nullptr);
+}
+
+int gcnhip_xent_fwd_rows_scaled(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_grad,
+                                const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
+                                int count, int shift_in_place, float *d_result, int32_t *d_result_i, const float *d_grad_row_scale) {
     if (!c || !logits || !truth || !d_result || num_classes <= 0 || ld < num_classes || n_listed < 0 || count <= 0) return -1;
     if (n_listed > 0 && !d_rows) return -1;
     if (training && (!grad || ld_grad < num_classes)) return -1;
@@ -379,7 +393,7 @@ int gcnhip_xent_fwd_rows(gcnhip_ctx *c, float *logits, int ld, float *grad, int 
     a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_listed; a.C = num_classes;
     a.training = training; a.shift = shift_in_place; a.acc_only = 0;
-    a.count = count; a.d_count = nullptr; a.rows = d_rows;
+    a.count = count; a.d_count = nullptr; a.rows = d_rows; a.grad_row_scale = d_grad_row_scale;
     return xent_launch(c, a, d_result, d_result_i);
 }
 
@@ -389,7 +403,7 @@ int gcnhip_accuracy(gcnhip_ctx *c, const float *logits, int ld, const int32_t *t
     XentArgs a;
     a.logits = const_cast<float *>(logits); a.grad = nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = 0; a.n_rows = n_rows; a.C = num_classes;
-    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr; a.rows = nullptr;
+    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr; a.rows = nullptr; a.grad_row_scale = nullptr;
     return xent_launch(c, a, nullptr, d_result_i);
 }
 

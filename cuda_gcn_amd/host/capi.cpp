@@ -119,6 +119,16 @@ int gcnhost_model_row_ids(gcnhost_model *m, int *ids, int *renumbered) {
             for (int r = 0; r < n; r++) ids[r] = order.empty() ? r0 + r : order[(size_t)r0 + r];
     })
 }
+int gcnhost_model_row_scale(gcnhost_model *m, float *dinv, int *factored) {
+    API_TRY({
+        if (factored) *factored = m->gcn->factored() ? 1 : 0;
+        if (dinv) {
+            std::vector<float> v;
+            m->gcn->row_scale(v);
+            if (!v.empty()) memcpy(dinv, v.data(), v.size() * sizeof(float));
+        }
+    })
+}
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups) {
     API_TRY({
         if (mode) *mode = m->gcn->schedule_mode();

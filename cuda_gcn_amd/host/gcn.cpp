@@ -84,6 +84,12 @@ void HipGCN::init(const HipGCNOptions &opt) {
     }
     env.seed = (uint64_t)opt.seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
     env.bf16_tables = (flags & HIPGCN_BF16_TABLES) != 0;
+    // The factored aggregation (gcnhip_graphsum_ex): no per-edge coefficient stream; the gathered matrices are stored
+    // pre-multiplied by dinv of their row (the producers fold the factor into a row-wise epilogue or a value array).  The
+    // fused f32 path only; HIPGCN_EDGE_COEF restores the reference's per-edge coefficients.
+    if (getenv("HIPGCN_EDGE_COEF")) flags |= HIPGCN_EDGE_COEF;
+    if (getenv("HIPGCN_PACKED_DH1")) flags |= HIPGCN_PACKED_DH1;
+    factored_ = !(flags & (HIPGCN_MODULAR | HIPGCN_BF16_TABLES | HIPGCN_PACKED_DH1 | HIPGCN_EDGE_COEF));
     const int world = env.comm->size(), rank = env.comm->rank();
     const int N = params.num_nodes, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
 
@@ -285,6 +291,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
     build_modules();
     if (getenv("HIPGCN_NO_AGG_FIRST_EVAL")) flags |= HIPGCN_NO_AGG_FIRST_EVAL;
     if (!(flags & (HIPGCN_NO_AGG_FIRST_EVAL | HIPGCN_MODULAR)) && gcnhip_feat_is_dense(feat) && n_local > 0) build_agg_first_eval();
+    if (factored_) apply_factored_scales();
     // opt-in everywhere: with several GPUs the lane brings a second communicator and the turnstile, which must be measured
     // on a multi-GPU node before they may become a default there (bench.py tries both schedules)
     if (getenv("HIPGCN_EVAL_LANE")) flags |= HIPGCN_EVAL_LANE;
@@ -303,6 +310,29 @@ void HipGCN::init(const HipGCNOptions &opt) {
     optimizer.reset(new HipAdam());
     optimizer->init(&env, {{W1, true}, {W2, false}}, ap, params.epochs > 0 ? params.epochs + 8 : 8);   // gcn.cpp:62-65
     GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
+}
+
+// The first layer of the factored model multiplies D^-1/2 X (and, for evaluation, D^-1/2 (A^ X)): the factor that the
+// aggregation's input rows must carry rides in the value arrays, so no GEMM or sparse kernel changes, and the weight
+// gradient X'^T . (raw sum) comes out as the reference's X^T . dH0.  Called once, after A^.X has been built from the
+// unscaled X.
+void HipGCN::apply_factored_scales() {
+    const float *dinv_row = nullptr;
+    GCNHIP_CHECK(gcnhip_graph_scales(graph, &dinv_row, nullptr, nullptr, nullptr));
+    GCNHIP_CHECK(gcnhip_feat_scale_rows(env.ctx, feat, dinv_row));
+    if (feat_agg) GCNHIP_CHECK(gcnhip_feat_scale_rows(env.ctx, feat_agg, dinv_row));
+    if (feat_full) {                                           // every row of X on every rank: the global degrees are graph_l1's columns
+        const float *dinv_all = nullptr;
+        GCNHIP_CHECK(gcnhip_graph_scales(graph_l1, nullptr, nullptr, &dinv_all, nullptr));
+        GCNHIP_CHECK(gcnhip_feat_scale_rows(env.ctx, feat_full, dinv_all));
+    }
+}
+
+void HipGCN::row_scale(std::vector<float> &dinv) {
+    dinv.assign((size_t)n_local, 1.f);
+    const float *d = nullptr;
+    GCNHIP_CHECK(gcnhip_graph_scales(graph, &d, nullptr, nullptr, nullptr));
+    if (n_local) GCNHIP_CHECK(gcnhip_d2h(env.ctx, dinv.data(), d, dinv.size() * sizeof(float)));
 }
 
 // Rank blocks are contiguous ranges of the node order.  When the order the dataset came in forces the all-gather (the
@@ -466,7 +496,13 @@ void HipGCN::build_modules() {
         auto *mm = new HipMatmul(&env, H1, W2, Z0, N, H, C, scale);
         if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = graph_l1; }
         wire_overlap(gs, false);
-        if (getenv("HIPGCN_PACKED_DH1")) flags |= HIPGCN_PACKED_DH1;
+        if (factored_) {
+            const float *dinv_row = nullptr, *dinv2_row = nullptr, *dinv2_col = nullptr;
+            GCNHIP_CHECK(gcnhip_graph_scales(graph, &dinv_row, &dinv2_row, nullptr, &dinv2_col));
+            gs->fwd_scaling = 2; gs->bwd_scaling = 3;          // H1' = dropout(relu(dinv^2 . sum)) ; dH0' = raw sum (dW1 = X'^T . dH0')
+            mm->da_row_scale = dinv2_row;                      // dH1' = dinv^2 . mask . (T . W2^T)
+            mm->da_row_scale_full = dinv2_col;                 // rows of the gathered table (several GPUs: dH1 rebuilt for all of them)
+        }
         // Opt-in (single GPU, hidden % 64 == 0, dropout >= 0.3 so that a 64-column half averages <= 22 values against
         // the slot's 30).  dH1 = mask . (dZ0 . W2^T) is ~3/4 zeros at positions known from H1: packed rows halve the
         // lines per edge of the backward gather with identical bits — but on gfx950 the unpacking (per column: rank,
@@ -499,9 +535,16 @@ void HipGCN::build_modules() {
         modules.push_back(sm);
         modules.push_back(gs);
         modules.push_back(mm);
-        { auto *gs = new HipGraphSum(&env, Z0, Z, graph, C); gs->bwd_row_bits = &bwd_bits; gs->bwd_graph = graph_bwd_out; gs->fwd_out_rows = &cur_out_rows; wire_overlap(gs, true); modules.push_back(gs); }
+        {
+            auto *gs = new HipGraphSum(&env, Z0, Z, graph, C);
+            gs->bwd_row_bits = &bwd_bits; gs->bwd_graph = graph_bwd_out; gs->fwd_out_rows = &cur_out_rows;
+            if (factored_) { gs->fwd_scaling = 1; gs->bwd_scaling = 3; }     // Z = dinv . sum(Z0') (the true logits); T = raw sum of dZ'
+            wire_overlap(gs, true);
+            modules.push_back(gs);
+        }
         auto *ce = new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false);
         ce->rows_list = &cur_rows; ce->rows_n = &cur_rows_n;
+        if (factored_) GCNHIP_CHECK(gcnhip_graph_scales(graph, &ce->grad_row_scale, nullptr, nullptr, nullptr));   // dZ' = dinv . dZ
         modules.push_back(ce);
     }
 }
@@ -647,12 +690,13 @@ void HipGCN::build_eval_lane() {
     } else {
         auto *sm = new HipSparseMatmul(&L.env, &eval_vals, variables[2].get(), L.H0.get(), feat, N, F, H, 0.f, nnz_off);
         auto *gs = new HipGraphSum(&L.env, L.H0.get(), L.H1.get(), L.graph, H, 0.f, 0);   // ReLU epilogue, no dropout in eval
+        if (factored_) gs->fwd_scaling = 2;
         if (replicate_l1) { sm->sp_full = feat_full; sm->vals_full = &full_vals; gs->fwd_graph_replicated = L.graph_l1; }
         L.modules.push_back(sm);
         L.modules.push_back(gs);
     }
     L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
-    { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_rows = &L.out_rows; L.modules.push_back(gs); }
+    { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_rows = &L.out_rows; if (factored_) gs->fwd_scaling = 1; L.modules.push_back(gs); }
     {
         auto *ce = new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false);
         ce->rows_list = &L.rows; ce->rows_n = &L.rows_n;

@@ -61,6 +61,9 @@ enum HipGCNFlags {
     HIPGCN_STRUCTURE_PARTITION = 2097152, // multi-GPU: rank blocks formed from groups found in the graph (cluster.h) instead of
                                           // contiguous id ranges, when that shrinks the neediest rank's halo (default: decided per graph)
     HIPGCN_ID_PARTITION = 4194304,        // ... never
+    HIPGCN_EDGE_COEF = 16777216,          // aggregate with the reference's per-edge coefficients 1/sqrt(deg deg) (module.cpp:91-93) instead of
+                                          // the factored form dinv[r] * sum(dinv[c] * x[c]) (default on the fused f32 path: no coefficient
+                                          // stream beside the indices, -6..10 % per aggregation; same real numbers, two more roundings per term)
     HIPGCN_SYNC_EPOCHS = 8388608,         // run(): wait for every epoch before the next is enqueued (the reference's loop, gcn.cpp:133-151:
                                           // `time=` is then that epoch's own latency).  Default: epochs are enqueued ahead of the line being
                                           // printed whenever no decision depends on a printed number (early_stopping == 0)
@@ -115,12 +118,18 @@ public:
     const char *node_order_name() const { return node_order_name_; }
     const ExchangePlan &exchange_plan() const { return xplan; }
     // variable k as in gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z); rows x cols floats, this rank's rows.
+    // FACTORED FORM (default on the fused f32 path; factored() tells, HIPGCN_EDGE_COEF restores the reference's values): the
+    // matrices an aggregation gathers from are stored pre-multiplied by dinv = 1/sqrt(deg) of their row, so get_var returns
+    // dinv.H0 (1), dinv.H1 (3), dinv.Z0 (4) and, as gradients, dinv.dZ (6), dinv.dH1 (3), dZ0/dinv (4), dH0/dinv (1); the
+    // logits Z (6), the weights and their gradients are the reference's own.  row_scale() returns dinv for this rank's rows.
     // PARTIAL-ROW CONTRACT of variable 6 (and 4 on an evaluation forward): by default the last aggregation of a forward
     // computes only the rows of the split being scored — all the loss and the accuracy read (module.cpp:131-133,
     // gcn.cpp:86-88) — so after train_epoch() only rows of the training split hold this epoch's logits, after eval(s)
     // only rows of split s; the other rows keep whatever an earlier forward left (or the zeros of the allocation).  The
     // reference fills every row on every forward: construct with HIPGCN_ALL_ROWS to get that.
     void get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols);
+    bool factored() const { return factored_; }
+    void row_scale(std::vector<float> &dinv);                 // 1/sqrt(deg) of this rank's rows (deg of the full graph, self loop included)
     void set_weights(const float *w1, const float *w2);       // [F x h], [h x C] row-major
     DeviceTimers &device_timers() { return *timers; }
     double timer_total(timer_instance t, long *count);        // both lanes
@@ -145,6 +154,8 @@ private:
     int n_local = 0;
     long nnzA_local = 0;
     int flags = 0;
+    bool factored_ = false;
+    void apply_factored_scales();                              // X, A^.X and the replicated X of this rank -> D^-1/2 . (them)
     int device_ = 0;
     const float *eval_vals = nullptr;
     HostRng rng;

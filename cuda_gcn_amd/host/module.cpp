@@ -40,12 +40,9 @@ void HipMatmul::backward() {
     } else if (fused_bwd_scale > 0.f && da_pack)
         GCNHIP_CHECK(gcnhip_matmul_bwd_packed(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                               a->grad, a->ld, da_pack, b->grad, b->ld, m, n, p, fused_bwd_scale));
-    else if (fused_bwd_scale > 0.f && mask_bits)
-        GCNHIP_CHECK(gcnhip_matmul_bwd_fused_bits(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
-                                                  a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale, mask_bits, mask_wpr));
-    else if (fused_bwd_scale > 0.f)
-        GCNHIP_CHECK(gcnhip_matmul_bwd_fused(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
-                                             a->grad, a->ld, b->grad, b->ld, m, n, p, fused_bwd_scale));
+    else if (fused_bwd_scale > 0.f)             // mask from the bits the aggregation left, else from a > 0; da rows x dinv^2 when factored
+        GCNHIP_CHECK(gcnhip_matmul_bwd_ex(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld, a->grad, a->ld, b->grad, b->ld, m, n, p,
+                                          fused_bwd_scale, mask_bits, mask_bits ? mask_wpr : 0, da_row_scale));
     else
         GCNHIP_CHECK(gcnhip_matmul_bwd(env->ctx, a->data, a->ld, b->data, b->ld, c->grad, c->ld,
                                        a->grad, a->ld, b->grad, b->ld, m, n, p));
@@ -54,9 +51,9 @@ void HipMatmul::backward() {
 
 void HipMatmul::rebuild_da(int first, int rows) {
     if (rows <= 0) return;
-    GCNHIP_CHECK(gcnhip_matmul_bwd_da_bits(env->ctx, b->data, b->ld, c->full_grad + (size_t)first * c->ld, c->ld,
-                                           a->full_grad + (size_t)first * a->ld, a->ld, rows, n, p,
-                                           pos_bits_full + (size_t)first * wpr, wpr, fused_bwd_scale));
+    GCNHIP_CHECK(gcnhip_matmul_bwd_ex(env->ctx, nullptr, 0, b->data, b->ld, c->full_grad + (size_t)first * c->ld, c->ld,
+                                      a->full_grad + (size_t)first * a->ld, a->ld, nullptr, 0, rows, n, p, fused_bwd_scale,
+                                      pos_bits_full + (size_t)first * wpr, wpr, da_row_scale_full ? da_row_scale_full + first : nullptr));
 }
 
 // ------------------------------------------------------------- SparseMatmul
@@ -185,14 +182,20 @@ void HipGraphSum::forward(bool training) {
         const bool fused = fused_relu_dropout >= 0.f;
         env->timers->start(TMR_GRAPHSUM_FW);
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-        if (split_loc)
-            GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_loc, rows_loc, in->full, in->ld, out->data, out->ld, dim, nullptr, 0,
-                                              0, 0, 0.f, 0, nullptr, 0, nullptr));
+        if (split_loc) {
+            gcnhip_gs_opts o1 = {};
+            o1.rows = rows_loc; o1.scaling = fwd_scaling ? 3 : 0;     // the first part leaves the raw sum
+            GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, split_loc, &o1, in->full, in->ld, out->data, out->ld, dim));
+        }
         env->xlane->wait(ev);
-        if (split_loc)
-            GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, split_rem, rows_rem, in->full, in->ld, out->data, out->ld, dim, nullptr, 1,
-                                              fused ? 1 : 0, training ? 1 : 0, fused ? fused_relu_dropout : 0.f, env->seed ^ KEY_HIDDEN_DROPOUT,
-                                              env->d_epoch, elem_offset, training ? env->keep_hidden : nullptr));
+        if (split_loc) {
+            gcnhip_gs_opts o2 = {};
+            o2.rows = rows_rem; o2.accumulate = 1; o2.scaling = fwd_scaling;
+            o2.relu_dropout = fused ? 1 : 0; o2.training = training ? 1 : 0; o2.p = fused ? fused_relu_dropout : 0.f;
+            o2.seed = env->seed ^ KEY_HIDDEN_DROPOUT; o2.d_epoch = env->d_epoch; o2.elem_offset = elem_offset;
+            o2.keep_mask = training ? env->keep_hidden : nullptr;
+            GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, split_rem, &o2, in->full, in->ld, out->data, out->ld, dim));
+        }
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_FW);
     } else {
@@ -209,19 +212,19 @@ void HipGraphSum::forward(bool training) {
         uint32_t *bits_here = nullptr;
         if (training && fused_relu_dropout >= 0.f && dim % 32 == 0)
             bits_here = mask_bits_out ? mask_bits_out : (pos_bits_full ? pos_bits_full + (size_t)env->plan->own_offset * wpr : nullptr);
-        if (bits_here) {
-            GCNHIP_CHECK(gcnhip_graphsum_relu_dropout_bits(env->ctx, graph, src, in->ld, out->data, out->ld, dim, 1,
-                                                           fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
-                                                           env->keep_hidden, bits_here, mask_bits_out ? (dim + 31) / 32 : wpr));
-            bits_written = true;
-        } else if (fused_relu_dropout >= 0.f)
-            GCNHIP_CHECK(gcnhip_graphsum_relu_dropout(env->ctx, graph, src, in->ld, out->data, out->ld, dim, training ? 1 : 0,
-                                                      fused_relu_dropout, env->seed ^ KEY_HIDDEN_DROPOUT, env->d_epoch, elem_offset,
-                                                      training ? env->keep_hidden : nullptr));
-        else if (out_rows)
-            GCNHIP_CHECK(gcnhip_graphsum_rowset(env->ctx, graph, out_rows, src, in->ld, out->data, out->ld, dim, nullptr));
-        else
-            GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, in->ld, out->data, out->ld, dim));
+        {
+            gcnhip_gs_opts o = {};
+            o.scaling = fwd_scaling;
+            if (fused_relu_dropout >= 0.f) {
+                o.relu_dropout = 1; o.training = training ? 1 : 0; o.p = fused_relu_dropout;
+                o.seed = env->seed ^ KEY_HIDDEN_DROPOUT; o.d_epoch = env->d_epoch; o.elem_offset = elem_offset;
+                o.keep_mask = training ? env->keep_hidden : nullptr;
+                if (bits_here) { o.pos_bits = bits_here; o.words_per_row = mask_bits_out ? (dim + 31) / 32 : wpr; bits_written = true; }
+            } else {
+                o.rows = out_rows;
+            }
+            GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, graph, &o, src, in->ld, out->data, out->ld, dim));
+        }
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_FW);
     }
@@ -272,9 +275,12 @@ void HipGraphSum::backward() {
         void *ev = env->xlane->begin(*env->plan, out->full_grad, out->ld);
         env->timers->start(TMR_GRAPHSUM_BW);
         if (dim > 64) env->timers->start(TMR_GRAPHSUM_WIDE);
-        if (loc) GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, loc, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 0, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        gcnhip_gs_opts o = {};
+        o.in_row_bits = bits; o.scaling = bwd_scaling;
+        if (loc) GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, loc, &o, out->full_grad, out->ld, in->grad, in->ld, dim));
         env->xlane->wait(ev);
-        if (rem) GCNHIP_CHECK(gcnhip_graphsum_part(env->ctx, rem, nullptr, out->full_grad, out->ld, in->grad, in->ld, dim, bits, 1, 0, 0, 0.f, 0, nullptr, 0, nullptr));
+        o.accumulate = 1;
+        if (rem) GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, rem, &o, out->full_grad, out->ld, in->grad, in->ld, dim));
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
         env->timers->stop(TMR_GRAPHSUM_BW);
         return;
@@ -291,7 +297,9 @@ void HipGraphSum::backward() {
         // (with per-op timers on, every launch runs alone on the main stream: the branches below)
         const size_t nb = pipe->blocks.size();
         for (size_t k = 0; k < nb; k++) {
-            GCNHIP_CHECK(gcnhip_graphsum_rowset(env->ctx, graph, pipe->blocks[k], src, out->ld, in->grad, in->ld, dim, nullptr));
+            gcnhip_gs_opts ob = {};
+            ob.rows = pipe->blocks[k]; ob.scaling = bwd_scaling;
+            GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, graph, &ob, src, out->ld, in->grad, in->ld, dim));
             GCNHIP_CHECK(gcnhip_event_record(env->ctx, pipe->ev_block[k]));
             GCNHIP_CHECK(gcnhip_stream_wait_event(pipe->side, pipe->ev_block[k]));
             pipe_consumer->backward_part((int)k);
@@ -300,10 +308,11 @@ void HipGraphSum::backward() {
         pipe->armed = true;
     } else if (out_grad_pack)
         GCNHIP_CHECK(gcnhip_graphsum_packed(env->ctx, graph, out_grad_pack, src, out->ld, in->grad, in->ld));
-    else if (row_bits)
-        GCNHIP_CHECK(gcnhip_graphsum_rowmask(env->ctx, graph, src, out->ld, in->grad, in->ld, dim, row_bits));
-    else
-        GCNHIP_CHECK(gcnhip_graphsum(env->ctx, graph, src, out->ld, in->grad, in->ld, dim));
+    else {
+        gcnhip_gs_opts o = {};
+        o.in_row_bits = row_bits; o.scaling = bwd_scaling;
+        GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, graph, &o, src, out->ld, in->grad, in->ld, dim));
+    }
     if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
     env->timers->stop(TMR_GRAPHSUM_BW);
 }
@@ -317,8 +326,9 @@ HipCrossEntropyLoss::HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32
 void HipCrossEntropyLoss::forward(bool training) {
     env->timers->start(TMR_LOSS_FW);
     if (rows_list && *rows_list && *count > 0)
-        GCNHIP_CHECK(gcnhip_xent_fwd_rows(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, *rows_list, *rows_n,
-                                          num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i));
+        GCNHIP_CHECK(gcnhip_xent_fwd_rows_scaled(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, *rows_list, *rows_n,
+                                                 num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i,
+                                                 grad_row_scale));
     else
     GCNHIP_CHECK(gcnhip_xent_fwd(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, logits->rows,
                                  num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i));

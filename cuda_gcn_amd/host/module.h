@@ -76,6 +76,9 @@ public:
     // (gcnhip_graphsum_relu_dropout_bits): da does not read `a` again
     const uint32_t *mask_bits = nullptr;
     int mask_wpr = 0;
+    // factored aggregation (gcnhip_graphsum_ex): da leaves multiplied by dinv^2 of its row — da_row_scale for this rank's
+    // rows, da_row_scale_full for the rows of the gathered table (rebuild_da)
+    const float *da_row_scale = nullptr, *da_row_scale_full = nullptr;
     HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
 private:
     void rebuild_da(int first_row, int n_rows);     // da rows [first_row, first_row + n_rows) of the table from dc + mask bits
@@ -143,6 +146,10 @@ public:
     // backward(): in->grad is produced block by block and handed to this consumer's weight gradient (BackwardPipeline)
     BackwardPipeline *pipe = nullptr;
     HipSparseMatmul *pipe_consumer = nullptr;
+    // gcnhip_graphsum_ex scaling of the forward / backward aggregation: 0 = the reference's per-edge coefficients; factored
+    // model: hidden layer forward 2 (result x dinv^2: already scaled for the class-width aggregation), class layer forward 1
+    // (true logits), every backward 3 (the consumer's operand carries the factor)
+    int fwd_scaling = 0, bwd_scaling = 0;
     HipGraphSum(HipEnv *env, HipVariable *in, HipVariable *out, gcnhip_graph *graph, int dim,
                 float fused_relu_dropout = -1.f, uint64_t elem_offset = 0);
     ~HipGraphSum() override;
@@ -171,6 +178,7 @@ public:
     // gradients are zero from allocation on).  NULL: every row is visited, as the reference does.
     int32_t *const *rows_list = nullptr;
     const int *rows_n = nullptr;
+    const float *grad_row_scale = nullptr;      // factored aggregation: the gradient rows leave multiplied by dinv of their row
     HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32_t *const *truth, const int *count,
                         float *d_result, int32_t *d_result_i, int num_classes, bool shift_in_place);
     void forward(bool) override;

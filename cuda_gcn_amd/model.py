@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO, PACKED_DH1, MASKED_BWD, BWD_PIPELINE, NO_LABEL_HINT, OVERLAP_EXCHANGE, STRUCTURE_PARTITION, ID_PARTITION, SYNC_EPOCHS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608
+MODULAR, HOST_MASKS, TIMERS, NO_GRAPH, EVAL_LANE, NO_EVAL_LANE, NO_REPLICATE_L1, REPLICATE_L1, GATHER_DH1, NO_ROW_GROUPS, NULL_COMM, BF16_TABLES, ALL_ROWS, NO_AGG_FIRST_EVAL, EXCHANGE_ALLGATHER, EXCHANGE_HALO, PACKED_DH1, MASKED_BWD, BWD_PIPELINE, NO_LABEL_HINT, OVERLAP_EXCHANGE, STRUCTURE_PARTITION, ID_PARTITION, SYNC_EPOCHS, EDGE_COEF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608, 16777216
 TIMER_NAMES = ["train", "test", "matmul_fw", "matmul_bw", "spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw",
                "loss_fw", "relu_fw", "relu_bw", "dropout_fw", "dropout_bw", "adam", "comm", "graphsum_wide"]
 
@@ -97,6 +97,27 @@ class HipGCNModel:
         e = C.c_int64()
         _ck(self.lib, self.lib.gcnhost_model_info(self.h, C.byref(r), C.byref(w), C.byref(s), C.byref(n), C.byref(e)), "info")
         return dict(rank=r.value, world=w.value, row_start=s.value, local_rows=n.value, local_edges=e.value)
+
+    def row_scale(self):
+        """(dinv = 1/sqrt(deg) of this rank's rows, factored?) — factored: var(1), var(3), var(4) are stored pre-multiplied by
+        dinv of their row and their gradients accordingly (host/gcn.h); EDGE_COEF restores the reference's values"""
+        n = self.info()["local_rows"]
+        d = np.ones(n, np.float32)
+        f = C.c_int()
+        _ck(self.lib, self.lib.gcnhost_model_row_scale(self.h, d.ctypes.data, C.byref(f)), "row_scale")
+        return d, bool(f.value)
+
+    def var_reference(self, k, grad=False):
+        """variable k as the REFERENCE stores it (gcn.cpp:21-54): the factored model's pre-multiplied rows divided back"""
+        v = self.var(k, grad)
+        d, factored = self.row_scale()
+        if not factored or k in (2, 5):
+            return v
+        d = d[:, None].astype(np.float64)
+        if not grad:
+            return (v / d).astype(np.float32) if k in (1, 3, 4) else v            # dinv.H0, dinv.H1, dinv.Z0 ; Z as is
+        # gradients: dZ' = dinv.dZ (6), dH1' = dinv.dH1 (3) ; T = dZ0/dinv (4), S = dH0/dinv (1)
+        return (v / d).astype(np.float32) if k in (6, 3) else (v * d).astype(np.float32)
 
     def row_ids(self):
         """(node of the caller's dataset for every local row of this rank, whether the model renumbered the nodes)"""

@@ -212,6 +212,43 @@ int gcnhip_graphsum_relu_dropout_bits(gcnhip_ctx *ctx, const gcnhip_graph *g, co
                                       uint64_t seed, const uint32_t *d_epoch, uint64_t elem_offset,
                                       const uint8_t *keep_mask, uint32_t *pos_bits, int words_per_row);
 
+/* ---- the factored operator (round 4) ------------------------------------------------------------------------------
+ * A^ = D^-1/2 (A + I) D^-1/2.  The reference multiplies every gathered row by a per-EDGE coefficient
+ * 1/sqrt(deg(src) deg(dst)) (module.cpp:91-93), and so do the entry points above — which makes the coefficient array a
+ * second stream beside the indices: 94 MB per launch at Reddit scale, measured at 6 % (hidden width) to 10 % (class width)
+ * of the launch (tools/gather_peak.py --coef; profiles/r04_gather_peak.json).  The same operator FACTORED needs no per-edge
+ * number at all:  (A^ x)[r] = dinv[r] * sum_e (dinv[col(e)] * x[col(e)]),  dinv = 1/sqrt(deg).
+ * gcnhip_graphsum_ex with scaling != 0 computes  out[r] = post[r] * sum_e in[col(e)]  where the CALLER has stored
+ * dinv[col] * x[col] in `in` (every producer on the training path has a row-wise epilogue or a value array that takes the
+ * factor for free: HipGCN, host/gcn.cpp "factored").  scaling: 0 = per-edge coefficients (identical to the entry points
+ * above), 1 = post = dinv[row], 2 = post = dinv[row]^2 (= 1/deg: the result is already dinv-scaled for the NEXT
+ * aggregation), 3 = no post factor (the consumer folds dinv[row] in, e.g. through a pre-scaled feature matrix).
+ * Same real numbers as the reference's operator; each term carries two more f32 roundings (dinv[r] * (dinv[c] * x)
+ * instead of coef * x), inside the summation-order bound the parity tests use.  f32 rows, 16-byte aligned.
+ * The other fields are the options of gcnhip_graphsum_rowset / _rowmask / _part / _relu_dropout_bits, all optional. */
+typedef struct {
+    const gcnhip_rowset *rows;          /* NULL: every row */
+    const uint32_t *in_row_bits;        /* NULL, or as gcnhip_graphsum_rowmask */
+    int accumulate;                     /* as gcnhip_graphsum_part: out = out + sum (then post, then the epilogue) */
+    int relu_dropout, training;         /* the fused epilogue of gcnhip_graphsum_relu_dropout */
+    float p;
+    uint64_t seed;
+    const uint32_t *d_epoch;
+    uint64_t elem_offset;
+    const uint8_t *keep_mask;
+    uint32_t *pos_bits;                 /* NULL, or as gcnhip_graphsum_relu_dropout_bits (needs relu_dropout) */
+    int words_per_row;
+    int scaling;                        /* see above */
+} gcnhip_gs_opts;
+int gcnhip_graphsum_ex(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_gs_opts *opts, const float *in, int ld_in,
+                       float *out, int ld_out, int dim);
+/* device pointers of the factor arrays of a prepared adjacency: dinv / dinv^2 per row ([n_rows]) and per column ([n_cols]);
+ * degrees are those of the full graph also for objects made by gcnhip_graph_create_restricted */
+int gcnhip_graph_scales(const gcnhip_graph *g, const float **d_dinv_row, const float **d_dinv2_row,
+                        const float **d_dinv_col, const float **d_dinv2_col);
+/* values of row r of a feature object *= d_row_scale[r] (all of its internal copies; synchronises): X -> D^-1/2 X */
+int gcnhip_feat_scale_rows(gcnhip_ctx *ctx, gcnhip_feat *f, const float *d_row_scale);
+
 /* ---- features (CUDASparseIndex of X + the input CUDAVariable) ----------------
  * CSR of X with n_rows rows and n_cols (= input_dim) columns.  A matrix whose
  * every row holds exactly the columns 0..n_cols-1 in order is detected as
@@ -301,6 +338,14 @@ int gcnhip_matmul_bwd_fused(gcnhip_ctx *ctx, const float *a, int lda, const floa
 int gcnhip_matmul_bwd_fused_bits(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
                                  const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
                                  int m, int n, int p, float relu_dropout_scale, const uint32_t *pos_bits, int words_per_row);
+
+/* every form of the fused backward in one call, plus an optional factor per row of da:  db = a^T . dc when db != NULL;
+ * da[r,:] = mask . (relu_dropout_scale * d_da_row_scale[r]) . (dc . b^T)[r,:], mask = pos_bits when given (a may then be
+ * NULL if db is NULL too), else a > 0; d_da_row_scale == NULL: factor 1 */
+int gcnhip_matmul_bwd_ex(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
+                         const float *dc, int lddc, float *da, int ldda, float *db, int lddb,
+                         int m, int n, int p, float relu_dropout_scale, const uint32_t *pos_bits, int words_per_row,
+                         const float *d_da_row_scale);
 
 /* Packed dH1 (exact).  ReLU and dropout zero about three quarters of dH1 = mask . (dZ0 . W2^T), at positions known
  * from H1, and its only reader is the hidden layer's backward aggregation (module.cpp:103-119), which pays per
@@ -393,6 +438,10 @@ int gcnhip_xent_fwd(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_
 int gcnhip_xent_fwd_rows(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_grad,
                          const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
                          int count, int shift_in_place, float *d_result, int32_t *d_result_i);
+/* ... with row r of grad multiplied by d_grad_row_scale[r] (NULL: as above) — the factored aggregation's input dinv . dZ */
+int gcnhip_xent_fwd_rows_scaled(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_grad,
+                                const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
+                                int count, int shift_in_place, float *d_result, int32_t *d_result_i, const float *d_grad_row_scale);
 /* accuracy alone (cuda_gcn.cu:100-120 without the 38 MB D2H) */
 int gcnhip_accuracy(gcnhip_ctx *ctx, const float *logits, int ld, const int32_t *truth,
                     int n_rows, int num_classes, int32_t *d_result_i);

@@ -103,6 +103,10 @@ int gcnhost_model_info(gcnhost_model *m, int *rank, int *world, int *row_start, 
  * node order; HIPGCN_ID_PARTITION keeps the ids, HIPGCN_STRUCTURE_PARTITION forces the renumbering).  ids[r] (local_rows
  * entries) = the node of the caller's dataset that local row r of this rank is; *renumbered = 0 when the ids were kept. */
 int gcnhost_model_row_ids(gcnhost_model *m, int *ids, int *renumbered);
+/* factored aggregation (gcn.h, HIPGCN_EDGE_COEF restores the reference's per-edge coefficients): *factored says whether
+ * gcnhost_model_get_var returns the gathered matrices pre-multiplied by dinv = 1/sqrt(deg) of their row (variables 1, 3, 4;
+ * the logits, weights and weight gradients are never scaled); dinv [local_rows] receives that factor (may be NULL) */
+int gcnhost_model_row_scale(gcnhost_model *m, float *dinv, int *factored);
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
 /* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
  * out == NULL: only report the shape. */

@@ -115,16 +115,24 @@ def test_trace_vs_reference_golden(name, seed, dropout):
     m.close()
 
 
+@pytest.mark.parametrize("edge_coef", [False, True])
 @pytest.mark.parametrize("all_rows", [True, False])
-def test_first_epoch_tensors_vs_oracle(oracle, all_rows):
+def test_first_epoch_tensors_vs_oracle(oracle, all_rows, edge_coef):
     """every intermediate of one training epoch (H0, H1, Z0, Z and their gradients).  By default the last
     aggregation computes only the rows of the scored split (all that the loss reads, module.cpp:131-133):
-    then Z is compared on those rows; with ALL_ROWS on every row."""
-    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS, ALL_ROWS
+    then Z is compared on those rows; with ALL_ROWS on every row.  Default: the factored aggregation (the gathered matrices
+    are stored pre-multiplied by dinv of their row: var_reference divides that back); EDGE_COEF: the reference's per-edge
+    coefficients, every variable stored as the reference stores it."""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS, ALL_ROWS, EDGE_COEF
     ds = datagen.make_dataset("cora-syn")
     N, H, C = ds["num_nodes"], 16, ds["output_dim"]
     om = oracle.model(ds, seed_time=9, hidden_dim=H, dropout=0.5)
-    m = HipGCNModel(ds, seed=9, flags=HOST_MASKS | (ALL_ROWS if all_rows else 0), hidden_dim=H, dropout=0.5)
+    m = HipGCNModel(ds, seed=9, flags=HOST_MASKS | (ALL_ROWS if all_rows else 0) | (EDGE_COEF if edge_coef else 0), hidden_dim=H, dropout=0.5)
+    dinv, factored = m.row_scale()
+    assert factored == (not edge_coef)
+    assert np.allclose(dinv, 1.0 / np.sqrt(np.diff(ds["g_indptr"])), rtol=1e-7)
+    if edge_coef:
+        assert np.array_equal(m.var(3), m.var_reference(3))
     assert np.array_equal(m.var(2).reshape(-1), om.var(2))          # same Glorot init as gcn-seq
     assert np.array_equal(m.var(5).reshape(-1), om.var(5))
     a, b = m.train_epoch(), om.train_epoch()
@@ -134,16 +142,16 @@ def test_first_epoch_tensors_vs_oracle(oracle, all_rows):
         want = om.var(k).reshape(shp)
         if k == 6:
             want = want - 0          # oracle's Z is max-shifted in place; fused path leaves Z unshifted
-            got = m.var(k)
+            got = m.var_reference(k)
             got = got - got.max(axis=1, keepdims=True) * (ds["split"] == 1)[:, None]
             if not all_rows:
                 assert np.all(got[ds["split"] != 1] == 0)      # never computed: still the allocation's zeros
                 got, want = got[ds["split"] == 1], want[ds["split"] == 1]
         else:
-            got = m.var(k)
+            got = m.var_reference(k)
         assert np.allclose(got, want, rtol=2e-5, atol=2e-6), k
         gw = om.var(k, True).reshape(shp)
-        assert np.allclose(m.var(k, True), gw, rtol=2e-4, atol=1e-7), ("grad", k)
+        assert np.allclose(m.var_reference(k, True), gw, rtol=2e-4, atol=1e-7), ("grad", k)
     # weight gradients are consumed by Adam: compare the updated weights instead
     for k in (2, 5):
         assert np.allclose(m.var(k).reshape(-1), om.var(k), rtol=1e-5, atol=1e-6)
@@ -318,9 +326,9 @@ def test_aggregate_first_eval_matches_reference_order(name, hidden):
 def test_packed_dh1_is_bit_identical_to_dense(name, hidden):
     """dH1 travelling as packed rows from the Matmul backward to the hidden layer's backward aggregation changes
     no bit of any weight or reported number"""
-    from cuda_gcn_amd.model import HipGCNModel, PACKED_DH1
+    from cuda_gcn_amd.model import HipGCNModel, PACKED_DH1, EDGE_COEF
     ds = datagen.make_dataset(name)
-    a = HipGCNModel(ds, seed=8, hidden_dim=hidden, dropout=0.5, epochs=12)
+    a = HipGCNModel(ds, seed=8, flags=EDGE_COEF, hidden_dim=hidden, dropout=0.5, epochs=12)   # (packed rows imply the per-edge coefficients)
     b = HipGCNModel(ds, seed=8, flags=PACKED_DH1, hidden_dim=hidden, dropout=0.5, epochs=12)
     ta, tb = a.run_epochs(10), b.run_epochs(10)
     assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
@@ -366,6 +374,34 @@ def test_backward_pipeline_is_bit_identical(extra, monkeypatch):
         assert np.array_equal(a.var(v).view(np.uint32), b.var(v).view(np.uint32))
         assert np.array_equal(a.var(v, True).view(np.uint32), b.var(v, True).view(np.uint32))
     assert np.array_equal(a.var(1, True).view(np.uint32), b.var(1, True).view(np.uint32))       # dH0, block by block
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,hidden,flags", [("cora-syn", 16, 0), ("pubmed-syn", 16, 0), ("reddit-mini", 128, 0), ("reddit-mini", 128, 16),
+                                               ("reddit-mini", 128, 8192 | 4096), ("rmat-12-32", 16, 0)])
+def test_factored_aggregation_matches_per_edge_coefficients(name, hidden, flags):
+    """the default factored operator dinv[r] * sum(dinv[c] * x[c]) against the reference's per-edge coefficients (EDGE_COEF):
+    same real numbers, two more f32 roundings per term — traces to 2e-5, every variable (scaled back) and the weights after 10
+    epochs to the summation-order tolerance; with the validation lane (16), in the reference's evaluation order on all rows"""
+    from cuda_gcn_amd.model import HipGCNModel, EDGE_COEF
+    ds = datagen.make_dataset(name)
+    a = HipGCNModel(ds, seed=8, flags=flags | EDGE_COEF, hidden_dim=hidden, dropout=0.5, epochs=12)
+    b = HipGCNModel(ds, seed=8, flags=flags, hidden_dim=hidden, dropout=0.5, epochs=12)
+    assert b.row_scale()[1] and not a.row_scale()[1]
+    la, lb = a.train_epoch(), b.train_epoch()
+    assert abs(la[0] - lb[0]) <= 2e-6 and la[1] == lb[1]
+    for k in (1, 3, 4):
+        x, y = a.var(k), b.var_reference(k)
+        assert np.allclose(x, y, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(x).max()))), k
+        gx, gy = a.var(k, True), b.var_reference(k, True)
+        assert np.allclose(gx, gy, rtol=2e-4, atol=2e-6 * max(1e-6, float(np.abs(gx).max()))), ("grad", k)
+    ta, tb = a.run_epochs(10), b.run_epochs(10)
+    assert np.abs(ta[:, [0, 2]] - tb[:, [0, 2]]).max() <= 2e-5, np.abs(ta - tb).max(axis=0)
+    assert np.abs(ta[:, [1, 3]] - tb[:, [1, 3]]).max() <= 2.0 / max(1, int((ds["split"] == 2).sum())) + 1e-6
+    for s in (2, 3):
+        ea, eb = a.eval(s), b.eval(s)
+        assert abs(ea[0] - eb[0]) <= 2e-5
+    assert np.allclose(a.var(2), b.var(2), rtol=0, atol=2e-3) and np.allclose(a.var(5), b.var(5), rtol=0, atol=2e-3)
     a.close(); b.close()
 
 
@@ -461,7 +497,7 @@ def test_full_size_reddit_two_epochs_vs_oracle(oracle):
     # a validation forward with the (identical) initial weights: every element of H1 and Z
     a, b = m.eval(2), om.eval(2)
     assert abs(a[0] - b[0]) <= 2e-5 and abs(a[1] - b[1]) <= 1e-4
-    h = m.var(3)
+    h = m.var_reference(3)
     assert np.allclose(h, om.var(3).reshape(h.shape), rtol=1e-4, atol=2e-6)
     z, zo = m.var(6), om.var(6).reshape(-1, ds["output_dim"])
     lab = ds["split"] == 2                                   # the oracle max-shifts the rows it scored, in place
@@ -476,6 +512,6 @@ def test_full_size_reddit_two_epochs_vs_oracle(oracle):
         assert abs(got[1] - want[1]) <= 2e-5 and abs(got[3] - want[3]) <= 1e-4, (e, got, want)
     # after Adam steps single weights whose gradient is ~0 may have moved by +-lr in opposite directions
     # (the first Adam step is lr * sign(g)); activations are therefore compared in bulk only
-    d = np.abs(m.var(3) - om.var(3).reshape(h.shape))
+    d = np.abs(m.var_reference(3) - om.var(3).reshape(h.shape))
     assert np.median(d) <= 1e-6 and d.max() <= 5e-3, (np.median(d), d.max())
     m.close(); om.close()

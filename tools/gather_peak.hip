@@ -29,6 +29,11 @@ struct GpArgs {
     float *out;
     int ld, dim, n_slices, store;
     int bounds[9];
+    // what the product adds to the pure gather, one at a time: coef_mode 1 = a coefficient per edge from its own array (a second
+    // coalesced 4-byte load per chunk) and a multiply; 2 = (index, coefficient) interleaved in one array of 8-byte pairs
+    int coef_mode;
+    const float *coef;
+    const int2 *pairs;
 };
 
 template <int U>
@@ -48,18 +53,28 @@ __global__ __launch_bounds__(256) void gather_peak_kernel(GpArgs a) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = tk.x; base < tk.y; base += 64) {
         const int cnt = min(64, tk.y - base);
-        const int my_idx = lane < cnt ? a.indices[base + lane] : a.indices[base];
+        int my_idx;
+        float my_c = 1.f;
+        if (a.coef_mode == 2) {
+            const int2 pr = a.pairs[base + (lane < cnt ? lane : 0)];
+            my_idx = pr.x; my_c = __int_as_float(pr.y);
+        } else {
+            my_idx = lane < cnt ? a.indices[base + lane] : a.indices[base];
+            if (a.coef_mode == 1) my_c = a.coef[base + (lane < cnt ? lane : 0)];
+        }
         const int iters = (cnt + G - 1) / G;
         for (int k = 0; k < iters; k += U) {            // idle lanes re-read the chunk's first row (the product kernel's tail does the same)
             float4 v[U];
+            float cc[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int src = (k + u) * G + g;
                 const int j = __shfl(my_idx, src < cnt ? src : 0, 64);
+                cc[u] = a.coef_mode ? __shfl(my_c, src < cnt ? src : 0, 64) : 1.f;
                 v[u] = *reinterpret_cast<const float4 *>(in + (size_t)j * a.ld);
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            for (int u = 0; u < U; u++) { acc.x += cc[u] * v[u].x; acc.y += cc[u] * v[u].y; acc.z += cc[u] * v[u].z; acc.w += cc[u] * v[u].w; }
         }
     }
 #pragma unroll
@@ -75,6 +90,7 @@ __global__ __launch_bounds__(256) void gather_peak_kernel(GpArgs a) {
 
 struct Handle {
     int2 *tasks = nullptr; int *task_row = nullptr; int *indices = nullptr; float *table = nullptr, *out = nullptr;
+    float *coef = nullptr; int2 *pairs = nullptr;
     int n_tasks = 0; long nnz = 0; size_t table_floats = 0;
     std::vector<int2> h_tasks;
     int n_cu = 256;
@@ -99,6 +115,15 @@ int gp_create(void **out, const int *h_e0, const int *h_e1, const int *h_row, in
     CK(hipMemcpy(h->tasks, h->h_tasks.data(), (size_t)n_tasks * sizeof(int2), hipMemcpyHostToDevice));
     CK(hipMemcpy(h->task_row, h_row, (size_t)n_tasks * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(h->indices, h_indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    {   // coefficients (all 1: the sums stay checkable) in their own array and interleaved with the indices
+        std::vector<float> cf((size_t)nnz, 1.0f);
+        std::vector<int2> pr((size_t)nnz);
+        for (long e = 0; e < nnz; e++) pr[e] = make_int2(h_indices[e], 0x3F800000);
+        CK(hipMalloc((void **)&h->coef, (size_t)nnz * sizeof(float)));
+        CK(hipMalloc((void **)&h->pairs, (size_t)nnz * sizeof(int2)));
+        CK(hipMemcpy(h->coef, cf.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+        CK(hipMemcpy(h->pairs, pr.data(), (size_t)nnz * sizeof(int2), hipMemcpyHostToDevice));
+    }
     std::vector<float> ones(h->table_floats, 1.0f);
     CK(hipMemcpy(h->table, ones.data(), h->table_floats * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemset(h->out, 0, h->table_floats * sizeof(float)));
@@ -109,18 +134,23 @@ int gp_create(void **out, const int *h_e0, const int *h_e1, const int *h_row, in
 int gp_destroy(void *p) {
     Handle *h = (Handle *)p;
     if (!h) return 0;
-    hipFree(h->tasks); hipFree(h->task_row); hipFree(h->indices); hipFree(h->table); hipFree(h->out);
+    hipFree(h->tasks); hipFree(h->task_row); hipFree(h->indices); hipFree(h->table); hipFree(h->out); hipFree(h->coef); hipFree(h->pairs);
     delete h;
     return 0;
 }
 
 // one configuration: average launch time over `iters` launches (after 2 warm-up launches), HIP events on the null stream
+int gp_run2(void *p, int ld, int dim, int U, int waves_per_simd, int store, int iters, int coef_mode, float *ms_out);
 int gp_run(void *p, int ld, int dim, int U, int waves_per_simd, int store, int iters, float *ms_out) {
+    return gp_run2(p, ld, dim, U, waves_per_simd, store, iters, 0, ms_out);
+}
+int gp_run2(void *p, int ld, int dim, int U, int waves_per_simd, int store, int iters, int coef_mode, float *ms_out) {
     Handle *h = (Handle *)p;
     if (!h || (size_t)ld * 1 > h->table_floats) return -1;
     GpArgs a;
     a.tasks = h->tasks; a.task_row = h->task_row; a.indices = h->indices; a.table = h->table; a.out = h->out;
     a.ld = ld; a.dim = dim; a.store = store;
+    a.coef_mode = coef_mode; a.coef = h->coef; a.pairs = h->pairs;
     const int ychunks = (dim + 63) / 64;
     a.n_slices = (ychunks > 1 && 8 % ychunks == 0) ? ychunks : 1;
     if (ychunks > 1 && a.n_slices == 1) return -1;      // only the shapes the product slices (d = 128, 256) or single-slice rows

@@ -36,6 +36,7 @@ def load_lib():
     lib = C.CDLL(LIB)
     lib.gp_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long]
     lib.gp_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.gp_run2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.gp_destroy.argtypes = [C.c_void_p]
     return lib
 
@@ -70,6 +71,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--best-only", action="store_true", help="only the best configuration of each stream (for a PMC pass)")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--coef", action="store_true", help="also time the gather with a coefficient stream (separate array / interleaved pairs)")
     a = ap.parse_args()
     lib = load_lib()
     t0 = time.time()
@@ -110,6 +112,14 @@ def main():
                         if best is None or gbps > best["GBps"]:
                             best = r
             doc.setdefault("best", []).append(best)
+            if a.coef and sname.startswith("own index stream, label-major"):
+                # what the product's coefficient stream costs on top of the pure gather, and whether interleaving it with the
+                # indices (one 8-byte load per lane instead of two 4-byte loads) gets that back
+                for mode, label in ((0, "no coefficients"), (1, "coefficients from their own array"), (2, "(index, coefficient) pairs, one array")):
+                    ms = C.c_float()
+                    lib.gp_run2(h, ld, dim, 4, 8, 1, a.iters, mode, C.byref(ms))
+                    doc.setdefault("coefficient_stream", []).append({"table": tname, "mode": label, "ms": ms.value, "GBps": 4.0 * dim * nnz / (ms.value * 1e-3) / 1e9})
+                    print(f"[gather_peak] coefficient stream, {tname[:6]}: {label}: {ms.value:.3f} ms", flush=True)
         lib.gp_destroy(h)
     # the ceilings bench.py uses: the product's own stream and schedule, best configuration, per table
     doc["ceiling_GBps"] = {b["table"].split(" ")[0]: b["GBps"] for b in doc["best"] if b["stream"].startswith("own index stream, label-major")}
