@@ -110,9 +110,7 @@ constexpr int GS_U = 4;        // row loads in flight per lane group when the ta
 // One chunk of <= 64 edges whose (index, coef) pairs sit in the wave's lanes: acc += sum over the chunk, lane group g
 // taking edges g, g + G, ... in order (the order every form of the kernel keeps, so all of them agree bit for bit).
 // NT: the row loads carry the non-temporal hint (the line is not to be kept in L2 / Infinity Cache at the expense of others)
-// COEF == false (the factored operator): no coefficient is handed round or multiplied — every real edge counts 1; an edge
-// whose input row is known to be zero arrives with index -1.
-template <int L, int GS_U, bool NT = false, bool COEF = true>
+template <int L, int GS_U, bool NT = false>
 __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in, int my_idx, float my_c, int cnt, int g, float4 acc) {
     auto ldrow = [&](const float *p) __attribute__((always_inline)) -> float4 {
         if (NT) {
@@ -137,17 +135,16 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
             for (int u = 0; u < GS_U; u++) {
                 const int src = (k + u) * G + g;
                 const int j = __shfl(my_idx, src, WAVE);
-                if (COEF) cc[u] = __shfl(my_c, src, WAVE);
+                cc[u] = __shfl(my_c, src, WAVE);
                 v[u] = ldrow(in + (size_t)j * a.ld_in);
             }
 #pragma unroll
-            for (int u = 0; u < GS_U; u++) acc = COEF ? f4_fma(cc[u], v[u], acc) : f4_add(acc, v[u]);
+            for (int u = 0; u < GS_U; u++) acc = f4_fma(cc[u], v[u], acc);
         }
     }
     // the tail of a row, and rows read through an input mask: the same batches, with the lanes that have no edge
     // (or an edge whose row is known to be zero) reading the chunk's first neighbour instead and keeping their sum
-    int j_safe = __shfl(my_idx, 0, WAVE);
-    if (!COEF && j_safe < 0) j_safe = 0;               // (the chunk's first edge is itself a known-zero row: any row will do)
+    const int j_safe = __shfl(my_idx, 0, WAVE);
     for (; k < iters; k += GS_U) {
         float4 v[GS_U];
         float cc[GS_U];
@@ -156,13 +153,13 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
         for (int u = 0; u < GS_U; u++) {
             const int src = (k + u) * G + g;
             const int j = __shfl(my_idx, src & 63, WAVE);
-            if (COEF) cc[u] = __shfl(my_c, src & 63, WAVE);
-            on[u] = src < cnt && (COEF ? cc[u] != 0.f : j >= 0);     // padded lanes and known-zero rows contribute nothing
+            cc[u] = __shfl(my_c, src & 63, WAVE);
+            on[u] = src < cnt && cc[u] != 0.f;         // padded lanes and known-zero rows contribute nothing
             v[u] = ldrow(in + (size_t)(on[u] ? j : j_safe) * a.ld_in);
         }
 #pragma unroll
         for (int u = 0; u < GS_U; u++) {
-            const float4 n = COEF ? f4_fma(cc[u], v[u], acc) : f4_add(acc, v[u]);
+            const float4 n = f4_fma(cc[u], v[u], acc);
             acc.x = on[u] ? n.x : acc.x; acc.y = on[u] ? n.y : acc.y; acc.z = on[u] ? n.z : acc.z; acc.w = on[u] ? n.w : acc.w;
         }
     }
@@ -172,7 +169,7 @@ __device__ __forceinline__ float4 gather_chunk(const GsArgs &a, const float *in,
 // L lanes per feature row (float4 each), G = 64/L rows per wave instruction.
 // SLICED: the launch binds one column slice to each XCD group (it only changes the block -> (tasks, columns) mapping; the
 // flag is a template argument so that profiles name the hidden-width launches apart from the class-width ones).
-template <int L, int U = GS_U, bool SLICED = false, bool NT = false, bool COEF = true>
+template <int L, int U = GS_U, bool SLICED = false, bool NT = false>
 __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     constexpr int G = WAVE / L;
     const int lane = threadIdx.x & 63;
@@ -208,10 +205,13 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         float my_c = 0.f;
         if (lane < cnt) {
             my_idx = a.indices[base + lane];
-            if (COEF) my_c = a.coef[base + lane];          // > 0 for every real edge
-            if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) { my_c = 0.f; if (!COEF) my_idx = -1; }
+            // > 0 for every real edge.  Factored operator (a.coef == NULL, wave-uniform): every edge counts 1 and no coefficient
+            // stream is read — the saving is the stream (measured 0.756 -> 0.720 ms at Reddit scale); instantiations that also
+            // drop the hand-out shuffle and the multiply measured the same 0.720 ms and were not kept
+            my_c = a.coef ? a.coef[base + lane] : 1.f;
+            if (a.row_bits && !((a.row_bits[my_idx >> 5] >> (my_idx & 31)) & 1u)) my_c = 0.f;
         }
-        acc = gather_chunk<L, U, NT, COEF>(a, in, my_idx, my_c, cnt, g, acc);
+        acc = gather_chunk<L, U, NT>(a, in, my_idx, my_c, cnt, g, acc);
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -777,16 +777,6 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], const gcnhip_ctx *c) {
     const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
     const bool nt_all = c->opt.gs_nt != 0;                            // EXPERIMENT: every row load non-temporal
     if (sliced && nt_all && L == 16 && a.coef) { graphsum_vec_kernel<16, 4, true, true><<<grid, 256, 0, s>>>(a); return; }
-    if (!a.coef) {                                          // the factored operator: its own instantiations (no coefficient hand-out)
-        if (sliced) {
-            if (u >= 4) graphsum_vec_kernel<L, 4, true, false, false><<<grid, 256, 0, s>>>(a);
-            else graphsum_vec_kernel<L, 2, true, false, false><<<grid, 256, 0, s>>>(a);
-        } else {
-            if (u >= 4) graphsum_vec_kernel<L, 4, false, false, false><<<grid, 256, 0, s>>>(a);
-            else graphsum_vec_kernel<L, 2, false, false, false><<<grid, 256, 0, s>>>(a);
-        }
-        return;
-    }
     if (sliced) {
         if (u >= 4) graphsum_vec_kernel<L, 4, true><<<grid, 256, 0, s>>>(a);
         else if (u >= 2) graphsum_vec_kernel<L, 2, true><<<grid, 256, 0, s>>>(a);

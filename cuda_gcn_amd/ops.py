@@ -15,6 +15,13 @@ import numpy as np
 from . import _lib
 
 
+class GsOpts(C.Structure):
+    """gcnhip_gs_opts (include/gcnhip.h)"""
+    _fields_ = [("rows", C.c_void_p), ("in_row_bits", C.c_void_p), ("accumulate", C.c_int), ("relu_dropout", C.c_int), ("training", C.c_int),
+                ("p", C.c_float), ("seed", C.c_uint64), ("d_epoch", C.c_void_p), ("elem_offset", C.c_uint64), ("keep_mask", C.c_void_p),
+                ("pos_bits", C.c_void_p), ("words_per_row", C.c_int), ("scaling", C.c_int)]
+
+
 class GcnHipError(RuntimeError):
     pass
 
@@ -144,6 +151,24 @@ class Device:
         ib = self._bits(row_nonzero) if row_nonzero is not None else None
         _ck(self.lib, self.lib.gcnhip_graphsum_rowset(self.ctx, g.h, rows_handle, xin.ptr, ld_in, out.ptr, ld_out, dim,
                                                        ib.ptr if ib else None), "gcnhip_graphsum_rowset")
+        return out.download()[:, :dim]
+
+    def graphsum_ex(self, g: "Graph", x, scaling, ld=None, rows=None, row_nonzero=None, prev=None, fill=np.nan):
+        """gcnhip_graphsum_ex: the factored operator.  `x` must already hold dinv[col] * (the reference's input) when scaling != 0;
+        prev: the rows of `out` before the call (accumulate = 1)"""
+        x = np.asarray(x, np.float32)
+        dim = x.shape[1]
+        ld = ld or (dim + 3) // 4 * 4
+        xin = self.padded(x, ld)
+        out = self.padded(prev, ld) if prev is not None else self.buf(np.full((g.n_rows, ld), fill, np.float32))
+        g.reserve(dim)
+        ib = self._bits(row_nonzero) if row_nonzero is not None else None
+        o = GsOpts()
+        o.rows = rows
+        o.in_row_bits = ib.ptr if ib else None
+        o.accumulate = 1 if prev is not None else 0
+        o.scaling = int(scaling)
+        _ck(self.lib, self.lib.gcnhip_graphsum_ex(self.ctx, g.h, C.byref(o), xin.ptr, ld, out.ptr, ld, dim), "gcnhip_graphsum_ex")
         return out.download()[:, :dim]
 
     def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None, row_nonzero=None):
@@ -534,6 +559,17 @@ class Graph:
         """segment scratch for aggregations up to `dim` columns (256 are reserved when the object is built)"""
         if dim > 256:
             _ck(self.dev.lib, self.dev.lib.gcnhip_graph_reserve_width(self.dev.ctx, self.h, int(dim)), "gcnhip_graph_reserve_width")
+
+    def scales(self):
+        """(dinv_row, dinv2_row, dinv_col, dinv2_col) of gcnhip_graph_scales, as numpy"""
+        ps = [C.c_void_p() for _ in range(4)]
+        _ck(self.dev.lib, self.dev.lib.gcnhip_graph_scales(self.h, *[C.byref(q) for q in ps]), "gcnhip_graph_scales")
+        out = []
+        for q, n in zip(ps, (self.n_rows, self.n_rows, self.n_cols, self.n_cols)):
+            a = np.empty(n, np.float32)
+            _ck(self.dev.lib, self.dev.lib.gcnhip_d2h(self.dev.ctx, a.ctypes.data, q, a.nbytes), "d2h")
+            out.append(a)
+        return out
 
     def coef(self):
         pc = C.c_void_p()

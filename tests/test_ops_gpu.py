@@ -148,6 +148,45 @@ def test_graphsum_output_row_mask(dev, gname, dim, ld):
     g.free()
 
 
+@pytest.mark.parametrize("gname", ["cora-syn", "hub"])
+@pytest.mark.parametrize("dim", [128, 41, 16, 7, 256])
+def test_factored_operator_vs_oracle(dev, oracle, gname, dim):
+    """gcnhip_graphsum_ex: out[r] = post[r] * sum_e in[col(e)] on an input pre-multiplied by dinv[col] equals the reference's
+    per-edge-coefficient operator (module.cpp:83-101) within the summation-order bound — scaling 1 (post = dinv), 2 (dinv^2:
+    the result pre-scaled for the next aggregation), 3 (no post factor), on a registered row subset, through an input-row
+    mask, as the second of two parts (accumulate), and on the hub graph's split rows (finalize launch)"""
+    gp, gi = hub_graph() if gname == "hub" else (lambda d: (d["g_indptr"], d["g_indices"]))(datagen.make_dataset(gname))
+    n = gp.size - 1
+    g = dev.graph(gp, gi)
+    dr, dr2, dc, dc2 = g.scales()
+    deg = np.diff(gp).astype(np.float64)
+    assert np.array_equal(dr, (1.0 / np.sqrt(deg)).astype(np.float32)) and np.array_equal(dr2, (1.0 / deg).astype(np.float32))
+    assert np.array_equal(dr, dc) and np.array_equal(dr2, dc2)
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    want = oracle.graphsum(gp, gi, x, dim)
+    mag = oracle.graphsum(gp, gi, np.abs(x), dim)
+    xs = (x * dr[:, None]).astype(np.float32)                     # what a producer's row-wise epilogue leaves
+    close_mag(dev.graphsum_ex(g, xs, 1), want, mag)
+    close_mag(dev.graphsum_ex(g, xs, 2) / dr[:, None].astype(np.float64), want, mag)
+    close_mag(dev.graphsum_ex(g, xs, 3) * dr[:, None].astype(np.float64), want, mag)
+    assert np.array_equal(dev.graphsum_ex(g, x, 0), dev.graphsum(g, x, ld_in=(dim + 3) // 4 * 4, ld_out=(dim + 3) // 4 * 4))   # scaling 0 = the per-edge operator
+    rows = rng.random(n) < 0.3
+    rows[0] = True
+    got = dev.graphsum_ex(g, xs, 1, rows=g.add_rowset(rows), fill=5.0)
+    close_mag(got[rows], want[rows], mag[rows])
+    assert np.all(got[~rows] == 5.0)
+    nz = rng.random(n) < 0.5
+    xm = x * nz[:, None]
+    close_mag(dev.graphsum_ex(g, (xm * dr[:, None]).astype(np.float32), 1, row_nonzero=nz), oracle.graphsum(gp, gi, xm, dim), mag)
+    # two operators with complementary columns: part 1 leaves the raw sum (3), part 2 adds its edges and applies the factor
+    own = np.arange(n) < n // 2
+    ga, gb = g.restricted(own), g.restricted(~own)
+    part = dev.graphsum_ex(ga, xs, 3)
+    close_mag(dev.graphsum_ex(gb, xs, 1, prev=part), want, mag)
+    ga.free(); gb.free(); g.free()
+
+
 @pytest.mark.parametrize("n,F,p", [(1000, 602, 128), (700, 64, 16), (513, 100, 41)])
 def test_aggregate_first_evaluation_form(dev, oracle, n, F, p):
     """gcnhip_feat_create_aggregated + gcnhip_spmm_fwd_relu: ReLU((A^.X).W) against the reference's order

@@ -56,7 +56,12 @@ def main():
             for dim in ((h,) if (len(sys.argv) > 4 and sys.argv[4] == "only_h") else (128, 256, 48)):
                 x = dev.buf(rng.standard_normal((N, dim), dtype=np.float32)); o = dev.buf((N, dim))
                 d_eff = 41 if dim == 48 else dim
-                ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, dim, o.ptr, dim, d_eff), "gs"), iters=10)
+                if int(os.environ.get("GS_SCALING", "0")):
+                    from cuda_gcn_amd.ops import GsOpts
+                    gso = GsOpts(); gso.scaling = int(os.environ["GS_SCALING"])
+                    ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum_ex(dev.ctx, g.h, C.byref(gso), x.ptr, dim, o.ptr, dim, d_eff), "gs_ex"), iters=10)
+                else:
+                    ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, dim, o.ptr, dim, d_eff), "gs"), iters=10)
                 bgs = 4 * (N + 1) + 4 * gi.size + 4 * gi.size * d_eff + 4 * N * d_eff
                 print(f"[{tag}] graphsum d={d_eff} ld={dim} table={N * dim * 4 / 2**20:.0f} MiB: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
                 x.free(); o.free()
@@ -74,10 +79,18 @@ def main():
     rng = np.random.default_rng(0)
     res = {}
 
+    scaling = int(os.environ.get("GS_SCALING", "0"))        # 1-3: the factored operator (gcnhip_graphsum_ex), as HipGCN launches it by default
+    from cuda_gcn_amd.ops import GsOpts
+    gso = GsOpts()
+    gso.scaling = scaling
+
     def gs(dim, ld):
         x = dev.buf(rng.standard_normal((N, ld)).astype(np.float32))
         o = dev.buf((N, ld))
-        ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, ld, o.ptr, ld, dim), "gs"))
+        if scaling:
+            ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum_ex(dev.ctx, g.h, C.byref(gso), x.ptr, ld, o.ptr, ld, dim), "gs_ex"))
+        else:
+            ms = timeit(dev, lambda: _ck(lib, lib.gcnhip_graphsum(dev.ctx, g.h, x.ptr, ld, o.ptr, ld, dim), "gs"))
         bgs = 4 * (N + 1) + 4 * nnzA + 4 * nnzA * dim + 4 * N * dim
         res[f"graphsum_d{dim}_ld{ld}"] = dict(ms=ms, GBps=bgs / ms / 1e6)
         print(f"graphsum d={dim} ld={ld}: {ms:.3f} ms  {bgs / ms / 1e6:.0f} GB/s (B_gs model)", flush=True)
