@@ -6,8 +6,12 @@ PKG      = cuda_gcn_amd
 LIBDIR   = $(PKG)/lib
 BINDIR   = $(PKG)/bin
 OBJDIR   = build/obj
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Iinclude
-CXXFLAGS = -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-sign-compare -Iinclude -I$(PKG)/host -I/opt/rocm/include -D__HIP_PLATFORM_AMD__
+# EXPERIMENTS=1: also compile the variants DESIGN.md records as built, bit-identical and slower (packed dH1 rows, the
+# persistent index-prefetching aggregation, non-temporal row loads, the in-launch segment sum, the persistent weight
+# gradient, W staged in LDS for the sparse forward, the backward pipeline of the host).  Their tests skip without it.
+EXPFLAG  = $(if $(EXPERIMENTS),-DGCNHIP_EXPERIMENTS,)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Iinclude $(EXPFLAG)
+CXXFLAGS = -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-sign-compare -Iinclude -I$(PKG)/host -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ $(EXPFLAG)
 
 KSRC = $(wildcard $(PKG)/csrc/*.hip)
 KOBJ = $(patsubst $(PKG)/csrc/%.hip,$(OBJDIR)/%.o,$(KSRC))

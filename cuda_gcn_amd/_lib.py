@@ -76,6 +76,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_error_string": (C.c_char_p, [I]),
     "gcnhip_last_error": (C.c_char_p, []),
     "gcnhip_version": (C.c_char_p, []),
+    "gcnhip_experiments": (I, []),
     "gcnhip_malloc": (I, [P, C.POINTER(P), C.c_size_t]),
     "gcnhip_free": (I, [P, P]),
     "gcnhip_memset_async": (I, [P, P, I, C.c_size_t]),

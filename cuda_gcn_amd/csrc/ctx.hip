@@ -70,6 +70,13 @@ const char *gcnhip_error_string(int code) {
 }
 
 const char *gcnhip_version(void) { return "gcnhip 0.1 (gfx950)"; }
+int gcnhip_experiments(void) {
+#ifdef GCNHIP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
     if (!out) return -1;

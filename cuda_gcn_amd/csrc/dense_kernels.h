@@ -702,9 +702,13 @@ static int launch_rowstream(gcnhip_ctx *c, const float *A, int lda, const float 
             default: RSP2(NT_, 0); break;                                                                 \
         }                                                                                                 \
     } while (0)
+#ifdef GCNHIP_EXPERIMENTS
     if (pack_slots) {
         if (NT == 4) RSP(4); else RSP(8);
     } else
+#else
+    if (pack_slots) return -1;
+#endif
     switch (NT) {
         case 1: RS(1); break;
         case 2: RS(2); break;

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_persist_kernel(PersistFwdArg
     }
 }
 
+#ifdef GCNHIP_EXPERIMENTS   // the persistent weight gradient: built, correct, measured slower
 // ------------------------------------------------------------------------------------------------ backward
 // dW[K x 128] = X~^T . dH0 over this workgroup's contiguous share of the m rows (the reduction dimension), ALL of the
 // output held in the accumulators of its eight waves: ceil(K/32) x 4 blocks of 32 x 32, block b -> wave b % 8 (so a wave
@@ -477,3 +478,4 @@ __global__ __launch_bounds__(512, 2) void dense_bwd_persist_kernel(PersistBwdArg
         }
     }
 }
+#endif  // GCNHIP_EXPERIMENTS

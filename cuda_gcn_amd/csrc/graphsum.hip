@@ -215,10 +215,15 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     }
 #pragma unroll
     for (int m = L; m < WAVE; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-    if (slot >= 0 && !a.seg_count) {                        // a finalize launch will add the segments
+#ifndef GCNHIP_EXPERIMENTS
+    if (slot >= 0) {                                        // a finalize launch will add the segments
+#else
+    if (slot >= 0 && !a.seg_count) {                        // a finalize launch will add the segments (seg_count: the in-launch sum, an experiment)
+#endif
         if (g == 0 && active) *reinterpret_cast<float4 *>(a.partials + (size_t)slot * a.part_ld + col0) = acc;
         return;
     }
+#ifdef GCNHIP_EXPERIMENTS
     if (slot >= 0) {
         // Hand-off between workgroups on any XCDs (cdna guide, Guideline 16): the partial leaves WRITE-THROUGH (sc1: no
         // release fence, which would write back this XCD's whole dirty L2), the wave drains its stores, one lane takes a
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
             for (; k < info.y; k++) acc = f4_add(acc, *reinterpret_cast<const float4 *>(pp + (size_t)k * a.part_ld));
         }
     }
+#endif
     uint32_t nib = 0;                                       // this lane's four (out > 0) bits, at their place in the row's word
     if (g == 0 && active) {
         float *o = a.out + (size_t)row * a.ld_out + col0;
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
     }
 }
 
+#ifdef GCNHIP_EXPERIMENTS   // measured-slower variants: compiled only by `make EXPERIMENTS=1`
 // ---- EXPERIMENT: persistent form that also keeps the next chunk's (index, coef) pairs in flight -------------------
 // A wave walks tasks t, t + stride, ... of its XCD group's range; while the rows of chunk k are gathered, the pairs of
 // chunk k+1 (of the same task, or the first chunk of the wave's next task, whose record was fetched a task earlier) are
@@ -482,6 +489,8 @@ __global__ __launch_bounds__(256) void rowpack_expand_kernel(const uint32_t *__r
     int off = 2;
     for (int c = 0; c < 64; c++) d[c] = ((m >> c) & 1ull) ? __uint_as_float(s[off++]) : 0.f;
 }
+
+#endif  // GCNHIP_EXPERIMENTS
 
 // ---- bf16 table, f32 accumulate (opt-in storage format) ------------------------
 // The gathered rows are stored as bfloat16 (round-to-nearest-even of the f32 values, made by
@@ -762,6 +771,7 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], const gcnhip_ctx *c) {
     // EXPERIMENT (GCNHIP_GS_PIPE): the persistent form that also prefetches the next chunk's indices.  Measured slower
     // than a wave per task once the row loads are batched (1.15 vs 0.85 ms at Reddit scale): fresh waves arriving in
     // task order keep the XCD's window of active rows tight, statically strided persistent waves drift apart.
+#ifdef GCNHIP_EXPERIMENTS
     const bool pipe = c->opt.gs_pipe != 0;
     if (pipe && a.n_tasks && !a.out_bits && !a.accumulate && !a.pos_bits && a.coef) {
         a.seg_count = nullptr; a.slot_info = nullptr;      // the experiment keeps the finalize launch
@@ -769,14 +779,17 @@ static void launch_vec(GsArgs &a, const int (*xb)[9], const gcnhip_ctx *c) {
         graphsum_pipe_kernel<L><<<dim3(per_xcd * 8, sliced ? 1 : ychunks), 256, 0, s>>>(a);
         return;
     }
+#endif
     // Batch depth by regime.  A table that fits the 256 MiB Infinity Cache is gathered with 4 row loads in flight per lane
     // group (latency-bound otherwise: 1.08 -> 0.85 ms at Reddit scale).  Past it the kernel is HBM-bound and 2 is the
     // optimum (R-MAT scale 21, 1 GiB table, d = 128: 5.33 / 5.16 / 5.51 ms with 1 / 2 / 4 in flight).
     const int force_u = c->opt.gs_u;
     const int u = force_u ? force_u : (a.table_bytes > ((size_t)256 << 20) ? 2 : 4);
     const dim3 grid(max_blocks * 8, sliced ? 1 : ychunks);
+#ifdef GCNHIP_EXPERIMENTS
     const bool nt_all = c->opt.gs_nt != 0;                            // EXPERIMENT: every row load non-temporal
     if (sliced && nt_all && L == 16 && a.coef) { graphsum_vec_kernel<16, 4, true, true><<<grid, 256, 0, s>>>(a); return; }
+#endif
     if (sliced) {
         if (u >= 4) graphsum_vec_kernel<L, 4, true><<<grid, 256, 0, s>>>(a);
         else if (u >= 2) graphsum_vec_kernel<L, 2, true><<<grid, 256, 0, s>>>(a);
@@ -852,7 +865,11 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     // does) and no finalize launch follows.  Same bits; measured no faster at 5 K segments and slower as their number grows
     // (every segment wave keeps its slot through a store drain and an atomic round trip: 0.835 vs 0.774 ms at 20 K segments),
     // so the default stays the fire-and-forget partial store plus one 8 us launch.  (Context option gs_fold.)
+#ifdef GCNHIP_EXPERIMENTS
     const bool fold = c->opt.gs_fold != 0;
+#else
+    const bool fold = false;
+#endif
     if (!in_bf && vec && n_split_rows && g->seg_count && fold) {
         a.slot_info = g->slot_info; a.seg_count = g->seg_count;
         a.n_slots_bytes = (int)std::min<size_t>((size_t)g->n_slots * g->part_ld * sizeof(float), 0x7FFFFFFFu);
@@ -948,6 +965,12 @@ int gcnhip_graphsum_ex(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_gs_opt
                          o->pos_bits, o->words_per_row, o->scaling);
 }
 
+#ifndef GCNHIP_EXPERIMENTS
+int gcnhip_rowpack_create(gcnhip_ctx *, gcnhip_rowpack **, int, int) { return gcnhip_fail("this entry point is a measured-slower experiment: build the library with `make EXPERIMENTS=1`"); }
+int gcnhip_rowpack_destroy(gcnhip_ctx *, gcnhip_rowpack *) { return 0; }
+int gcnhip_rowpack_expand(gcnhip_ctx *, const gcnhip_rowpack *, float *, int) { return gcnhip_fail("this entry point is a measured-slower experiment: build the library with `make EXPERIMENTS=1`"); }
+int gcnhip_graphsum_packed(gcnhip_ctx *, const gcnhip_graph *, const gcnhip_rowpack *, const float *, int, float *, int) { return gcnhip_fail("this entry point is a measured-slower experiment: build the library with `make EXPERIMENTS=1`"); }
+#else
 int gcnhip_rowpack_create(gcnhip_ctx *c, gcnhip_rowpack **out, int rows, int cols) {
     if (!c || !out || rows < 0 || cols < 64 || cols % 64 != 0) return -1;
     GCNHIP_TRY(hipSetDevice(c->device));
@@ -1005,6 +1028,8 @@ int gcnhip_graphsum_packed(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_ro
     }
     return 0;
 }
+
+#endif  // GCNHIP_EXPERIMENTS
 
 int gcnhip_f32_to_bf16(gcnhip_ctx *c, const float *src, int ld_src, uint16_t *dst, int ld_dst, int64_t rows, int dim) {
     if (!c || !src || !dst || rows < 0 || dim <= 0 || ld_src < dim || ld_dst < dim || ld_dst % 8 != 0 || !aligned16(dst)) return -1;

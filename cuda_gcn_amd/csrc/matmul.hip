@@ -64,6 +64,12 @@ int gcnhip_matmul_bwd_fused_bits(gcnhip_ctx *c, const float *a, int lda, const f
 }
 
 // the same with da leaving as packed rows (dense_kernels.h): da_dense receives only the halves that do not fit a slot
+#ifndef GCNHIP_EXPERIMENTS
+int gcnhip_matmul_bwd_packed(gcnhip_ctx *, const float *, int, const float *, int, const float *, int, float *, int, gcnhip_rowpack *,
+                             float *, int, int, int, int, float) {
+    return gcnhip_fail("gcnhip_matmul_bwd_packed is a measured-slower experiment: build the library with `make EXPERIMENTS=1`");
+}
+#else
 int gcnhip_matmul_bwd_packed(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
                              const float *dc, int lddc, float *da_dense, int ldda, gcnhip_rowpack *pack,
                              float *db, int lddb, int m, int n, int p, float relu_dropout_scale) {
@@ -77,6 +83,7 @@ int gcnhip_matmul_bwd_packed(gcnhip_ctx *c, const float *a, int lda, const float
     }
     return launch_rowstream(c, dc, lddc, b, ldb, 1, da_dense, ldda, m, p, n, a, lda, relu_dropout_scale, nullptr, 0, pack->slots, pack->halves);
 }
+#endif
 
 // Every form of the fused backward behind one call, with an optional factor per row of da (the factored aggregation,
 // gcnhip_graphsum_ex: dH1' = dinv^2 . dH1):  db = a^T . dc when db != NULL (a is then required);

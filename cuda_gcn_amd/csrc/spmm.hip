@@ -205,7 +205,11 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
             pa.x = t.x; pa.ldx = t.ldx; pa.wp = c->wpack; pa.out = out; pa.ldo = ld_out;
             pa.m = t.m; pa.K = t.K; pa.n_chunks = n_chunks; pa.n_rb = ceil_div(t.m, 32);
             pa.bits = t.bits; pa.relu = relu;
+#ifdef GCNHIP_EXPERIMENTS
             pa.dbg_linear = c->opt.dbg_linear ? 1 : 0;
+#else
+            pa.dbg_linear = 0;
+#endif
             const int wgs = std::max(1, std::min(c->n_cu, pa.n_rb));
             if (pa.bits) dense_fwd_persist_kernel<true><<<wgs, 512, 0, c->stream>>>(pa);
             else dense_fwd_persist_kernel<false><<<wgs, 512, 0, c->stream>>>(pa);
@@ -255,8 +259,14 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
     // every XCD's L2, and the rows were never what bound these kernels (spmm_sparse.h).  Opt-in: context option spmm_lds = 1.
     const size_t w_bytes = (size_t)a.w_floats * sizeof(float);
     const int wgs = std::max(1, std::min(c->n_cu, ceil_div(f->n_rows, 16)));
+#ifdef GCNHIP_EXPERIMENTS
     const bool lds_form = c->opt.spmm_lds == 1 && vec && units <= 64 && p <= 256 && w_bytes <= SPMM_LDS_MAX_BYTES && f->n_rows > 0;
+#else
+    const bool lds_form = false;
+    (void)w_bytes; (void)wgs;
+#endif
     a.nnz_bytes = (int)std::min<int64_t>(f->nnz * 4, 0x7FFFFFFF);
+#ifdef GCNHIP_EXPERIMENTS
     if (lds_form && units <= 16 && f->nnz * 4 < 0x7FFFFFFF && !c->opt.spmm_general) {      // narrow rows: the shuffle-free kernel over LDS
         const int per_cu = w_bytes <= 32 * 1024 ? 2 : 1;                                    // 1024-thread workgroups: at most two per CU
         const int wq = std::max(1, std::min(c->n_cu * per_cu, ceil_div(f->n_rows, 16)));
@@ -285,6 +295,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         GCNHIP_LAUNCH_CHECK();
         return 0;
     }
+#endif
     // rows per wave: enough waves to fill every slot about twice, at most 8 rows each (one wave per row on small inputs)
     a.rows_per_wave = std::max(1, std::min(8, (int)(f->n_rows / ((int64_t)c->n_cu * 64))));
     if (c->opt.spmm_rows > 0) a.rows_per_wave = std::min(32, c->opt.spmm_rows);
@@ -341,6 +352,9 @@ static bool dense_bwd_plan(const gcnhip_ctx *c, const gcnhip_feat *f, int p, int
 
 // The whole product by the persistent form (dense_persist.h): one workgroup per CU, each with a contiguous share of the rows
 // and ALL of dW in its accumulators; one slab per workgroup.  Returns 1 when the shape is not its (then the split tiles run).
+#ifndef GCNHIP_EXPERIMENTS
+static int dense_bwd_persist(gcnhip_ctx *, const gcnhip_feat *, const float *, const float *, int, int, const DropSpec &) { return 1; }
+#else
 static int dense_bwd_persist(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p, const DropSpec &d) {
     // EXPERIMENT, opt-in (GCNHIP_GEMM_PERSIST_BWD): measured SLOWER than the split tiles at Reddit scale (0.50 ms without,
     // 0.61 ms with dropout against 0.387 ms; profiles/r03_gemm_pmc.json: the pipes 41-53 % busy, 37 % of the wave cycles
@@ -366,6 +380,7 @@ static int dense_bwd_persist(gcnhip_ctx *c, const gcnhip_feat *f, const float *v
     c->slab_n = G;
     return 0;
 }
+#endif
 
 // splits [s0, s1) of the plan into their slabs
 static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,

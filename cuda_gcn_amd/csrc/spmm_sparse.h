@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void spmm_csr_fwd_kernel(SpFwdArgs a) {
     }
 }
 
+#ifdef GCNHIP_EXPERIMENTS   // W staged in LDS: built, bit-identical, measured slower wherever W fits
 // W staged in LDS once per workgroup (16 waves); the workgroup then walks rows wave by wave.  16-byte aligned rows only.
 template <int L>
 __global__ __launch_bounds__(1024) void spmm_csr_fwd_lds_kernel(SpFwdArgs a) {
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(1024) void spmm_csr_fwd_lds_kernel(SpFwdArgs a) {
     for (int row = blockIdx.x * 16 + (threadIdx.x >> 6); row < a.n_rows; row += gridDim.x * 16)
         sp_fwd_row<L, true>(a, sp_ws, row, lane, epoch);
 }
+#endif  // GCNHIP_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The narrow-row kernels (16-byte aligned rows of at most 64 floats: L <= 16 lanes per row — hidden 16 is the reference's
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256) void spmm_csr_fwd_q_kernel(SpFwdArgs a) {
     sp_fwd_q_rows<L>(a, a.w, row0, min(K, a.n_rows - row0), lane, epoch);
 }
 
+#ifdef GCNHIP_EXPERIMENTS
 // ... with W staged in LDS once per (persistent) workgroup: the W rows then cost no L2 traffic at all
 template <int L>
 __global__ __launch_bounds__(1024) void spmm_csr_fwd_q_lds_kernel(SpFwdArgs a) {
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(1024) void spmm_csr_fwd_q_lds_kernel(SpFwdArgs a) {
     for (int row0 = (blockIdx.x * 16 + (threadIdx.x >> 6)) * K; row0 < a.n_rows; row0 += gridDim.x * 16 * K)
         sp_fwd_q_rows<L>(a, sp_wq, row0, min(K, a.n_rows - row0), lane, epoch);
 }
+#endif  // GCNHIP_EXPERIMENTS
 
 // ----------------------------------------------------------- sparse backward
 // A task = (column j of X, entries [q0, q1) of its CSC list, partial slot or -1): dW[j, :] (or the slot's partial row)

@@ -89,6 +89,12 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // fused f32 path only; HIPGCN_EDGE_COEF restores the reference's per-edge coefficients.
     if (getenv("HIPGCN_EDGE_COEF")) flags |= HIPGCN_EDGE_COEF;
     if (getenv("HIPGCN_PACKED_DH1")) flags |= HIPGCN_PACKED_DH1;
+    if (getenv("HIPGCN_BWD_PIPELINE")) flags |= HIPGCN_BWD_PIPELINE;
+    if ((flags & (HIPGCN_PACKED_DH1 | HIPGCN_BWD_PIPELINE)) && !gcnhip_experiments()) {
+        // measured-slower variants live behind the library's compile-time switch (make EXPERIMENTS=1)
+        fprintf(stderr, "gcn-hip: HIPGCN_PACKED_DH1 / HIPGCN_BWD_PIPELINE ignored: libgcnhip.so was built without GCNHIP_EXPERIMENTS\n");
+        flags &= ~(HIPGCN_PACKED_DH1 | HIPGCN_BWD_PIPELINE);
+    }
     factored_ = !(flags & (HIPGCN_MODULAR | HIPGCN_BF16_TABLES | HIPGCN_PACKED_DH1 | HIPGCN_EDGE_COEF));
     const int world = env.comm->size(), rank = env.comm->rank();
     const int N = params.num_nodes, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
@@ -530,7 +536,6 @@ void HipGCN::build_modules() {
         }
         // Opt-in: measured at Reddit scale, 2 / 4 / 8 blocks: 254 / 240 / 237 epochs/s against 277 on one stream — the
         // split-K product next to the gather takes the gather's wave slots, and each block launch has its own tail.
-        if (getenv("HIPGCN_BWD_PIPELINE")) flags |= HIPGCN_BWD_PIPELINE;
         if ((flags & HIPGCN_BWD_PIPELINE) && !env.bf16_tables && !dh1_pack) build_bwd_pipeline(sm, gs);
         modules.push_back(sm);
         modules.push_back(gs);

@@ -78,6 +78,11 @@ const char *gcnhip_error_string(int code);
 /* detail of the calling thread's most recent -1 (argument error) where the library has one to give, else "" */
 const char *gcnhip_last_error(void);
 const char *gcnhip_version(void);
+/* 1 when the library was built with `make EXPERIMENTS=1`: the variants DESIGN.md records as built, bit-identical and SLOWER
+ * (packed rows: gcnhip_rowpack_*, gcnhip_matmul_bwd_packed, gcnhip_graphsum_packed; the options gs_pipe, gs_nt, gs_fold,
+ * gemm_persist_bwd, spmm_lds, dbg_linear) are compiled in.  The default build leaves them out: those entry points then
+ * return -1 (gcnhip_last_error() says why) and those options are ignored. */
+int gcnhip_experiments(void);
 
 /* ---- memory (CUDAVariable ctor/dtor/zero: src/cuda/cuda_variable.cu:3-31) ---- */
 int gcnhip_malloc(gcnhip_ctx *ctx, void **ptr, size_t bytes);

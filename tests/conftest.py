@@ -28,3 +28,13 @@ def ref():
     if not Ref.available():
         pytest.skip("oracle/_ref not built (reference tree absent on this box)")
     return Ref()
+
+
+@pytest.fixture(scope="session")
+def experiments():
+    """the measured-slower variants (packed dH1 rows, in-launch segment sum, backward pipeline, W in LDS ...) are compiled
+    only by `make EXPERIMENTS=1` (include/gcnhip.h, gcnhip_experiments); their bit-identity tests skip on the default build"""
+    from cuda_gcn_amd import _lib
+    if not _lib.gcnhip().gcnhip_experiments():
+        pytest.skip("libgcnhip.so built without GCNHIP_EXPERIMENTS (make EXPERIMENTS=1)")
+    return True

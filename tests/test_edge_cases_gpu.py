@@ -160,7 +160,7 @@ def test_wide_aggregation_on_split_rows_needs_reserve_width(oracle):
 
 
 @pytest.mark.parametrize("dim", [128, 41, 256])
-def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim):
+def test_in_kernel_segment_sum_equals_the_two_launch_form(oracle, dim, experiments):
     """split (hub) rows: the wave that finishes a row's last segment adds the partials itself (graphsum.hip, Guideline 16
     hand-off; opt-in, context option gs_fold).  Same bits as the default graphsum_finalize launch, launch after launch on CHANGING inputs —
     a partial served from a stale cache line of the previous launch would show here — and with the ReLU+dropout+bits

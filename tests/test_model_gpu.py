@@ -323,7 +323,7 @@ def test_aggregate_first_eval_matches_reference_order(name, hidden):
 
 
 @pytest.mark.parametrize("name,hidden", [("reddit-mini", 128), ("cora-syn", 64)])
-def test_packed_dh1_is_bit_identical_to_dense(name, hidden):
+def test_packed_dh1_is_bit_identical_to_dense(name, hidden, experiments):
     """dH1 travelling as packed rows from the Matmul backward to the hidden layer's backward aggregation changes
     no bit of any weight or reported number"""
     from cuda_gcn_amd.model import HipGCNModel, PACKED_DH1, EDGE_COEF
@@ -357,7 +357,7 @@ def test_restricted_backward_operator_matches_masked_launch(name, hidden):
 
 
 @pytest.mark.parametrize("extra", ["graph", "no_graph", "lane"])
-def test_backward_pipeline_is_bit_identical(extra, monkeypatch):
+def test_backward_pipeline_is_bit_identical(extra, monkeypatch, experiments):
     """opt-in BWD_PIPELINE: hidden-layer backward aggregation in row blocks with each block's share of dW1 on a second
     stream against the one-stream order: same kernels, same rows, same split ranges — not a bit of any trace or
     weight differs, replayed from a captured hipGraph, eagerly, or beside the validation lane"""

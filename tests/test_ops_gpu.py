@@ -229,7 +229,7 @@ def test_gather_rows_packs_exactly(dev, ld):
 
 @pytest.mark.parametrize("gname", ["cora-syn", "hub"])
 @pytest.mark.parametrize("n,density", [(128, 0.25), (64, 0.25), (256, 0.3), (128, 0.6), (128, 1.0), (128, 0.0)])
-def test_packed_rows_backward_is_bit_identical_to_dense(dev, gname, n, density):
+def test_packed_rows_backward_is_bit_identical_to_dense(dev, gname, n, density, experiments):
     """dH1 as packed rows (gcnhip_matmul_bwd_packed + gcnhip_graphsum_packed) against the dense path
     (gcnhip_matmul_bwd_fused + gcnhip_graphsum): the same bits, whatever share of the halves overflows their slot
     (density 0.6: most halves hold more than 30 values; 1.0: all of them; 0.0: empty masks)"""
@@ -591,7 +591,7 @@ def test_spmm_sparse_long_columns_every_task_width(oracle, p, nw, general):
 
 
 @pytest.mark.parametrize("name,p", [("pubmed-syn", 16), ("cora-syn", 16), ("cora-syn", 7), ("tiny-syn", 64)])
-def test_spmm_forward_from_lds_gives_the_same_bits(name, p):
+def test_spmm_forward_from_lds_gives_the_same_bits(name, p, experiments):
     """W staged in LDS (spmm_csr_fwd_lds_kernel, option spmm_lds = 1) against the general kernel gathering rows from global
     memory (spmm_general = 1): the same lane groups add the same products in the same order — equal bit for bit, with dropout
     and with the ReLU epilogue; the default narrow-row kernel associates the sum differently: equal within the f32 bound"""
