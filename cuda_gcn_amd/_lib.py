@@ -97,6 +97,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graphsum_masked": (I, [P, P, P, I, P, I, I, P, P]),
     "gcnhip_graph_add_rowset": (I, [P, P, P, C.POINTER(P)]),
     "gcnhip_graph_create_restricted": (I, [P, C.POINTER(P), P, P]),
+    "gcnhip_graph_clone": (I, [P, C.POINTER(P), P]),
     "gcnhip_rowset_size": (I, [P, C.POINTER(I)]),
     "gcnhip_graphsum_rowset": (I, [P, P, P, P, I, P, I, I, P]),
     "gcnhip_graphsum_relu_dropout": (I, [P, P, P, I, P, I, I, I, F, U64, P, U64, P]),

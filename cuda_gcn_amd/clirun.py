@@ -63,6 +63,7 @@ def run(name, cwd, hidden="-", epochs="-", dropout="-", early_stopping="-", env=
     out["command"] = " ".join(["gcn-hip"] + args[1:])
     out["env"] = dict(env or {})
     out["process_wall_s"] = wall
+    out["stderr_tail"] = r.stderr[-6000:]
     n = len(out["epochs"])
     if n and out.get("total_training_time_s"):
         out["epochs_per_s"] = n / out["total_training_time_s"]

@@ -53,6 +53,15 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
 
 void HipGCN::init(const HipGCNOptions &opt) {
     device_ = opt.device;
+    // HIPGCN_VERBOSE: where the model build's wall time goes (stderr), phase by phase
+    const bool verbose = getenv("HIPGCN_VERBOSE") != nullptr && opt.rank == 0;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "gcn-hip: build %-34s %8.3f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
     // argument checks first: nothing is allocated for a request that cannot be served
     if (opt.world > 1 && !opt.comm && !opt.host_allgather && !(flags & HIPGCN_NULL_COMM) && !opt.nccl_id)
         throw GcnHipFailure(-1, "world > 1 needs an RCCL unique id");
@@ -123,6 +132,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
     const bool may_renumber = world > 1 && !(flags & HIPGCN_ID_PARTITION) &&
                               ((flags & HIPGCN_STRUCTURE_PARTITION) || (exchange_mode != 1 && !(flags & HIPGCN_HOST_MASKS)));
     if (may_renumber) renumber_nodes(world);
+    phase("context, comm, node order");
     const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
     part = make_partition(gp.data(), N, world);
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
@@ -136,6 +146,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
         StructureGroups sg = structure_groups(gp.data(), gi.data(), N);
         if (sg.useful) { structure_group = std::move(sg.group); structure_n_groups = sg.n_groups; }
     }
+    phase("labels / structure groups");
     xplan = make_exchange_plan(gp.data(), gi.data(), N, part, rank, exchange_mode);
     env.plan = &xplan;
     env.xbuf = &xbuf;
@@ -147,6 +158,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph, gp.data(), gi.data(), N, N, nullptr));
         GCNHIP_CHECK(gcnhip_graph_reserve_width(env.ctx, graph, std::max(params.hidden_dim, params.output_dim)));
     }
+    phase("adjacency object (gcnhip_graph_create)");
     const std::vector<int> &fp = data->feature_index.indptr, &fi = data->feature_index.indices;
     const long f0 = fp[r0], f1 = fp[r1];
     {
@@ -170,6 +182,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
         GCNHIP_CHECK(gcnhip_graph_create(env.ctx, &graph_l1, lp.data(), gi.data() + gp[r0], n_local, N, deg.data()));
         GCNHIP_CHECK(gcnhip_graph_reserve_width(env.ctx, graph_l1, std::max(params.hidden_dim, params.output_dim)));
     }
+    phase("feature objects (gcnhip_feat_create)");
     // truth per split, once (the reference rebuilds and re-uploads it per call: cuda_gcn.cu:85-97)
     {
         int32_t *d_split = dev_upload(env.ctx, data->split.data() + r0, (size_t)n_local);
@@ -283,7 +296,9 @@ void HipGCN::init(const HipGCNOptions &opt) {
         env.keep_input_bwd = d_keep0 + (f0 - keep0_first);
         env.keep_hidden = d_keep1;
     }
+    phase("truth, row subsets, variables, Glorot");
     if (!(flags & HIPGCN_NO_ROW_GROUPS)) tune_schedule();
+    phase("row schedules timed (tune_schedule)");
     // The output layer's backward aggregates dZ, which is zero outside the training split: the edges that point at those
     // rows leave the operator for good (a third of Reddit's, 95 % of Cora's) — after the row order has been chosen,
     // which the restricted object inherits.
@@ -297,7 +312,9 @@ void HipGCN::init(const HipGCNOptions &opt) {
     build_modules();
     if (getenv("HIPGCN_NO_AGG_FIRST_EVAL")) flags |= HIPGCN_NO_AGG_FIRST_EVAL;
     if (!(flags & (HIPGCN_NO_AGG_FIRST_EVAL | HIPGCN_MODULAR)) && gcnhip_feat_is_dense(feat) && n_local > 0) build_agg_first_eval();
+    phase("restricted operator, modules, A^.X");
     if (factored_) apply_factored_scales();
+    phase("factored scales");
     // opt-in everywhere: with several GPUs the lane brings a second communicator and the turnstile, which must be measured
     // on a multi-GPU node before they may become a default there (bench.py tries both schedules)
     if (getenv("HIPGCN_EVAL_LANE")) flags |= HIPGCN_EVAL_LANE;
@@ -316,6 +333,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
     optimizer.reset(new HipAdam());
     optimizer->init(&env, {{W1, true}, {W2, false}}, ap, params.epochs > 0 ? params.epochs + 8 : 8);   // gcn.cpp:62-65
     GCNHIP_CHECK(gcnhip_ctx_sync(env.ctx));
+    phase("validation lane, optimizer");
 }
 
 // The first layer of the factored model multiplies D^-1/2 X (and, for evaluation, D^-1/2 (A^ X)): the factor that the
@@ -655,18 +673,11 @@ void HipGCN::build_eval_lane() {
     GCNHIP_CHECK(gcnhip_memset_async(L.env.ctx, q, 0xFF, sizeof(uint32_t)));
     GCNHIP_CHECK(gcnhip_malloc(L.env.ctx, &q, 4 * sizeof(float))); L.d_result = (float *)q;
     GCNHIP_CHECK(gcnhip_malloc(L.env.ctx, &q, 2 * sizeof(int32_t))); L.d_result_i = (int32_t *)q;
-    // same adjacency, own scratch for split rows
+    // same adjacency, own scratch for split rows: a device-side clone of the training lane's object, in the row schedule that
+    // lane measured as fastest (round 4: rebuilding it from the host lists was 0.67 s of a 1.8 s model build at Reddit scale)
     const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
-    if (world > 1) {
-        const LocalGraph lg = build_table_graph(gp.data(), gi.data(), params.num_nodes, part, xplan);
-        GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, lg.indptr.data(), lg.indices.data(), lg.n_rows, lg.n_cols, lg.col_deg.data()));
-        GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph, std::max(params.hidden_dim, params.output_dim)));
-    } else {
-        GCNHIP_CHECK(gcnhip_graph_create(L.env.ctx, &L.graph, gp.data(), gi.data(), params.num_nodes, params.num_nodes, nullptr));
-        GCNHIP_CHECK(gcnhip_graph_reserve_width(L.env.ctx, L.graph, std::max(params.hidden_dim, params.output_dim)));
-    }
+    GCNHIP_CHECK(gcnhip_graph_clone(L.env.ctx, &L.graph, graph));
     if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(L.env.ctx, L.graph, L.split_rows);
-    apply_schedule(L.env.ctx, L.graph);                     // the schedule the training lane measured as fastest
     const ExchangePlan *xp = world > 1 ? &xplan : nullptr;
     L.H0.reset(new HipVariable()); L.H1.reset(new HipVariable()); L.Z0.reset(new HipVariable()); L.Z.reset(new HipVariable());
     if (feat_agg) {

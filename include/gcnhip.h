@@ -182,6 +182,11 @@ int gcnhip_graphsum_rowset(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_
  * scale the masked class-width backward takes 0.39 ms, the restricted operator 0.27 ms (a third of the edges gone and
  * no predicate on the loads).  The object is independent of the parent: destroy it with gcnhip_graph_destroy. */
 int gcnhip_graph_create_restricted(gcnhip_ctx *ctx, gcnhip_graph **out, const gcnhip_graph *parent, const uint32_t *h_col_bits);
+/* A second, independent object with the parent's edges, coefficients and CURRENT row order and its own task lists and split-row
+ * scratch — for a second stream that aggregates through the same adjacency at the same time (HipGCN's validation lane).  Device
+ * copies only: the host preparation of gcnhip_graph_create (per-row neighbour sort: 0.4 s at Reddit scale) is not repeated.
+ * Row subsets are not copied: register them on the clone.  Synchronises the context. */
+int gcnhip_graph_clone(gcnhip_ctx *ctx, gcnhip_graph **out, const gcnhip_graph *parent);
 /* One PART of an aggregation whose edges were split over two operators with the same rows (both made by
  * gcnhip_graph_create_restricted from one parent with complementary column sets).  The row-partitioned epoch uses it
  * to start on the edges that point at this rank's own rows while the rows of the other ranks are still in flight on the
