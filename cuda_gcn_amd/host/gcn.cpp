@@ -1,6 +1,7 @@
 #include "gcn.h"
 #include "cluster.h"
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,10 +143,15 @@ void HipGCN::init(const HipGCNOptions &opt) {
     labels_assortative = !(flags & (HIPGCN_NO_ROW_GROUPS | HIPGCN_NO_LABEL_HINT)) && labels_are_assortative(*data, N, C);
     // no usable labels: look for row groups in the graph itself (one pass over the edges per sweep, every rank the same
     // result); whether they are used is decided by timing, like every other schedule (tune_schedule)
-    if (!(flags & HIPGCN_NO_ROW_GROUPS) && !labels_assortative && n_local >= 4096 && !getenv("HIPGCN_NO_STRUCTURE_GROUPS")) {
-        StructureGroups sg = structure_groups(gp.data(), gi.data(), N);
-        if (sg.useful) { structure_group = std::move(sg.group); structure_n_groups = sg.n_groups; }
-    }
+    // (on a host thread beside the object builds and H2D copies below: one sweep over an R-MAT graph of scale 22 is 3 s, and its
+    //  result is not needed before the schedules are timed)
+    std::future<StructureGroups> groups_search;
+    if (!(flags & HIPGCN_NO_ROW_GROUPS) && !labels_assortative && n_local >= 4096 && !getenv("HIPGCN_NO_STRUCTURE_GROUPS"))
+        groups_search = std::async(std::launch::async, [&gp, &gi, N]() { return structure_groups(gp.data(), gi.data(), N); });
+    struct JoinGroups {                       // never leave the thread running over a dataset that is being torn down
+        std::future<StructureGroups> &f;
+        ~JoinGroups() { if (f.valid()) f.wait(); }
+    } join_groups{groups_search};
     phase("labels / structure groups");
     xplan = make_exchange_plan(gp.data(), gi.data(), N, part, rank, exchange_mode);
     env.plan = &xplan;
@@ -297,6 +303,11 @@ void HipGCN::init(const HipGCNOptions &opt) {
         env.keep_hidden = d_keep1;
     }
     phase("truth, row subsets, variables, Glorot");
+    if (groups_search.valid()) {
+        StructureGroups sg = groups_search.get();
+        if (sg.useful) { structure_group = std::move(sg.group); structure_n_groups = sg.n_groups; }
+        phase("structure groups (waited for)");
+    }
     if (!(flags & HIPGCN_NO_ROW_GROUPS)) tune_schedule();
     phase("row schedules timed (tune_schedule)");
     // The output layer's backward aggregates dZ, which is zero outside the training split: the edges that point at those
@@ -438,9 +449,11 @@ void HipGCN::tune_schedule() {
     float best = 0.f;
     Cand pick = cands[0];
     gcnhip_graph *g = replicate_l1 ? graph_l1 : graph;       // the layer-1 aggregation, the widest one
+    bool fresh = true;                                       // g still has the schedule it was built with: descending degree = candidate 0
     for (const Cand &c : cands) {
         sched_mode = c.mode; sched_groups = c.groups;
-        apply_schedule(env.ctx, g);
+        if (!(fresh && c.mode == 0)) apply_schedule(env.ctx, g);
+        fresh = false;
         float ms = 0.f;
         for (int it = 0; it < 3; it++) {                     // first run warms the caches and sizes the scratch
             if (it == 1) GCNHIP_CHECK(gcnhip_event_record(env.ctx, e0));
@@ -452,9 +465,10 @@ void HipGCN::tune_schedule() {
     }
     gcnhip_event_destroy(e0);
     gcnhip_event_destroy(e1);
+    const bool g_has_pick = sched_mode == pick.mode && sched_groups == pick.groups;    // the last candidate timed is still applied to g
     sched_mode = pick.mode; sched_groups = pick.groups;
-    apply_schedule(env.ctx, graph);
-    if (graph_l1) apply_schedule(env.ctx, graph_l1);
+    if (!(g == graph && g_has_pick)) apply_schedule(env.ctx, graph);
+    if (graph_l1 && !(g == graph_l1 && g_has_pick)) apply_schedule(env.ctx, graph_l1);
     GCNHIP_CHECK(gcnhip_memset_async(env.ctx, out->data, 0, out->elems() * sizeof(float)));
 }
 
