@@ -24,6 +24,7 @@
 //  * early_stopping > 0: yes — gcn.cpp:141-150 compares validation losses between epochs.  The loop is the
 //    reference's (one epoch, wait, print, decide) and evaluation keeps its operation order A^.(X.W1), so that a
 //    near-tie stops at the epoch gcn-seq stops at.
+// GCN_WRITE_CACHE=1: after parsing the text files, write data/<name>.gcnbin for the next run.
 // Overrides: GCN_SYNC_EPOCHS=1 (reference loop, `time=` = that epoch's own latency), GCN_EVAL_LANE=0|1,
 // GCN_REFERENCE_ORDER=0|1.
 #include <chrono>
@@ -62,6 +63,12 @@ int main(int argc, char **argv) {
         exit(EXIT_FAILURE);
     }
     const double load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
+    // GCN_WRITE_CACHE=1: a dataset that was parsed from the three text files leaves data/<name>.gcnbin behind, so the next
+    // run loads it in a fraction of the time (Reddit's text form is gigabytes of `k:v` tokens)
+    if (env_int("GCN_WRITE_CACHE", 0) && !parser.from_cache()) {
+        if (Parser::save_binary(parser.cache_path(), params, data)) std::cerr << "gcn-hip: wrote " << parser.cache_path() << std::endl;
+        else std::cerr << "gcn-hip: could not write " << parser.cache_path() << std::endl;
+    }
 #define ARG(i) (argc > (i) && strcmp(argv[i], "-") != 0)
     if (ARG(4)) params.hidden_dim = atoi(argv[4]);
     if (ARG(6)) params.dropout = (float)atof(argv[6]);

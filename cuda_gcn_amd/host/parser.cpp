@@ -122,8 +122,10 @@ bool Parser::parseSplit(const std::string &path) {          // parser.cpp:94-103
 
 bool Parser::parse() {
     // a binary cache, when present, wins
+    from_cache_ = false;
     if (load_binary(root + name + ".gcnbin", gcnParams, gcnData)) {
         std::cout << "Loaded binary cache." << std::endl;
+        from_cache_ = true;
         return true;
     }
     *gcnData = GCNData();      // a rejected cache leaves nothing behind: the text parsers append

@@ -16,8 +16,11 @@ public:
     Parser(GCNParams *gcnParams, GCNData *gcnData, std::string graph_name, std::string root = "");
     bool parse();
     static bool save_binary(const std::string &path, const GCNParams &p, const GCNData &d);
+    bool from_cache() const { return from_cache_; }          // the last parse() was served by <name>.gcnbin
+    std::string cache_path() const { return root + name + ".gcnbin"; }
     static bool load_binary(const std::string &path, GCNParams *p, GCNData *d);
 private:
+    bool from_cache_ = false;
     std::string root, name;
     GCNParams *gcnParams;
     GCNData *gcnData;

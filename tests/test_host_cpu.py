@@ -351,3 +351,28 @@ def test_node_order_by_structure_when_ids_carry_no_locality():
     c = model.choose_node_order(sgp.astype(np.int32), sgi, 8)
     assert c["ids_share"] <= 0.75                                                 # the halo plan is still what make_exchange_plan picks
     assert np.array_equal(np.sort(c["order"]), np.arange(n))
+
+
+def test_gcn_hip_writes_the_cache_and_refuses_to_run_without_a_gpu(tmp_path):
+    """`GCN_WRITE_CACHE=1 gcn-hip <name>`: the text files are parsed, data/<name>.gcnbin is written (identical arrays when
+    loaded back), and on a box without a GPU the program then exits with an error — it has no CPU path"""
+    import subprocess
+    from cuda_gcn_amd import model, _lib
+    import ctypes
+    n = ctypes.c_int(-1)
+    if _lib.gcnhip().gcnhip_device_count(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    binary = os.path.join(ROOT, "cuda_gcn_amd", "bin", "gcn-hip")
+    if not os.path.exists(binary):
+        pytest.skip("gcn-hip not built")
+    ds = datagen.make_dataset("tiny-syn")
+    root = str(tmp_path / "data")
+    datagen.write_text(ds, root, "tiny-syn")
+    r = subprocess.run([binary, "tiny-syn"], cwd=str(tmp_path), env=dict(os.environ, GCN_WRITE_CACHE="1"), capture_output=True, text=True)
+    assert r.returncode != 0 and "no GPU available" in r.stderr and "Parse Split Succeeded." in r.stdout
+    assert os.path.exists(os.path.join(root, "tiny-syn.gcnbin")) and "wrote" in r.stderr
+    for ext in (".graph", ".svmlight", ".split"):
+        os.remove(os.path.join(root, "tiny-syn" + ext))
+    back = model.load_dataset(root, "tiny-syn")
+    for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
+        assert np.array_equal(back[k], ds[k]), k
