@@ -1,6 +1,8 @@
 #include "gcn.h"
 #include "cluster.h"
 #include <chrono>
+#include <deque>
+#include <thread>
 #include <future>
 #include <cstdio>
 #include <cstdlib>
@@ -1084,16 +1086,17 @@ void HipGCN::run_epochs(int n, float *trace) {
     }
 }
 
-void HipGCN::readback_create() {
+void HipGCN::readback_create(bool own_stream) {
+    if (readback && (readback->ctx != nullptr) != own_stream) readback_destroy();
     if (readback) return;
     readback.reset(new Readback());
     Readback &R = *readback;
-    GCNHIP_CHECK(gcnhip_ctx_create(&R.ctx, device_, nullptr));
+    if (own_stream) GCNHIP_CHECK(gcnhip_ctx_create(&R.ctx, device_, nullptr));
     void *q = nullptr;
-    GCNHIP_CHECK(gcnhip_host_alloc(&q, (size_t)PIPELINE_DEPTH * 16 * sizeof(float)));
+    GCNHIP_CHECK(gcnhip_host_alloc(&q, (size_t)PIPELINE_DEPTH * READBACK_GROUP_MAX * 32 * sizeof(float)));
     R.host = (float *)q;
     for (int k = 0; k < PIPELINE_DEPTH; k++) {
-        GCNHIP_CHECK(gcnhip_event_create_sync(&R.ev_ready[k]));
+        if (own_stream) GCNHIP_CHECK(gcnhip_event_create_sync(&R.ev_ready[k]));
         GCNHIP_CHECK(gcnhip_event_create_sync(&R.ev_copied[k]));
     }
 }
@@ -1111,15 +1114,26 @@ void HipGCN::readback_destroy() {
     readback.reset();
 }
 
-// everything of epoch `e` (0-based) has been enqueued, its validation pass last on `producer`: when that has run, the
-// read-back stream copies slots 0 and 1 of the epoch's ring row (16 floats) to pinned memory
-void HipGCN::readback_enqueue(long e, gcnhip_ctx *producer) {
+// everything of epochs e .. e+n-1 (0-based) has been enqueued, the last validation pass on `producer`: behind it, their
+// ring rows (32 floats each; slots 0 = train and 1 = validation are read) are copied to slot k of the pinned buffer.  The
+// ring wraps at RING rows: at most two copies.  The copy goes on `producer` itself.  With a stream of its own for the
+// read-back (round 4's first version) the copy leaves the producer's timeline, but a barrier packet then sits on a second
+// hardware queue for as long as the group runs, and the producer's own launches slow down beside it: gcn-hip per epoch,
+// own stream -> producer's stream: Cora 102 -> 81 us (captured epoch replayed), Pubmed 124 -> 114 us and Reddit
+// 3329 -> 3291 us (validation lane); profiles/r04_cli_run_loop.json, DESIGN.md §4.10.
+void HipGCN::readback_enqueue(long e, int n, int k, gcnhip_ctx *producer) {
     Readback &R = *readback;
-    const int k = (int)(e % PIPELINE_DEPTH);
-    GCNHIP_CHECK(gcnhip_event_record(producer, R.ev_ready[k]));
-    GCNHIP_CHECK(gcnhip_stream_wait_event(R.ctx, R.ev_ready[k]));
-    GCNHIP_CHECK(gcnhip_d2h_async(R.ctx, R.host + (size_t)k * 16, d_ring + (size_t)((uint32_t)e % RING) * 32, 16 * sizeof(float)));
-    GCNHIP_CHECK(gcnhip_event_record(R.ctx, R.ev_copied[k]));
+    gcnhip_ctx *on = producer;
+    if (R.ctx) {
+        GCNHIP_CHECK(gcnhip_event_record(producer, R.ev_ready[k]));
+        GCNHIP_CHECK(gcnhip_stream_wait_event(R.ctx, R.ev_ready[k]));
+        on = R.ctx;
+    }
+    float *dst = R.host + (size_t)k * READBACK_GROUP_MAX * 32;
+    const int r0 = (int)((uint32_t)e % RING), n1 = std::min(n, RING - r0);
+    GCNHIP_CHECK(gcnhip_d2h_async(on, dst, d_ring + (size_t)r0 * 32, (size_t)n1 * 32 * sizeof(float)));
+    if (n > n1) GCNHIP_CHECK(gcnhip_d2h_async(on, dst + (size_t)n1 * 32, d_ring, (size_t)(n - n1) * 32 * sizeof(float)));
+    GCNHIP_CHECK(gcnhip_event_record(on, R.ev_copied[k]));
 }
 
 void HipGCN::run() {                            // gcn.cpp:130-158
@@ -1129,45 +1143,95 @@ void HipGCN::run() {                            // gcn.cpp:130-158
     report_test();
 }
 
-// No printed number feeds back into the run (no early stopping): epochs are enqueued up to PIPELINE_DEPTH ahead of the
-// line being printed.  With the validation lane, eval(e) is zipped with train(e+1) exactly as in run_epochs.
+// No printed number feeds back into the run (no early stopping): epochs are enqueued ahead of the line being printed, and
+// their metrics come back in GROUPS of consecutive epochs — one event wait and one small copy per group, up to
+// PIPELINE_DEPTH groups in flight.  The first READBACK_CALIBRATION epochs go one per group; their steady completion rate
+// then sets the group size so that a group spans about READBACK_GROUP_SECONDS (1 on Reddit-size graphs, where an epoch is
+// milliseconds; 16 on Cora / Pubmed, whose ~100 us epochs would otherwise spend as long on the host's per-epoch event and
+// copy calls as on the device).  Lines of a group are printed together, each with time= the group's interval / its size.
+// With the validation lane, eval(e) is zipped with train(e+1) exactly as in run_epochs.
 void HipGCN::run_pipelined() {
-    readback_create();
+    const bool zipped = lane && !(timers->enabled && env.comm->size() == 1);
+    {   // the read-back copies ride on the producer's stream; HIPGCN_READBACK_STREAM=1 gives them their own (measured
+        // slower at every size, see readback_enqueue; kept so that the measurement can be repeated)
+        const char *s = getenv("HIPGCN_READBACK_STREAM");
+        readback_create(s && atoi(s) != 0);
+    }
     Readback &R = *readback;
     const bool talk = env.comm->rank() == 0;
     const long E = params.epochs, first = epochs_done;
-    long enq = 0, printed = 0;                   // epochs (of this run) whose training pass is enqueued / whose line is out
-    const bool zipped = lane && !(timers->enabled && env.comm->size() == 1);
-    double total_train = 0;
+    long enq = 0, evald = 0, grouped = 0, printed = 0;   // epochs (of this run) with: training pass enqueued / validation pass
+                                                         // enqueued / a read-back enqueued / their line out
+    struct Group { long e0; int n, slot; };
+    std::deque<Group> inflight;
+    long n_groups = 0;
+    int group = 1;
+    if (const char *s = getenv("HIPGCN_READBACK_GROUP")) group = -std::max(1, std::min(atoi(s), (int)READBACK_GROUP_MAX));   // < 0: pinned
+    double total_train = 0, calib = 0;
     auto t_prev = std::chrono::high_resolution_clock::now();
+    const bool verbose = getenv("HIPGCN_VERBOSE") != nullptr;
+    double host_enqueue_s = 0, host_wait_s = 0;
+    const int poll_us = getenv("HIPGCN_POLL_US") ? atoi(getenv("HIPGCN_POLL_US")) : 0;
     while (printed < E) {
-        while (enq < E && enq - printed < PIPELINE_DEPTH) {
-            if (zipped) {
-                if (enq == 0) train_epoch_async();
-                else { eval_then_train_zipped(2); readback_enqueue(first + enq - 1, lane->env.ctx); }
-                if (enq == E - 1) { eval_on_lane(2); readback_enqueue(first + enq, lane->env.ctx); }
-            } else {
-                if (!enqueue_epoch_replay()) { train_epoch_async(); eval_async(2); }
-                readback_enqueue(first + enq, env.ctx);
+        const auto t_enq0 = std::chrono::high_resolution_clock::now();
+        while ((int)inflight.size() < PIPELINE_DEPTH && grouped < E) {
+            const int n = (int)std::min<long>(std::abs(group), E - grouped);
+            while (evald < grouped + n) {
+                if (zipped) {
+                    if (enq == 0) { train_epoch_async(); enq = 1; }
+                    if (enq < E) { eval_then_train_zipped(2); enq++; }       // eval(evald) beside train(evald + 1)
+                    else eval_on_lane(2);
+                } else {
+                    if (!enqueue_epoch_replay()) { train_epoch_async(); eval_async(2); }
+                    enq++;
+                }
+                evald++;
             }
-            enq++;
+            const int slot = (int)(n_groups++ % PIPELINE_DEPTH);
+            readback_enqueue(first + grouped, n, slot, zipped ? lane->env.ctx : env.ctx);
+            inflight.push_back({grouped, n, slot});
+            grouped += n;
         }
-        const int k = (int)((first + printed) % PIPELINE_DEPTH);
-        GCNHIP_CHECK(gcnhip_event_sync(R.ev_copied[k]));
+        const Group g = inflight.front();
+        inflight.pop_front();
+        const auto t_wait0 = std::chrono::high_resolution_clock::now();
+        if (poll_us > 0) {
+            for (int done = 0;;) {
+                GCNHIP_CHECK(gcnhip_event_query(R.ev_copied[g.slot], &done));
+                if (done) break;
+                std::this_thread::sleep_for(std::chrono::microseconds(poll_us));
+            }
+        } else GCNHIP_CHECK(gcnhip_event_sync(R.ev_copied[g.slot]));
         const auto t_now = std::chrono::high_resolution_clock::now();
-        const float dt = std::chrono::duration_cast<std::chrono::duration<float>>(t_now - t_prev).count();
+        host_enqueue_s += std::chrono::duration<double>(t_wait0 - t_enq0).count();
+        host_wait_s += std::chrono::duration<double>(t_now - t_wait0).count();
+        const double dt_group = std::chrono::duration_cast<std::chrono::duration<double>>(t_now - t_prev).count();
         t_prev = t_now;
-        total_train += dt;
-        const float *tr = R.host + (size_t)k * 16, *va = tr + 8;
-        const float train_loss = tr[0] / (int)tr[1] + params.weight_decay * tr[4] / 2, train_acc = (float)tr[2] / (int)tr[3];
-        const float val_loss = va[0] / (int)va[1] + params.weight_decay * va[4] / 2, val_acc = (float)va[2] / (int)va[3];
-        if (talk)
-            printf("epoch=%ld train_loss=%.5f train_acc=%.5f val_loss=%.5f val_acc=%.5f time=%.5f\n",
-                   printed + 1, train_loss, train_acc, val_loss, val_acc, dt);
-        printed++;
+        total_train += dt_group;
+        const float dt = (float)(dt_group / g.n);
+        for (int i = 0; i < g.n; i++) {
+            const float *tr = R.host + ((size_t)g.slot * READBACK_GROUP_MAX + i) * 32, *va = tr + 8;
+            const float train_loss = tr[0] / (int)tr[1] + params.weight_decay * tr[4] / 2, train_acc = (float)tr[2] / (int)tr[3];
+            const float val_loss = va[0] / (int)va[1] + params.weight_decay * va[4] / 2, val_acc = (float)va[2] / (int)va[3];
+            if (talk)
+                printf("epoch=%ld train_loss=%.5f train_acc=%.5f val_loss=%.5f val_acc=%.5f time=%.5f\n",
+                       g.e0 + i + 1, train_loss, train_acc, val_loss, val_acc, dt);
+        }
+        printed += g.n;
+        if (group == 1 && printed > READBACK_CALIBRATION / 2 && printed <= READBACK_CALIBRATION) calib += dt_group;
+        if (group == 1 && printed == READBACK_CALIBRATION) {
+            const double per_epoch = calib / (READBACK_CALIBRATION / 2);
+            int want = per_epoch > 0 ? (int)(READBACK_GROUP_SECONDS / per_epoch) : 1;
+            int pow2 = 1;
+            while (pow2 * 2 <= want && pow2 * 2 <= READBACK_GROUP_MAX) pow2 *= 2;
+            group = -pow2;
+            if (verbose && talk) fprintf(stderr, "[hipgcn] read-back groups of %d epochs (%.1f us per epoch while calibrating)\n", pow2, 1e6 * per_epoch);
+        }
     }
     sync();
     if (talk) printf("total training time=%.5f\n", (float)total_train);
+    if (verbose && talk)
+        fprintf(stderr, "[hipgcn] run loop: %.1f us per epoch enqueueing, %.1f us per epoch waiting for read-backs\n", 1e6 * host_enqueue_s / E, 1e6 * host_wait_s / E);
 }
 
 void HipGCN::run_synchronous() {

@@ -92,10 +92,11 @@ public:
     HipGCN(const HipGCN &) = delete;
 
     // gcn.cpp:130-158, same output lines.  With early stopping (or HIPGCN_SYNC_EPOCHS) the loop is the reference's: enqueue
-    // one epoch, wait, print, decide.  Otherwise nothing the host prints feeds back into the run, so up to PIPELINE_DEPTH
-    // epochs are in flight while epoch e's line is printed (its 16 metrics floats arrive through a read-back stream):
-    // `time=` is then the interval between consecutive epoch completions and `total training time` their sum = the wall
-    // time of the whole loop.
+    // one epoch, wait, print, decide.  Otherwise nothing the host prints feeds back into the run, so epochs are enqueued
+    // ahead of the line being printed and their metrics arrive through a read-back stream in groups of consecutive epochs
+    // (1 when an epoch takes milliseconds, up to READBACK_GROUP_MAX when it takes tens of microseconds; run_pipelined):
+    // `time=` is then the interval between consecutive group completions / the group's size and `total training time`
+    // their sum = the wall time of the whole loop.
     void run();
     std::pair<float, float> train_epoch();                    // synchronises to return (loss, acc)
     std::pair<float, float> eval(int current_split);
@@ -221,16 +222,19 @@ private:
     void *epoch_graph = nullptr;                               // captured train_epoch + eval(2)
     bool enqueue_epoch_replay();                               // one epoch from the captured hipGraph (captures it on first use); false: not replayable
     // run(): read-back of an epoch's metrics row without stalling the producer streams
-    static constexpr int PIPELINE_DEPTH = 4;
+    static constexpr int PIPELINE_DEPTH = 4;                   // read-back groups in flight
+    static constexpr int READBACK_GROUP_MAX = 64;              // epochs per read-back group, at most (RING is a multiple)
+    static constexpr int READBACK_CALIBRATION = 16;            // epochs read back one by one before the group size is set
+    static constexpr double READBACK_GROUP_SECONDS = 2e-3;     // a group spans about this long
     struct Readback {
-        gcnhip_ctx *ctx = nullptr;                             // its own stream
-        float *host = nullptr;                                 // pinned [PIPELINE_DEPTH][16]: slots 0 (train) and 1 (validation) of a ring row
+        gcnhip_ctx *ctx = nullptr;                             // its own stream (NULL: copies go on the producer's)
+        float *host = nullptr;                                 // pinned [PIPELINE_DEPTH][READBACK_GROUP_MAX][32]: whole ring rows
         void *ev_ready[PIPELINE_DEPTH] = {}, *ev_copied[PIPELINE_DEPTH] = {};
     };
     std::unique_ptr<Readback> readback;
-    void readback_create();
+    void readback_create(bool own_stream);
     void readback_destroy();
-    void readback_enqueue(long epoch_index, gcnhip_ctx *producer);
+    void readback_enqueue(long first_epoch_index, int n_epochs, int slot, gcnhip_ctx *producer);
     void run_synchronous();
     void run_pipelined();
     void report_test();

@@ -17,10 +17,13 @@
 //
 // Schedule defaults follow from ONE question: does a printed number feed back into the run?
 //  * early_stopping == 0 (the reference's default, gcn.cpp:9-11): no.  The run takes the library's fastest tested
-//    schedule — epochs enqueued ahead of the line being printed (HipGCN::run_pipelined), on one GPU the validation
-//    forward on a second stream, evaluation forwards as ReLU((A^.X).W1) with A^.X built once (validation loss within
-//    2e-5 of the reference's operation order, training bit-identical).  `time=` is the interval between consecutive
-//    epoch completions; `total training time=` their sum = the wall time of the loop.
+//    schedule — epochs enqueued ahead of the line being printed (HipGCN::run_pipelined), evaluation forwards as
+//    ReLU((A^.X).W1) with A^.X built once (validation loss within 2e-5 of the reference's operation order, training
+//    bit-identical), and on one GPU either the validation forward on a second stream (graphs above LANE_MIN_NODES
+//    nodes: Pubmed, Reddit) or one stream replaying the captured epoch (Cora, Citeseer: 18 launches of ~4 us, where two
+//    streams of eager launches are bound by the host; tools/cli_small.py).  Metrics come back in groups of consecutive
+//    epochs (1 on Reddit, 16 where an epoch takes ~100 us): the lines of a group are printed together, `time=` is the
+//    group's interval / its size; `total training time=` their sum = the wall time of the loop.
 //  * early_stopping > 0: yes — gcn.cpp:141-150 compares validation losses between epochs.  The loop is the
 //    reference's (one epoch, wait, print, decide) and evaluation keeps its operation order A^.(X.W1), so that a
 //    near-tie stops at the epoch gcn-seq stops at.
@@ -45,6 +48,8 @@ static int env_int(const char *name, int dflt) {
     const char *s = getenv(name);
     return s ? atoi(s) : dflt;
 }
+
+static constexpr size_t LANE_MIN_NODES = 8192;
 
 int main(int argc, char **argv) {
     setbuf(stdout, NULL);
@@ -96,7 +101,7 @@ int main(int argc, char **argv) {
     const bool feedback = params.early_stopping > 0;          // see the header: printed numbers decide the run
     // validation lane: on one GPU unless early stopping serialises the epochs anyway; with several GPUs it brings a second
     // communicator and stays opt-in until measured on such a node
-    if (env_int("GCN_EVAL_LANE", (world == 1 && !feedback) ? 1 : 0)) base.flags |= HIPGCN_EVAL_LANE;
+    if (env_int("GCN_EVAL_LANE", (world == 1 && !feedback && data.graph.indptr.size() > LANE_MIN_NODES) ? 1 : 0)) base.flags |= HIPGCN_EVAL_LANE;
     else base.flags |= HIPGCN_NO_EVAL_LANE;
     if (env_int("GCN_REFERENCE_ORDER", feedback ? 1 : 0)) base.flags |= HIPGCN_NO_AGG_FIRST_EVAL;
     if (env_int("GCN_SYNC_EPOCHS", 0)) base.flags |= HIPGCN_SYNC_EPOCHS;

@@ -146,7 +146,7 @@ def test_worker_thread_path_on_one_gpu(seq_binary):
 
 
 def test_pipelined_and_synchronous_loops_print_the_same_numbers():
-    """HipGCN::run_pipelined (epochs enqueued ahead, metrics through the read-back stream) against the reference's loop
+    """HipGCN::run_pipelined (epochs enqueued ahead, metrics copied back behind them) against the reference's loop
     (GCN_SYNC_EPOCHS=1): every printed number identical, with and without the validation lane, on the dense path too"""
     for name, hidden in (("cora-syn", "16"), ("reddit-mini", "128")):
         ds = datagen.make_dataset(name)
@@ -162,3 +162,27 @@ def test_pipelined_and_synchronous_loops_print_the_same_numbers():
         assert len(runs[0][0]) == 12
         for r in runs[1:]:
             assert r == runs[0], name
+
+
+def test_grouped_read_back_prints_every_epoch_once_in_order():
+    """run_pipelined brings the metrics back in groups of consecutive epochs once the first 16 have set the group size
+    (HIPGCN_READBACK_GROUP pins it; 7 does not divide the 1024-row metrics ring, so a group straddles the wrap): 1100 Cora
+    epochs print the same 1100 lines as the wait-per-epoch loop, whatever the grouping, the lane or the stream the copies
+    ride on, and the time= fields add up to `total training time=`"""
+    ds = datagen.make_dataset("cora-syn")
+    n = 1100
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "data"))
+        datagen.write_gcnbin(ds, os.path.join(td, "data", "cora-syn.gcnbin"))
+        args = ["cora-syn", "-", "-", "-", "-", "-", "-", "-", str(n)]
+        runs = []
+        for env in ({"GCN_SYNC_EPOCHS": "1", "GCN_EVAL_LANE": "0"}, {}, {"HIPGCN_READBACK_GROUP": "1"}, {"HIPGCN_READBACK_GROUP": "7"},
+                    {"HIPGCN_READBACK_GROUP": "64"}, {"HIPGCN_READBACK_GROUP": "7", "GCN_EVAL_LANE": "1"},
+                    {"HIPGCN_READBACK_GROUP": "7", "HIPGCN_READBACK_STREAM": "1"}, {"GCN_EVAL_LANE": "1", "HIPGCN_READBACK_STREAM": "1"}):
+            la, ea, _ = run_cli(HIP, td, args, GCN_SEED="5", **env)
+            tot, tst = total_and_test(la)
+            assert [e["epoch"] for e in ea] == list(range(1, n + 1)), env
+            assert abs(sum(e["time"] for e in ea) - tot) <= n * 1e-5 + 1e-3, env        # each line rounds to %.5f
+            runs.append(([{k: v for k, v in e.items() if k != "time"} for e in ea], {k: v for k, v in tst.items() if k != "time"}))
+    for r in runs[1:]:
+        assert r == runs[0]
