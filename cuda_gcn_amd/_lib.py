@@ -163,7 +163,6 @@ GCNHIP_SYMBOLS = {
     "gcnhip_stream_wait_event": (I, [P, P]),
     "gcnhip_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),
     "gcnhip_event_sync": (I, [P]),
-    "gcnhip_event_query": (I, [P, P]),
 }
 
 

@@ -212,14 +212,6 @@ int gcnhip_stream_wait_event(gcnhip_ctx *c, void *ev) {
     return 0;
 }
 int gcnhip_event_sync(void *ev) { GCNHIP_TRY(hipEventSynchronize((hipEvent_t)ev)); return 0; }
-int gcnhip_event_query(void *ev, int *done) {
-    if (!ev || !done) return -1;
-    const hipError_t e = hipEventQuery((hipEvent_t)ev);
-    *done = e == hipSuccess;
-    if (e == hipErrorNotReady) return 0;
-    GCNHIP_TRY(e);
-    return 0;
-}
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms) {
     GCNHIP_TRY(hipEventSynchronize((hipEvent_t)stop));
     GCNHIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

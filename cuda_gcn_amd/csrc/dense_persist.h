@@ -54,9 +54,8 @@ __device__ __forceinline__ void pg_glds4(const void *gsrc, uint32_t lds_dst) {
 // `scale` (the input dropout's 1/(1-p), 1 without dropout) is folded in here: X~ . W = (X . m) . (scale W), so the kernel's
 // per-element work on A is one AND with the keep mask (for p = 0.5 the product is the same bits; otherwise scale*w is
 // rounded once more than x*scale would be — inside the bound the oracle comparison uses).
-__global__ __launch_bounds__(256) void pg_pack_w_kernel(const float *__restrict__ w, int ldw, int K, int n_kg, float *__restrict__ wp, float scale) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (kg, hh, col)
-    if (idx >= n_kg * 256) return;
+__device__ inline void pg_pack_w_body(int idx, const float *__restrict__ w, int ldw, int K, int n_kg, float *__restrict__ wp, float scale) {
+    if (idx >= n_kg * 256) return;                               // idx = (kg, hh, col)
     const int col = idx & 127, hh = (idx >> 7) & 1, kg = idx >> 8;
     float v[4];
 #pragma unroll
@@ -65,6 +64,19 @@ __global__ __launch_bounds__(256) void pg_pack_w_kernel(const float *__restrict_
         v[t] = k < K ? w[(size_t)k * ldw + col] * scale : 0.f;
     }
     *reinterpret_cast<float4 *>(wp + (size_t)kg * 1024 + col * 8 + 4 * (hh ^ ((col >> 3) & 1))) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__global__ __launch_bounds__(256) void pg_pack_w_kernel(const float *__restrict__ w, int ldw, int K, int n_kg, float *__restrict__ wp, float scale) {
+    pg_pack_w_body(blockIdx.x * blockDim.x + threadIdx.x, w, ldw, K, n_kg, wp, scale);
+}
+// The two small launches in front of a training forward in one: workgroups [0, n_bits_wgs) draw the keep bits
+// (dropbits_block_kernel), the n_kg workgroups behind them pack W (pg_pack_w_kernel).  Independent work, one launch less
+// on the critical path of every epoch (≈ 4 us).
+__global__ __launch_bounds__(256) void dropbits_pack_w_kernel(uint32_t *__restrict__ bits, int64_t n_elems, int thr, uint64_t seed,
+                                                              const uint32_t *d_epoch, uint64_t block0, int n_bits_wgs,
+                                                              const float *__restrict__ w, int ldw, int K, int n_kg,
+                                                              float *__restrict__ wp, float scale) {
+    if ((int)blockIdx.x < n_bits_wgs) dropbits_block_body((int64_t)blockIdx.x * 256 + threadIdx.x, bits, n_elems, thr, seed, d_epoch, block0);
+    else pg_pack_w_body(((int)blockIdx.x - n_bits_wgs) * 256 + threadIdx.x, w, ldw, K, n_kg, wp, scale);
 }
 
 struct PersistFwdArgs {

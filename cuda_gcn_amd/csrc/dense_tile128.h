@@ -37,6 +37,33 @@ __global__ __launch_bounds__(256) void dropbits_kernel(uint32_t *__restrict__ bi
     bits[w] = word;
 }
 
+// The same words when the stream offset is a multiple of 128 (one GPU: 0): a thread owns a whole Philox block = four words,
+// so every Philox call is used in full (dropbits_kernel draws one block per WORD and keeps a quarter of it: 13.8 us per
+// epoch at Reddit size, this form 5) and the words leave as one 16-byte store.  `bits` is 16-byte aligned (hipMalloc) and
+// has slack past the last word (ctx.hip).
+__device__ inline void dropbits_block_body(int64_t q, uint32_t *__restrict__ bits, int64_t n_elems, int thr,
+                                           uint64_t seed, const uint32_t *d_epoch, uint64_t block0) {
+    if (q * 128 >= n_elems) return;                                           // Philox block q = elements 128q .. 128q+127
+    const uint32_t epoch = d_epoch ? *d_epoch : 0u;
+    const uint64_t c = block0 + (uint64_t)q;
+    uint32_t ge[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (thr != 0) {
+        const int n_planes = 16 - (__ffs(thr) - 1);
+        for (int i = n_planes; i >= 1; i--) {                                 // keep_word's recurrence, on the four groups at once
+            uint32_t r[4];
+            philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), epoch, (uint32_t)i, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            const bool and_plane = (thr >> (16 - i)) & 1;
+#pragma unroll
+            for (int g = 0; g < 4; g++) ge[g] = and_plane ? (r[g] & ge[g]) : (r[g] | ge[g]);
+        }
+    }
+    *reinterpret_cast<uint4 *>(bits + q * 4) = make_uint4(ge[0], ge[1], ge[2], ge[3]);
+}
+__global__ __launch_bounds__(256) void dropbits_block_kernel(uint32_t *__restrict__ bits, int64_t n_elems, int thr,
+                                                             uint64_t seed, const uint32_t *d_epoch, uint64_t block0) {
+    dropbits_block_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, bits, n_elems, thr, seed, d_epoch, block0);
+}
+
 struct Tile128Args {
     const float *x; int ldx;          // X: m x K, row stride ldx
     const float *w; int ldw;          // fwd: W [K x p];  bwd: dH0 [m x p]

@@ -156,10 +156,16 @@ static DropSpec make_drop(float p_drop, uint64_t seed, const uint32_t *d_epoch, 
 }
 
 // keep bits for the nnz stored elements of f (Philox or injected decisions)
+// whole Philox blocks per thread (dense_tile128.h): device decisions from a stream offset that is a multiple of 128
+static inline bool keep_bits_by_block(const DropSpec &d) { return !d.keep_mask && (d.off & 127) == 0; }
+
 static int make_keep_bits(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d) {
     if (!f->keep_bits) return gcnhip_fail("input dropout on a feature object without a keep-bit array (gcnhip_feat_create_aggregated builds evaluation-only objects)");
     const int64_t words = (f->nnz + 31) / 32;
-    dropbits_kernel<<<ceil_div(words, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off, d.keep_mask);
+    if (keep_bits_by_block(d))
+        dropbits_block_kernel<<<ceil_div((words + 3) / 4, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7);
+    else
+        dropbits_kernel<<<ceil_div(words, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off, d.keep_mask);
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -185,7 +191,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
     if (f->n_rows == 0) return 0;
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
     if (f->dense && p > 64) {                 // 128 x 128 MFMA tiles
-        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
+        if (d.on && !f->keep_bits) return gcnhip_fail("input dropout on a feature object without a keep-bit array (gcnhip_feat_create_aggregated builds evaluation-only objects)");
         Tile128Args t;
         t.x = vals; t.ldx = f->n_cols; t.w = w; t.ldw = ld_w; t.out = out; t.ldo = ld_out;
         int vx = x_vec_width(f, vals);
@@ -199,7 +205,14 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         const int n_chunks = (t.K + PG_BK - 1) / PG_BK;
         if (fast && p == 128 && !tiles_only && !c->corun && aligned16(t.x) && aligned16(out) &&
             (uint64_t)(t.m + PG_ROWS) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 4096 * sizeof(float) <= c->wpack_bytes) {
-            pg_pack_w_kernel<<<ceil_div(n_chunks * 4 * 256, 256), 256, 0, c->stream>>>(w, ld_w, t.K, n_chunks * 4, c->wpack, t.bits ? t.scale : 1.f);
+            if (d.on && keep_bits_by_block(d)) {         // keep bits and the packed W from one launch
+                const int n_bits_wgs = (int)ceil_div(((f->nnz + 31) / 32 + 3) / 4, (int64_t)256);
+                dropbits_pack_w_kernel<<<n_bits_wgs + n_chunks * 4, 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7, n_bits_wgs,
+                                                                                       w, ld_w, t.K, n_chunks * 4, c->wpack, t.scale);
+            } else {
+                if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
+                pg_pack_w_kernel<<<ceil_div(n_chunks * 4 * 256, 256), 256, 0, c->stream>>>(w, ld_w, t.K, n_chunks * 4, c->wpack, t.bits ? t.scale : 1.f);
+            }
             GCNHIP_LAUNCH_CHECK();
             PersistFwdArgs pa;
             pa.x = t.x; pa.ldx = t.ldx; pa.wp = c->wpack; pa.out = out; pa.ldo = ld_out;
@@ -216,6 +229,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
             GCNHIP_LAUNCH_CHECK();
             return 0;
         }
+        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
         // eight waves per tile: same bits, 4 % faster than the four-wave form (0.383 -> 0.367 ms at Reddit scale);
         // GCNHIP_GEMM_W4 selects the four-wave kernel for A/B runs
         const bool w4 = c->opt.gemm_w4 != 0;

@@ -2,7 +2,6 @@
 #include "cluster.h"
 #include <chrono>
 #include <deque>
-#include <thread>
 #include <future>
 #include <cstdio>
 #include <cstdlib>
@@ -1171,7 +1170,6 @@ void HipGCN::run_pipelined() {
     auto t_prev = std::chrono::high_resolution_clock::now();
     const bool verbose = getenv("HIPGCN_VERBOSE") != nullptr;
     double host_enqueue_s = 0, host_wait_s = 0;
-    const int poll_us = getenv("HIPGCN_POLL_US") ? atoi(getenv("HIPGCN_POLL_US")) : 0;
     while (printed < E) {
         const auto t_enq0 = std::chrono::high_resolution_clock::now();
         while ((int)inflight.size() < PIPELINE_DEPTH && grouped < E) {
@@ -1195,13 +1193,7 @@ void HipGCN::run_pipelined() {
         const Group g = inflight.front();
         inflight.pop_front();
         const auto t_wait0 = std::chrono::high_resolution_clock::now();
-        if (poll_us > 0) {
-            for (int done = 0;;) {
-                GCNHIP_CHECK(gcnhip_event_query(R.ev_copied[g.slot], &done));
-                if (done) break;
-                std::this_thread::sleep_for(std::chrono::microseconds(poll_us));
-            }
-        } else GCNHIP_CHECK(gcnhip_event_sync(R.ev_copied[g.slot]));
+        GCNHIP_CHECK(gcnhip_event_sync(R.ev_copied[g.slot]));
         const auto t_now = std::chrono::high_resolution_clock::now();
         host_enqueue_s += std::chrono::duration<double>(t_wait0 - t_enq0).count();
         host_wait_s += std::chrono::duration<double>(t_now - t_wait0).count();

@@ -92,7 +92,7 @@ int gcnhip_h2d(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);   /* 
 int gcnhip_d2h(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronises */
 int gcnhip_d2d_async(gcnhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* Read-back without stalling the producer: page-locked host memory and a device-to-host copy that is only ENQUEUED on
- * ctx's stream (wait for it with an event recorded behind it + gcnhip_event_sync / _query).  HipGCN::run() uses them to
+ * ctx's stream (wait for it with an event recorded behind it + gcnhip_event_sync).  HipGCN::run() uses them to
  * print epoch e's line while epochs e+1.. are already running: behind a group of epochs, the metrics rows of the group are
  * copied on the producing stream and an event recorded that the host waits on.  (The reference's CUDA path instead blocks
  * on a cudaMemcpy of the whole logits matrix per accuracy call, src/cuda/cuda_gcn.cu:100-120.) */
@@ -515,7 +515,6 @@ int gcnhip_event_destroy(void *ev);
 int gcnhip_event_record(gcnhip_ctx *ctx, void *ev);
 int gcnhip_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
 int gcnhip_event_sync(void *ev);                                   /* the host waits for the work recorded before ev */
-int gcnhip_event_query(void *ev, int *done);                       /* *done = 1 when that work has finished, else 0; never waits */
 /* make the context's stream wait (on the device) for work recorded before `ev` on another context's stream */
 int gcnhip_stream_wait_event(gcnhip_ctx *ctx, void *ev);
 
