@@ -2,6 +2,7 @@
 // Host-side preparation happens ONCE per dataset (the reference re-derives
 // degrees per edge per call and re-uploads X every epoch).
 #include "common.h"
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -95,6 +96,19 @@ int gcnhip_ctx_create(gcnhip_ctx **out, int device, void *stream) {
         c->own_stream = true;
     }
     auto fill = [&]() -> int {
+        {   // code objects are loaded per device; gcn-hip's worker threads create their contexts at the same time
+            static std::mutex mu;
+            static bool preloaded[64] = {};
+            std::lock_guard<std::mutex> lock(mu);
+            if (device >= 0 && device < 64 && !preloaded[device]) {
+                GCNHIP_TRY((hipError_t)gcnhip_preload_elementwise());
+                GCNHIP_TRY((hipError_t)gcnhip_preload_graphsum());
+                GCNHIP_TRY((hipError_t)gcnhip_preload_matmul());
+                GCNHIP_TRY((hipError_t)gcnhip_preload_spmm());
+                GCNHIP_TRY((hipError_t)gcnhip_preload_xent());
+                preloaded[device] = true;
+            }
+        }
         hipDeviceProp_t prop;
         GCNHIP_TRY(hipGetDeviceProperties(&prop, device));
         c->n_cu = prop.multiProcessorCount;

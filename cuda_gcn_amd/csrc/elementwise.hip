@@ -359,3 +359,5 @@ int gcnhip_metrics_record(gcnhip_ctx *c, float *d_ring, int capacity, int slot_i
 }
 
 }  // extern "C"
+
+GCNHIP_DEFINE_PRELOAD(elementwise, adam_kernel)

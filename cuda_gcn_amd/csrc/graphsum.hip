@@ -1051,3 +1051,5 @@ int gcnhip_graphsum_bf16(gcnhip_ctx *c, const gcnhip_graph *g, const uint16_t *i
 }
 
 }  // extern "C"
+
+GCNHIP_DEFINE_PRELOAD(graphsum, graphsum_finalize_kernel)

@@ -121,3 +121,5 @@ int gcnhip_matmul_bwd_da_bits(gcnhip_ctx *c, const float *b, int ldb, const floa
 }
 
 }  // extern "C"
+
+GCNHIP_DEFINE_PRELOAD(matmul, (gemm_atb_kernel<4, 4>))

@@ -537,3 +537,5 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
 }
 
 }  // extern "C"
+
+GCNHIP_DEFINE_PRELOAD(spmm, pg_pack_w_kernel)

@@ -408,3 +408,5 @@ int gcnhip_accuracy(gcnhip_ctx *c, const float *logits, int ld, const int32_t *t
 }
 
 }  // extern "C"
+
+GCNHIP_DEFINE_PRELOAD(xent, count_labelled_kernel)
