@@ -149,6 +149,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_set_truth": (I, [P, P, P, P, I, I]),
     "gcnhip_sumsq": (I, [P, P, I64, P]),
     "gcnhip_adam_step": (I, [P, C.POINTER(AdamVar), I, F, P, P, F, F, F, F, P]),
+    "gcnhip_adam_step_advance": (I, [P, C.POINTER(AdamVar), I, F, P, P, F, F, F, F, P, P, P]),
     "gcnhip_counter_add": (I, [P, P, C.c_uint32]),
     "gcnhip_metrics_record": (I, [P, P, I, I, P, P, P, P]),
     "gcnhip_metrics_record_with_next_loss": (I, [P, P, I, I, P, P]),

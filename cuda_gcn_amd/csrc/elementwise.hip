@@ -131,6 +131,7 @@ struct AdamArgs {
     float *partial;             // per-block sum of w0^2 after the update (or NULL)
     uint32_t *ticket;           // with `partial`: the block that arrives last adds the partials (NULL: sum_partials_kernel follows)
     float *sumsq_out;
+    uint32_t *epoch_counter, *epoch_done;   // with `ticket`: the last block leaves *epoch_done = e, *epoch_counter = e + 1 (NULL: no advance)
 };
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ float sh[4];
@@ -179,8 +180,20 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         float acc = 0.f;
         for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float tot = block_sum(acc, sh);
-        if (threadIdx.x == 0) *a.sumsq_out = tot;
+        if (threadIdx.x == 0) {
+            *a.sumsq_out = tot;
+            if (a.epoch_counter) {                  // every block read the word (the step size index) before it took its ticket
+                const uint32_t e = *a.epoch_counter;
+                if (a.epoch_done) *a.epoch_done = e;
+                *a.epoch_counter = e + 1u;
+            }
+        }
     }
+}
+__global__ void epoch_advance_kernel(uint32_t *counter, uint32_t *done) {
+    const uint32_t e = *counter;
+    if (done) *done = e;
+    *counter = e + 1u;
 }
 
 // bits[r*wpr + (c >> 5)] bit (c & 31) = h[r, c] > 0 — one wave per row, one ballot per 64 columns
@@ -310,9 +323,10 @@ int gcnhip_sumsq(gcnhip_ctx *c, const float *x, int64_t n, float *d_out) {
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }
-int gcnhip_adam_step(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, float step_size,
-                     const float *d_step_sizes, const uint32_t *d_epoch,
-                     float beta1, float beta2, float eps, float weight_decay, float *d_sumsq) {
+static int adam_step_impl(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, float step_size,
+                          const float *d_step_sizes, const uint32_t *d_epoch,
+                          float beta1, float beta2, float eps, float weight_decay, float *d_sumsq,
+                          uint32_t *d_epoch_counter, uint32_t *d_epoch_done) {
     if (!c || !vars || n_vars < 1 || n_vars > 4) return -1;
     if (d_step_sizes && !d_epoch) return -1;
     AdamArgs a;
@@ -328,13 +342,31 @@ int gcnhip_adam_step(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, flo
     const bool two_launches = c->opt.adam_sum_launch != 0;                      // A/B aid, tests (context option)
     a.ticket = (d_sumsq && !two_launches) ? c->ticket + 1 : nullptr;
     a.sumsq_out = d_sumsq;
+    a.epoch_counter = a.ticket ? d_epoch_counter : nullptr;     // rides on the in-launch final reduction
+    a.epoch_done = a.ticket ? d_epoch_done : nullptr;
     adam_kernel<<<blocks, 256, 0, c->stream>>>(a);
     GCNHIP_LAUNCH_CHECK();
     if (d_sumsq && !a.ticket) {
         sum_partials_kernel<<<1, 256, 0, c->stream>>>(a.partial, blocks, d_sumsq);
         GCNHIP_LAUNCH_CHECK();
     }
+    if (d_epoch_counter && !a.epoch_counter) {                  // no final reduction in the launch to carry it: its own launch
+        epoch_advance_kernel<<<1, 1, 0, c->stream>>>(d_epoch_counter, d_epoch_done);
+        GCNHIP_LAUNCH_CHECK();
+    }
     return 0;
+}
+int gcnhip_adam_step(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, float step_size,
+                     const float *d_step_sizes, const uint32_t *d_epoch,
+                     float beta1, float beta2, float eps, float weight_decay, float *d_sumsq) {
+    return adam_step_impl(c, vars, n_vars, step_size, d_step_sizes, d_epoch, beta1, beta2, eps, weight_decay, d_sumsq, nullptr, nullptr);
+}
+int gcnhip_adam_step_advance(gcnhip_ctx *c, const gcnhip_adam_var *vars, int n_vars, float step_size,
+                             const float *d_step_sizes, const uint32_t *d_epoch,
+                             float beta1, float beta2, float eps, float weight_decay, float *d_sumsq,
+                             uint32_t *d_epoch_counter, uint32_t *d_epoch_done) {
+    if (!d_epoch_counter) return -1;
+    return adam_step_impl(c, vars, n_vars, step_size, d_step_sizes, d_epoch, beta1, beta2, eps, weight_decay, d_sumsq, d_epoch_counter, d_epoch_done);
 }
 int gcnhip_counter_add(gcnhip_ctx *c, uint32_t *d_counter, uint32_t inc) {
     if (!c || !d_counter) return -1;

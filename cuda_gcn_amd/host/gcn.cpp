@@ -279,9 +279,15 @@ void HipGCN::init(const HipGCNOptions &opt) {
         GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, (size_t)RING * 4 * 8 * sizeof(float)));
         d_ring = (float *)q;
         GCNHIP_CHECK(gcnhip_memset_async(env.ctx, q, 0, (size_t)RING * 4 * 8 * sizeof(float)));
-        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, sizeof(uint32_t)));
+        // two epoch words: [0] the epoch being (or about to be) trained, read by the training pass; [1] the epoch whose update
+        // ran last, naming the metrics row of an evaluation on this stream.  Adam's launch moves both (gcnhip_adam_step_advance),
+        // so an epoch starts without a counter launch.  Before the first update: 0 and -1 (the row an evaluation of the
+        // initial weights has always used).
+        GCNHIP_CHECK(gcnhip_malloc(env.ctx, &q, 2 * sizeof(uint32_t)));
         env.d_epoch = (uint32_t *)q;
-        GCNHIP_CHECK(gcnhip_memset_async(env.ctx, q, 0xFF, sizeof(uint32_t)));   // -1: the first train epoch makes it 0
+        env.d_epoch_done = env.d_epoch + 1;
+        GCNHIP_CHECK(gcnhip_memset_async(env.ctx, env.d_epoch, 0, sizeof(uint32_t)));
+        GCNHIP_CHECK(gcnhip_memset_async(env.ctx, env.d_epoch_done, 0xFF, sizeof(uint32_t)));
     }
     // Glorot with the reference's RNG and draw order: all of W1, then all of W2 (gcn.cpp:30,49)
     rng.seed_time((unsigned)opt.seed);
@@ -878,7 +884,7 @@ static bool loss_records() {
 }
 
 void HipGCN::train_begin() {
-    GCNHIP_CHECK(gcnhip_counter_add(env.ctx, env.d_epoch, 1u));
+    // (*env.d_epoch is this epoch's number already: the previous epoch's Adam launch advanced it)
     if (env.comm->size() == 1 && loss_records())   // loss/accuracy of this forward + the L2 term of the weights it uses
         GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(env.ctx, d_ring, RING, 0, env.d_epoch, optimizer->d_sumsq));
     epochs_done++;
@@ -986,14 +992,15 @@ void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
         GCNHIP_CHECK(gcnhip_d2d_async(env.ctx, input->data, gcnhip_feat_values(feat), (size_t)gcnhip_feat_nnz(feat) * sizeof(float)));
     set_truth(s);
     const bool in_loss = env.comm->size() == 1 && loss_records();
-    if (in_loss) GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch, optimizer->d_sumsq));
+    // (an evaluation on this stream scores the weights of the last update: the row of env.d_epoch_done, not of the epoch to come)
+    if (in_loss) GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch_done, optimizer->d_sumsq));
     for (auto m : eval_modules.empty() ? modules : eval_modules) m->forward(false);
     if (env.comm->size() > 1) {
         timers->start(TMR_COMM);
         env.comm->allreduce_sum(d_result, 4);
         timers->stop(TMR_COMM);
     }
-    if (!in_loss) GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch, d_result, nullptr, optimizer->d_sumsq));
+    if (!in_loss) GCNHIP_CHECK(gcnhip_metrics_record(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch_done, d_result, nullptr, optimizer->d_sumsq));
 }
 
 std::pair<float, float> HipGCN::read_metrics(long epoch_index, int slot) {
@@ -1164,8 +1171,12 @@ void HipGCN::run_pipelined() {
     struct Group { long e0; int n, slot; };
     std::deque<Group> inflight;
     long n_groups = 0;
-    int group = 1;
-    if (const char *s = getenv("HIPGCN_READBACK_GROUP")) group = -std::max(1, std::min(atoi(s), (int)READBACK_GROUP_MAX));   // < 0: pinned
+    int group = 1;                                       // epochs per read-back group
+    bool group_settled = false;                          // pinned by HIPGCN_READBACK_GROUP, or set after the calibration epochs
+    if (const char *s = getenv("HIPGCN_READBACK_GROUP")) {
+        group = std::max(1, std::min(atoi(s), (int)READBACK_GROUP_MAX));
+        group_settled = true;
+    }
     double total_train = 0, calib = 0;
     auto t_prev = std::chrono::high_resolution_clock::now();
     const bool verbose = getenv("HIPGCN_VERBOSE") != nullptr;
@@ -1173,7 +1184,7 @@ void HipGCN::run_pipelined() {
     while (printed < E) {
         const auto t_enq0 = std::chrono::high_resolution_clock::now();
         while ((int)inflight.size() < PIPELINE_DEPTH && grouped < E) {
-            const int n = (int)std::min<long>(std::abs(group), E - grouped);
+            const int n = (int)std::min<long>(group, E - grouped);
             while (evald < grouped + n) {
                 if (zipped) {
                     if (enq == 0) { train_epoch_async(); enq = 1; }
@@ -1210,14 +1221,14 @@ void HipGCN::run_pipelined() {
                        g.e0 + i + 1, train_loss, train_acc, val_loss, val_acc, dt);
         }
         printed += g.n;
-        if (group == 1 && printed > READBACK_CALIBRATION / 2 && printed <= READBACK_CALIBRATION) calib += dt_group;
-        if (group == 1 && printed == READBACK_CALIBRATION) {
+        if (!group_settled && printed > READBACK_CALIBRATION / 2 && printed <= READBACK_CALIBRATION) calib += dt_group;
+        if (!group_settled && printed == READBACK_CALIBRATION) {      // (groups of one until here: printed counts epochs one by one)
             const double per_epoch = calib / (READBACK_CALIBRATION / 2);
-            int want = per_epoch > 0 ? (int)(READBACK_GROUP_SECONDS / per_epoch) : 1;
-            int pow2 = 1;
-            while (pow2 * 2 <= want && pow2 * 2 <= READBACK_GROUP_MAX) pow2 *= 2;
-            group = -pow2;
-            if (verbose && talk) fprintf(stderr, "[hipgcn] read-back groups of %d epochs (%.1f us per epoch while calibrating)\n", pow2, 1e6 * per_epoch);
+            const int want = per_epoch > 0 ? (int)(READBACK_GROUP_SECONDS / per_epoch) : 1;
+            group = 1;
+            while (group * 2 <= want && group * 2 <= READBACK_GROUP_MAX) group *= 2;
+            group_settled = true;
+            if (verbose && talk) fprintf(stderr, "[hipgcn] read-back groups of %d epochs (%.1f us per epoch while calibrating)\n", group, 1e6 * per_epoch);
         }
     }
     sync();

@@ -218,7 +218,7 @@ private:
     uint8_t *d_keep0 = nullptr, *d_keep1 = nullptr;
     std::vector<uint8_t> h_keep0, h_keep1;
     long keep0_first = 0;                                      // global nnz index of h_keep0[0]
-    long epochs_done = 0;                                      // host mirror of *d_epoch + 1
+    long epochs_done = 0;                                      // training passes enqueued = *env.d_epoch once their Adam launches have run
     void *epoch_graph = nullptr;                               // captured train_epoch + eval(2)
     bool enqueue_epoch_replay();                               // one epoch from the captured hipGraph (captures it on first use); false: not replayable
     // run(): read-back of an epoch's metrics row without stalling the producer streams

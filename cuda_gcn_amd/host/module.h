@@ -27,6 +27,7 @@ struct HipEnv {
     DeviceTimers *timers = nullptr;
     uint64_t seed = 0;
     uint32_t *d_epoch = nullptr;
+    uint32_t *d_epoch_done = nullptr;      // main context only: the epoch whose update ran last (written with d_epoch + 1 by the Adam launch)
     // parity mode: decisions generated on the host with the reference's RNG
     const uint8_t *keep_input = nullptr;     // [nnz of the X the forward multiplies: local rows, or all rows when replicated]
     const uint8_t *keep_input_bwd = nullptr; // [local nnz of X] (same decisions, this rank's slice)

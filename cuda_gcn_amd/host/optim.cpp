@@ -49,8 +49,14 @@ void HipAdam::step() {
     // inside the table the step size is read on the device at index *d_epoch (== step_count - 1),
     // which keeps a captured epoch replayable; past it the host value is passed
     const bool use_table = step_count <= table_len;
-    GCNHIP_CHECK(gcnhip_adam_step(env->ctx, vars.data(), (int)vars.size(), step_size(params, step_count),
-                                  use_table ? d_step_sizes : nullptr, use_table ? env->d_epoch : nullptr,
-                                  params.beta1, params.beta2, params.eps, params.weight_decay, d_sumsq));
+    if (env->d_epoch_done)      // the launch also advances the epoch word: the next training pass needs no counter launch
+        GCNHIP_CHECK(gcnhip_adam_step_advance(env->ctx, vars.data(), (int)vars.size(), step_size(params, step_count),
+                                              use_table ? d_step_sizes : nullptr, use_table ? env->d_epoch : nullptr,
+                                              params.beta1, params.beta2, params.eps, params.weight_decay, d_sumsq,
+                                              env->d_epoch, env->d_epoch_done));
+    else
+        GCNHIP_CHECK(gcnhip_adam_step(env->ctx, vars.data(), (int)vars.size(), step_size(params, step_count),
+                                      use_table ? d_step_sizes : nullptr, use_table ? env->d_epoch : nullptr,
+                                      params.beta1, params.beta2, params.eps, params.weight_decay, d_sumsq));
     env->timers->stop(TMR_ADAM);
 }

@@ -497,8 +497,9 @@ class Device:
         _ck(self.lib, self.lib.gcnhip_sumsq(self.ctx, xb.ptr, xb.shape[0], ob.ptr), "gcnhip_sumsq")
         return float(ob.download()[0])
 
-    def adam_steps(self, ws, grads_per_step, decays, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8):
-        """ws: list of arrays; grads_per_step: list (steps) of lists (vars). Returns (ws, sumsq of ws[0])"""
+    def adam_steps(self, ws, grads_per_step, decays, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8, epoch_words=None):
+        """ws: list of arrays; grads_per_step: list (steps) of lists (vars). Returns (ws, sumsq of ws[0]).
+        epoch_words: a device buffer of two uint32 [counter, done] -> gcnhip_adam_step_advance moves them with every step"""
         bufs = []
         for w in ws:
             w = np.ascontiguousarray(w, np.float32).reshape(-1)
@@ -513,7 +514,11 @@ class Device:
                 bufs[k]["g"].upload(np.ascontiguousarray(g, np.float32).reshape(-1))
             # optim.cpp:26 in float arithmetic
             step = np.float32(lr) * np.sqrt(np.float32(1) - np.power(b2, np.float32(t), dtype=np.float32)) / (np.float32(1) - np.power(b1, np.float32(t), dtype=np.float32))
-            _ck(self.lib, self.lib.gcnhip_adam_step(self.ctx, arr, len(ws), float(step), None, None, beta1, beta2, eps, weight_decay, sq.ptr), "gcnhip_adam_step")
+            if epoch_words is not None:
+                _ck(self.lib, self.lib.gcnhip_adam_step_advance(self.ctx, arr, len(ws), float(step), None, None, beta1, beta2, eps, weight_decay, sq.ptr,
+                                                                epoch_words.ptr, epoch_words.ptr + 4), "gcnhip_adam_step_advance")
+            else:
+                _ck(self.lib, self.lib.gcnhip_adam_step(self.ctx, arr, len(ws), float(step), None, None, beta1, beta2, eps, weight_decay, sq.ptr), "gcnhip_adam_step")
         return [b["w"].download() for b in bufs], float(sq.download()[0])
 
 

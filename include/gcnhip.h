@@ -477,6 +477,15 @@ typedef struct {
 int gcnhip_adam_step(gcnhip_ctx *ctx, const gcnhip_adam_var *vars, int n_vars, float step_size,
                      const float *d_step_sizes, const uint32_t *d_epoch,
                      float beta1, float beta2, float eps, float weight_decay, float *d_sumsq);
+/* The same update, and the epoch word advanced behind it in the same launch (the block that finishes last, after every
+ * block has read the word): *d_epoch_done = e, *d_epoch_counter = e + 1 with e the counter's value during the launch.
+ * The training pass of epoch e + 1 then reads its epoch from d_epoch_counter without a launch of its own
+ * (gcnhip_counter_add), while an evaluation of epoch e's weights names its metrics row through d_epoch_done.
+ * d_epoch (the index into d_step_sizes) may be d_epoch_counter itself or NULL. */
+int gcnhip_adam_step_advance(gcnhip_ctx *ctx, const gcnhip_adam_var *vars, int n_vars, float step_size,
+                             const float *d_step_sizes, const uint32_t *d_epoch,
+                             float beta1, float beta2, float eps, float weight_decay, float *d_sumsq,
+                             uint32_t *d_epoch_counter, uint32_t *d_epoch_done);
 
 /* ---- small device utilities for graph-replayed epochs -------------------------- */
 int gcnhip_counter_add(gcnhip_ctx *ctx, uint32_t *d_counter, uint32_t inc);

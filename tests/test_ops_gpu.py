@@ -900,6 +900,26 @@ def test_adam_sum_of_squares_in_the_launch_equals_the_second_launch(dev):
         dev.set_option("adam_sum_launch", 0)
 
 
+def test_adam_step_advance_moves_the_epoch_words_and_nothing_else(dev):
+    """gcnhip_adam_step_advance: the same update as gcnhip_adam_step, and behind it counter = e + 1, done = e — from the launch's
+    last block when the final reduction is in the launch, from a launch of its own otherwise (adam_sum_launch)"""
+    rng = np.random.default_rng(9)
+    try:
+        for n in (300, 77056):
+            w = rng.standard_normal(n).astype(np.float32)
+            gs = rng.standard_normal((4, n)).astype(np.float32)
+            (ref,), sq_ref = dev.adam_steps([w], [[g] for g in gs], [1], 0.01, 5e-4)
+            for two in (0, 1):
+                dev.set_option("adam_sum_launch", two)
+                words = dev.buf(np.array([41, 0xFFFFFFFF], np.uint32))
+                (got,), sq = dev.adam_steps([w], [[g] for g in gs], [1], 0.01, 5e-4, epoch_words=words)
+                assert np.array_equal(got, ref) and sq == sq_ref
+                assert words.download().tolist() == [45, 44]
+                words.free()
+    finally:
+        dev.set_option("adam_sum_launch", 0)
+
+
 def test_xent_golden(dev, mods):
     lg, tr = mods["ce_logits"], mods["ce_truth"]
     cnt = int((tr >= 0).sum())
