@@ -93,7 +93,7 @@ public:
 
     // gcn.cpp:130-158, same output lines.  With early stopping (or HIPGCN_SYNC_EPOCHS) the loop is the reference's: enqueue
     // one epoch, wait, print, decide.  Otherwise nothing the host prints feeds back into the run, so epochs are enqueued
-    // ahead of the line being printed and their metrics arrive through a read-back stream in groups of consecutive epochs
+    // ahead of the line being printed and their metrics are copied back behind them in groups of consecutive epochs
     // (1 when an epoch takes milliseconds, up to READBACK_GROUP_MAX when it takes tens of microseconds; run_pipelined):
     // `time=` is then the interval between consecutive group completions / the group's size and `total training time`
     // their sum = the wall time of the whole loop.
