@@ -28,6 +28,7 @@ struct GcnOptions {
     int gs_u;               // > 0: row loads in flight per lane group of the aggregation (0: by table size)
     int gs_nt;              // 1: non-temporal row loads in the sliced aggregation (measured slower)
     int gs_fold;            // 1: split rows are summed inside the aggregation launch (same bits; no faster)
+    int gs_l;               // 8 / 4: column slices of 32 / 16 floats in the XCD-sliced aggregation (default 0: 64 floats)
     int gemm_tiles;         // 1: first-layer forward by the tile kernels instead of the persistent form
     int gemm_w4;            // 1: four-wave forward tiles
     int gemm_persist_bwd;   // 1: persistent first-layer weight gradient (measured slower)

@@ -1,0 +1,386 @@
+// dense_bf16x3.h — the dense first-layer products on the bf16 matrix pipe with f32 results (round 5):
+//     forward   H0[m x 128]  = X~[m x K] . W[K x 128]            (SparseMatmul::forward on a dense X, module.cpp:47-61)
+//     backward  dW[K x 128]  = X~^T[K x m] . dH0[m x 128]         (SparseMatmul::backward, module.cpp:63-77)
+// Why: the exact-f32 MFMA (dense_persist.h, dense_tile128.h) runs at 1/16 of the bf16 MFMA rate on gfx950 and these three
+// 35.9-GFLOP products were 31 % of the epoch at 0.65-0.73 of that pipe's peak.
+// How: every f32 operand is split EXACTLY into three bf16 planes, x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi),
+// lo = x - hi - mid (round-to-nearest planes: |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, and lo has at most 8 significant bits, so
+// it is a bf16 number: nothing is lost in the split).  A product a.b is the sum of nine plane products; the six with
+// weight >= 2^-16 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi) are issued as v_mfma_f32_32x32x16_bf16 into the SAME f32
+// accumulator (NP = 6); NP = 8 adds mid.lo and lo.mid (weight 2^-24).  bf16 x bf16 is exact in f32, so the only errors
+// are the dropped plane products (<= 2^-23 |a.b| for NP = 6, <= 2^-32 for NP = 8) and the accumulator's roundings — fewer
+// of them than the exact-f32 chain's one per k (the pipe adds 16 products per instruction before it rounds).  The error
+// against a float64 product is measured beside the exact-f32 kernels' in tools/gemm_bf16x3.hip and tests/test_ops_gpu.py;
+// both sit inside the summation-order bound the parity tests use (8 eps_f32 sum|terms|).
+// X (and A^.X) stay f32 in HBM and are split in registers on their way from LDS to the MFMA operands (the same 561 MB per
+// product as the f32 kernels; pre-split planes would be 842 MB); W1 / dH0 are split by small pre-passes.
+// The f32-MFMA kernels stay selectable (option gemm_bf16x3 = 0).
+#pragma once
+#include "dense_persist.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+#define MFMA_BF16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a_), (b_), (c_), 0, 0, 0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BX_BK = 32;                                    // K per chunk of X (two MFMA k-steps of 16 = two half-items)
+constexpr int BX_BH_BYTES = 3 * 4 * 1024;                    // 12288: one k-step of W: [plane][column block][lane] x 16 bytes
+constexpr int BX_NB = 8;                                     // ring of W k-steps in LDS
+constexpr int BX_PD = 4;                                     // ... issued this many half-items ahead of their use
+constexpr int BX_SMEM = BX_NB * BX_BH_BYTES;                 // 98304
+
+// (global_load_lds_dwordx3 is no way to move a 12 KB block in 768-byte pieces: measured on gfx950, tools/gemm_bf16x3.hip's probe,
+// it writes each lane's 12 bytes at LDS base + lane * 16 and leaves the fourth dword of every 16 untouched.  The W k-step
+// therefore travels as twelve 1 KB dwordx4 pieces: waves 0-3 issue two, waves 4-7 one; the counted waits below know.)
+
+// two f32 -> their bf16 roundings (one v_cvt_pk_bf16_f32) as a packed word
+__device__ __forceinline__ uint32_t bx_cvt2(float a, float b) {
+    const bf16x2_t h = __builtin_convertvector((float2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, h);
+}
+// (a, b) -> word i of the three planes: a = hi + mid + lo exactly (see the header)
+__device__ __forceinline__ void bx_split2(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l) {
+    // (v_pk_add_f32 beside MFMAs is slower than two scalar subtractions: cdna guide, "anti-lever")
+    h = bx_cvt2(a, b);
+    float ra = a - __uint_as_float(h << 16);
+    asm("" : "+v"(ra));                                      // opaque: keeps hipcc from packing the two subtractions into v_pk_add_f32
+    const float rb = b - __uint_as_float(h & 0xFFFF0000u);
+    m = bx_cvt2(ra, rb);
+    float sa = ra - __uint_as_float(m << 16);
+    asm("" : "+v"(sa));
+    const float sb = rb - __uint_as_float(m & 0xFFFF0000u);
+    l = bx_cvt2(sa, sb);
+}
+struct BxPlanes { uint32_t w[3][4]; };                       // [plane][word]: 8 bf16 per plane
+__device__ __forceinline__ bf16x8 bx_plane(const BxPlanes &P, int p) {
+    const uint4 q = make_uint4(P.w[p][0], P.w[p][1], P.w[p][2], P.w[p][3]);
+    return __builtin_bit_cast(bf16x8, q);
+}
+
+// W[K x 128] (* scale) -> the forward's B image, one 12 KB block per k-step hs: 16-byte piece ((hs*3 + p)*4 + n)*64 + lane
+// holds plane p of W[k(hs, lane >> 5, j)][32 n + (lane & 31)], j = 0..7, where the MFMA's k slots are PERMUTED inside a
+// 32-wide chunk so that a lane of the forward reads 16 consecutive floats of its row of X:
+//     k(hs, h, j) = 32 (hs >> 1) + 16 h + 8 (hs & 1) + j          (rows past K: zero)
+// One thread per (hs, n, lane).
+__device__ inline void bx_pack_w_body(int idx, const float *__restrict__ w, int ldw, int K, int n_hs, uint4 *__restrict__ wp, float scale) {
+    if (idx >= n_hs * 4 * 64) return;
+    const int lane = idx & 63, n = (idx >> 6) & 3, hs = idx >> 8;
+    const int col = 32 * n + (lane & 31), k0 = 32 * (hs >> 1) + 16 * (lane >> 5) + 8 * (hs & 1);
+    BxPlanes P;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int k = k0 + 2 * i;
+        const float a = k < K ? w[(size_t)k * ldw + col] * scale : 0.f, b = (k + 1) < K ? w[(size_t)(k + 1) * ldw + col] * scale : 0.f;
+        bx_split2(a, b, P.w[0][i], P.w[1][i], P.w[2][i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) wp[(((size_t)hs * 3 + p) * 4 + n) * 64 + lane] = make_uint4(P.w[p][0], P.w[p][1], P.w[p][2], P.w[p][3]);
+}
+__global__ __launch_bounds__(256) void bx_pack_w_kernel(const float *__restrict__ w, int ldw, int K, int n_hs, uint4 *__restrict__ wp, float scale) {
+    bx_pack_w_body(blockIdx.x * blockDim.x + threadIdx.x, w, ldw, K, n_hs, wp, scale);
+}
+// keep bits + packed W in one launch (as dropbits_pack_w_kernel of dense_persist.h)
+__global__ __launch_bounds__(256) void dropbits_bx_pack_w_kernel(uint32_t *__restrict__ bits, int64_t n_elems, int thr, uint64_t seed,
+                                                                 const uint32_t *d_epoch, uint64_t block0, int n_bits_wgs,
+                                                                 const float *__restrict__ w, int ldw, int K, int n_hs,
+                                                                 uint4 *__restrict__ wp, float scale) {
+    if ((int)blockIdx.x < n_bits_wgs) dropbits_block_body((int64_t)blockIdx.x * 256 + threadIdx.x, bits, n_elems, thr, seed, d_epoch, block0);
+    else bx_pack_w_body(((int)blockIdx.x - n_bits_wgs) * 256 + threadIdx.x, w, ldw, K, n_hs, wp, scale);
+}
+
+struct Bx3FwdArgs {
+    const float *x; int ldx;          // X, 16-byte aligned rows, ldx >= round_up(K, 32) with zero padding
+    const uint4 *wp;                  // packed planes of W (bx_pack_w_kernel): 2 * n_chunks blocks of 12 KB
+    float *out; int ldo;              // H0 [m x 128]; m * ldo * 4 < 2^32 (buffer stores)
+    int m, K, n_chunks, n_rb;         // n_chunks = ceil(K / 32); n_rb = ceil(m / 32)
+    const uint32_t *bits;             // keep bits of the stored elements (element row*K + col), NULL: no dropout
+    int relu;
+};
+
+struct BxB3 { bf16x8 h, m, l; };
+template <int N> struct BxN { static constexpr int value = N; };
+struct BxRaw { f32x4 v[4]; u32x2 kw; };                       // one chunk of this lane's row: 16 floats (k = 16 hh + 0..15) + the keep words
+
+// Every vector-memory operation of the kernel is inline asm, so that ONE hand-kept count covers them all (vmcnt counts loads,
+// LDS-DMA pieces and stores together, in issue order; hipcc neither sees these nor waits for them).
+template <int OFF>
+__device__ __forceinline__ void bx_gload16(f32x4 &dst, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void bx_gload8(u32x2 &dst, const uint32_t *p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding; the registers of `r` are tied to the statement so
+// that no use of them can be scheduled ahead of it
+// LDS reads are inline asm as well: hipcc sinks an LDS load it can see to its first use (across sched_barrier), which puts
+// every read right in front of the MFMA that needs it — the one-load-in-flight disease.  Issued here, waited for by
+// BX_WAIT_LDS one group later (lgkmcnt(0): everything this wave has asked LDS for).
+template <int OFF>
+__device__ __forceinline__ void bx_ldsread16(bf16x8 &dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+#define BX_WAIT_LDS(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((b).h), "+v"((b).m), "+v"((b).l) :: "memory")
+// the words pair i of a split produced are complete HERE (hipcc otherwise sinks the whole split to its first use, one clump of
+// VALU in front of the next half-item's first MFMA instead of two instructions behind each MFMA of this one)
+#define BX_PIN(P, i) asm volatile("" : "+v"((P).w[0][i]), "+v"((P).w[1][i]), "+v"((P).w[2][i]))
+#define BX_WAIT_RAW(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((r).v[0]), "+v"((r).v[1]), "+v"((r).v[2]), "+v"((r).v[3]), "+v"((r).kw) :: "memory")
+
+// One 512-thread workgroup per CU for the whole launch, given a contiguous share of the 32-row blocks.  A ROUND is 8 row blocks:
+// wave w owns rows 32w .. 32w+31 of the round x all 128 columns (4 accumulator blocks of 32 x 32).
+//  * X never touches LDS: a lane reads 16 consecutive floats of its row per chunk straight into registers, three chunks deep
+//    (raw[g] being split, raw[g+1] landed or landing, raw[g+2] just issued) — the rows are private to the wave, so LDS would
+//    only buy coalescing, and the 64-byte pieces of two lanes make up the row's whole 128-byte line.
+//  * The W planes of a k-step (12 KB, shared by the 8 waves) arrive by LDS-DMA BX_PD half-items ahead into a ring of BX_NB.
+//  * A half-item = one MFMA k-step: 4 column blocks x NP plane products.  Groups G0..G3 (one column block each); the split
+//    of the next half-item's X values is spread over the four groups (one pair of values behind each), the W planes of the next
+//    group are read while this group's MFMAs run, the barrier (W k-step h+1 landed, ring slot free) sits between G1 and G2.
+// The last round of a workgroup may have fewer than 8 row blocks: waves without one run the same instruction stream on the
+// share's last row and store nothing (the counted waits need every wave to issue the same operations).
+// ABL (timing experiments only, wrong results): 1 no X loads, 2 no W DMA, 4 no split, 8 no W LDS reads
+template <bool DROP, int NP, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BX_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    if (a.m < 0) smem[tid] = 0;       // never taken: the array is otherwise written by DMA only, which the compiler cannot see
+
+    const int rb_lo = (int)((int64_t)blockIdx.x * a.n_rb / gridDim.x);
+    const int nb = (int)((int64_t)(blockIdx.x + 1) * a.n_rb / gridDim.x) - rb_lo;
+    if (nb <= 0) return;
+    const int row_last = min(a.m, (rb_lo + nb) * 32) - 1;       // rows past this workgroup's share are read as its last row (cache hits, no HBM traffic)
+    const int n_rounds = (nb + 7) >> 3;
+    const int n_items = n_rounds * a.n_chunks;                   // chunks of this wave, all rounds
+    const int n_hs = 2 * a.n_chunks;
+    const bool two_pieces = wave < 4;                            // pieces of a W k-step this wave issues: 2 (waves 0-3) or 1
+
+    // the X values (and keep words) of chunk (round t, chunk c) of this lane's row
+    auto load_raw = [&](BxRaw &r, int t, int c) __attribute__((always_inline)) {
+        const int row = min((rb_lo + 8 * t + wave) * 32 + li, row_last);
+        const float *p = a.x + (size_t)row * a.ldx + c * BX_BK + 16 * hh;
+        if (ABL & 1) p = a.x + lane * 16;
+        bx_gload16<0>(r.v[0], p); bx_gload16<16>(r.v[1], p); bx_gload16<32>(r.v[2], p); bx_gload16<48>(r.v[3], p);
+        if (DROP) {
+            const uint64_t e0 = (uint64_t)row * a.K + c * BX_BK + 16 * hh;
+            bx_gload8(r.kw, a.bits + (e0 >> 5));
+        } else {
+            r.kw = (u32x2){0u, 0u};
+        }
+    };
+    constexpr int LA = DROP ? 5 : 4;                             // vector-memory operations of one load_raw
+    // the W k-step of half-item hq (its index inside the round repeats with every round) into ring slot hq % BX_NB
+    auto issue_b = [&](int hq) __attribute__((always_inline)) {
+        if (ABL & 2) return;
+        int hs = hq % n_hs;
+        const uint32_t dst = lds0 + (hq % BX_NB) * BX_BH_BYTES;
+        const uint4 *src = a.wp + (size_t)hs * (BX_BH_BYTES / 16);
+        pg_glds16(src + wave * 64 + lane, dst + wave * 1024);
+        if (two_pieces) pg_glds16(src + (wave + 8) * 64 + lane, dst + (wave + 8) * 1024);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((uint32_t)a.m * (uint32_t)a.ldo * 4u), 0x00020000);
+    auto store_block = [&](f32x16 &v, int row0, int col, bool live) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float x = (a.relu && !(v[r] > 0.f)) ? 0.f : v[r];
+            // a wave without a row block of its own in this round stores past the buffer's range: dropped by the hardware, counted like the others
+            const uint32_t off = live ? ((uint32_t)row * (uint32_t)a.ldo + (uint32_t)col) * 4u : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), orsrc, (int)off, 0, 0);
+            v[r] = 0.f;
+        }
+    };
+
+    // pair i (0..3) of k-step s of a landed chunk -> word i of the three planes (keep bits applied first)
+    auto split_pair = [&](BxPlanes &P, const BxRaw &r, uint32_t win, int s, int i) __attribute__((always_inline)) {
+        const f32x4 v = r.v[2 * s + (i >> 1)];
+        float x0 = (i & 1) ? v[2] : v[0], x1 = (i & 1) ? v[3] : v[1];
+        if (DROP) {
+            const int j = 8 * s + 2 * i;                         // bit j of the window <-> this lane's k value j of the chunk
+            x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)(((int32_t)(win << (31 - j))) >> 31));
+            x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)(((int32_t)(win << (30 - j))) >> 31));
+        }
+        if (ABL & 4) { P.w[0][i] = __float_as_uint(x0); P.w[1][i] = __float_as_uint(x1); P.w[2][i] = P.w[0][i]; return; }
+        bx_split2(x0, x1, P.w[0][i], P.w[1][i], P.w[2][i]);
+    };
+    auto window = [&](const BxRaw &r, int t, int c) __attribute__((always_inline)) -> uint32_t {
+        if (!DROP) return 0u;
+        const int row = min((rb_lo + 8 * t + wave) * 32 + li, row_last);
+        const uint32_t sh = (uint32_t)(((uint64_t)row * a.K + c * BX_BK + 16 * hh) & 31);
+        return (uint32_t)(((((uint64_t)r.kw[1]) << 32) | r.kw[0]) >> sh);
+    };
+    // the three planes of column block N of the W k-step in ring slot hq % BX_NB: issued, not waited for
+    auto read_b = [&](BxB3 &b, int hq, auto n_tag) __attribute__((always_inline)) {
+        constexpr int N = (ABL & 8) ? 0 : decltype(n_tag)::value;
+        const uint32_t addr = lds0 + (hq % BX_NB) * BX_BH_BYTES + lane * 16;
+        bx_ldsread16<(0 * 4 + N) * 1024>(b.h, addr);
+        bx_ldsread16<(1 * 4 + N) * 1024>(b.m, addr);
+        bx_ldsread16<(2 * 4 + N) * 1024>(b.l, addr);
+    };
+    // acc += A . B over the NP plane products, smallest weights first
+    auto mac = [&](f32x16 &c, const BxPlanes &A, const BxB3 &B) __attribute__((always_inline)) {
+        const bf16x8 ah = bx_plane(A, 0), am = bx_plane(A, 1), al = bx_plane(A, 2);
+        if (NP >= 8) { c = MFMA_BF16(al, B.m, c); c = MFMA_BF16(am, B.l, c); }
+        c = MFMA_BF16(al, B.h, c);
+        c = MFMA_BF16(am, B.m, c);
+        c = MFMA_BF16(ah, B.l, c);
+        c = MFMA_BF16(am, B.h, c);
+        c = MFMA_BF16(ah, B.m, c);
+        c = MFMA_BF16(ah, B.h, c);
+    };
+    // one group: NP MFMAs with 3 of the group's other instructions (split VALU, LDS reads) behind each
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+        }
+    };
+
+    // ---- prologue: W k-steps 0 .. BX_PD-1, X chunks 0 and 1; everything landed
+    BxRaw R0, R1, R2;
+#pragma unroll
+    for (int q = 0; q < BX_PD; q++) issue_b(q);
+    load_raw(R0, 0, 0);
+    {
+        const int t1 = a.n_chunks > 1 ? 0 : 1, c1 = a.n_chunks > 1 ? 1 : 0;
+        load_raw(R1, min(t1, n_rounds - 1), n_items > 1 ? c1 : 0);
+    }
+    BX_WAIT_RAW(0, R0);
+    BX_WAIT_RAW(0, R1);
+    __builtin_amdgcn_s_barrier();
+    BxPlanes P0, P1;
+    {
+        const uint32_t w0 = window(R0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) split_pair(P0, R0, w0, 0, i);
+    }
+    BxB3 Bc, Bn;
+    read_b(Bc, 0, BxN<0>());
+    BX_WAIT_LDS(Bc);
+    int since_store = 1000;                                      // half-items since this wave's last epilogue (its 64 stores sit in the queue)
+
+    // one chunk = two half-items.  Ra = raw[g] (its second half still to be split), Rb = raw[g+1] (landed by the second
+    // half-item), Rc = the buffer raw[g+2] goes into
+    auto chunk = [&](BxRaw &Ra, BxRaw &Rb, BxRaw &Rc, int g) __attribute__((always_inline)) {
+        const int t = g / a.n_chunks, c = g - t * a.n_chunks;
+        int t1 = t, c1 = c + 1; if (c1 == a.n_chunks) { c1 = 0; ++t1; }
+        int t2 = t1, c2 = c1 + 1; if (c2 == a.n_chunks) { c2 = 0; ++t2; }
+        if (t1 >= n_rounds) { t1 = n_rounds - 1; c1 = a.n_chunks - 1; }       // past the end: the same operations on the last chunk (nobody uses them)
+        if (t2 >= n_rounds) { t2 = n_rounds - 1; c2 = a.n_chunks - 1; }
+        const int h0 = 2 * g;
+        const uint32_t wa = window(Ra, t, c);
+        // ================= half-item (g, 0): MFMAs on P0; raw[g]'s second half -> P1; raw[g+2] issued
+        read_b(Bn, h0, BxN<1>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P1, Ra, wa, 1, 0);
+        mac(acc[0], P0, Bc);
+        interleave();
+        BX_PIN(P1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bn);
+        read_b(Bc, h0, BxN<2>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P1, Ra, wa, 1, 1);
+        mac(acc[1], P0, Bn);
+        interleave();
+        BX_PIN(P1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bc);
+        // W k-step h0+1 has landed (issued BX_PD-1 half-items ago; younger: BX_PD-2 W issues and the X loads of one chunk, or
+        // this wave's 64 stores), every wave is past half-item h0-1: its ring slot takes k-step h0+BX_PD
+        if (since_store <= 2) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
+        else if (two_pieces) { if (DROP) PG_WAIT_BARRIER(9); else PG_WAIT_BARRIER(8); }
+        else { if (DROP) PG_WAIT_BARRIER(7); else PG_WAIT_BARRIER(6); }
+        issue_b(h0 + BX_PD);
+        load_raw(Rc, t2, c2);
+        read_b(Bn, h0, BxN<3>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P1, Ra, wa, 1, 2);
+        mac(acc[2], P0, Bc);
+        interleave();
+        BX_PIN(P1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bn);
+        read_b(Bc, h0 + 1, BxN<0>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P1, Ra, wa, 1, 3);
+        mac(acc[3], P0, Bn);
+        interleave();
+        BX_PIN(P1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bc);
+        since_store++;
+        // ================= half-item (g, 1): MFMAs on P1; raw[g+1]'s first half -> P0
+        // raw[g+1] has landed: issued three half-items ago; younger: two W issues and the X loads of raw[g+2]
+        if (since_store <= 2) BX_WAIT_RAW(63, Rb);
+        else if (two_pieces) { if (DROP) BX_WAIT_RAW(9, Rb); else BX_WAIT_RAW(8, Rb); }
+        else { if (DROP) BX_WAIT_RAW(7, Rb); else BX_WAIT_RAW(6, Rb); }
+        const uint32_t wb = window(Rb, t1, c1);
+        read_b(Bn, h0 + 1, BxN<1>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P0, Rb, wb, 0, 0);
+        mac(acc[0], P1, Bc);
+        interleave();
+        BX_PIN(P0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bn);
+        read_b(Bc, h0 + 1, BxN<2>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P0, Rb, wb, 0, 1);
+        mac(acc[1], P1, Bn);
+        interleave();
+        BX_PIN(P0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bc);
+        // (here the W k-step waited for was issued at an even half-item, in FRONT of that half-item's X loads: two W issues and
+        //  the X loads of two chunks are younger)
+        if (since_store <= 2) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
+        else if (two_pieces) { if (DROP) PG_WAIT_BARRIER(14); else PG_WAIT_BARRIER(12); }
+        else { if (DROP) PG_WAIT_BARRIER(12); else PG_WAIT_BARRIER(10); }
+        issue_b(h0 + 1 + BX_PD);
+        read_b(Bn, h0 + 1, BxN<3>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P0, Rb, wb, 0, 2);
+        mac(acc[2], P1, Bc);
+        interleave();
+        BX_PIN(P0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bn);
+        read_b(Bc, h0 + 2, BxN<0>());
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(P0, Rb, wb, 0, 3);
+        mac(acc[3], P1, Bn);
+        interleave();
+        BX_PIN(P0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_WAIT_LDS(Bc);
+        since_store++;
+        if (c == a.n_chunks - 1) {
+            const bool live = 8 * t + wave < nb;
+#pragma unroll
+            for (int n = 0; n < 4; n++) store_block(acc[n], (rb_lo + 8 * t + wave) * 32, 32 * n + li, live);
+            since_store = 0;
+        }
+    };
+    int g = 0;
+    for (; g + 3 <= n_items; g += 3) {
+        chunk(R0, R1, R2, g);
+        chunk(R1, R2, R0, g + 1);
+        chunk(R2, R0, R1, g + 2);
+    }
+    if (g < n_items) { chunk(R0, R1, R2, g); g++; }
+    if (g < n_items) { chunk(R1, R2, R0, g); g++; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing of this wave may still be landing in LDS when it ends
+}

@@ -27,6 +27,25 @@ SHAPES = {
     "tiny-syn": (97, 23, 5, 211, 6, 30, 25, 30),
 }
 
+# Reddit-shaped variants that differ only in the community structure planted in the graph (round 5: the headline's
+# sensitivity to that structure).  `<reddit-syn|reddit-mini>-<variant>`: (share of the edges whose second endpoint is drawn
+# inside the first endpoint's class, class sizes).  The plain names keep the round-1 generator: 0.6, equal classes.
+#   h0    SURVEY 8(d)'s literal Chung-Lu graph: no planted structure at all (the labels are then independent of the graph)
+#   h03   half the mixing of the plain graph
+#   zipf  the plain graph's mixing with class sizes ~ 1/rank: the largest class holds 23 % of the nodes (54 K rows = 13.9 MB of
+#         256-byte column slices, 3.3 x one XCD's L2), the smallest 0.6 %
+REDDIT_VARIANTS = {"h0": (0.0, "equal"), "h03": (0.3, "equal"), "zipf": (0.6, "zipf")}
+
+
+def reddit_variant(name: str):
+    """(base shape name, homophily, class sizes) of a reddit-* dataset name"""
+    parts = name.split("-")
+    base = "-".join(parts[:2])
+    if len(parts) == 2:
+        return base, 0.6, "equal"
+    h, sizes = REDDIT_VARIANTS[parts[2]]
+    return base, h, sizes
+
 
 def _unique_undirected(u, v, n):
     """drop self loops and duplicate pairs; return (lo, hi) arrays"""
@@ -127,17 +146,27 @@ def make_dataset(name: str, seed: int = DEFAULT_SEED, rows: slice | None = None)
         nnz_row = 0
         n_train = n_val = n_test = -2
     else:
-        N, F, C, M, nnz_row, n_train, n_val, n_test = SHAPES[name]
+        homophily, class_sizes = 0.6, "equal"
         if name.startswith("reddit"):
-            # Chung-Lu, power-law expected degrees (exponent ~2.3), capped; 60 % of the edges stay
+            base, homophily, class_sizes = reddit_variant(name)
+            N, F, C, M, nnz_row, n_train, n_val, n_test = SHAPES[base]
+        else:
+            N, F, C, M, nnz_row, n_train, n_val, n_test = SHAPES[name]
+        if name.startswith("reddit"):
+            # Chung-Lu, power-law expected degrees (exponent ~2.3), capped; by default 60 % of the edges stay
             # inside a class (Reddit communities are posts of one subreddit = one label)
             w = (np.arange(1, N + 1, dtype=np.float64)) ** (-1.0 / 1.3)
             rng.shuffle(w)
             cap = 2.0e4 * w.sum() / (2.0 * M)
             w = np.minimum(w, cap)
-            pre_label = np.random.default_rng(seed + 1).integers(0, C, N).astype(np.int32)
+            lrng = np.random.default_rng(seed + 1)
+            if class_sizes == "zipf":
+                pz = 1.0 / np.arange(1, C + 1, dtype=np.float64)
+                pre_label = lrng.choice(C, N, p=pz / pz.sum()).astype(np.int32)
+            else:
+                pre_label = lrng.integers(0, C, N).astype(np.int32)
             pre_label[:C] = np.arange(C, dtype=np.int32)
-            lo, hi = _sample_edges(rng, N, M, w, pre_label, 0.6)
+            lo, hi = _sample_edges(rng, N, M, w, pre_label, homophily)
         else:
             lo, hi = _sample_edges(rng, N, M)
     if not name.startswith("rmat-"):
@@ -194,10 +223,22 @@ def make_dataset(name: str, seed: int = DEFAULT_SEED, rows: slice | None = None)
         split[perm[n_train:n_train + n_val]] = 2
         split[perm[n_train + n_val:n_train + n_val + n_test]] = 3
 
-    return dict(name=name, num_nodes=N, input_dim=F, output_dim=C,
-                g_indptr=g_indptr, g_indices=g_indices,
-                f_indptr=f_indptr, f_indices=f_indices, f_val=f_val,
-                label=label, split=split)
+    ds = dict(name=name, num_nodes=N, input_dim=F, output_dim=C,
+              g_indptr=g_indptr, g_indices=g_indices,
+              f_indptr=f_indptr, f_indices=f_indices, f_val=f_val,
+              label=label, split=split)
+    if name.startswith("reddit"):
+        ds["planted_homophily"] = homophily
+        ds["class_sizes"] = class_sizes
+    return ds
+
+
+def edge_homophily(ds):
+    """share of the stored non-self edges whose two ends carry the same label (what the generator planted, measured)"""
+    gp, gi = ds["g_indptr"].astype(np.int64), ds["g_indices"]
+    src = np.repeat(np.arange(gp.size - 1), np.diff(gp))
+    m = src != gi
+    return float((ds["label"][src[m]] == ds["label"][gi[m]]).mean())
 
 
 def write_text(ds, root: str, name: str | None = None):

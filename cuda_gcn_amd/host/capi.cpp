@@ -67,6 +67,7 @@ int gcnhost_model_create(gcnhost_model **out, const gcnhost_params *p,
         HipGCNOptions o;
         o.device = device; o.seed = seed; o.flags = flags; o.rank = rank; o.world = world; o.nccl_id = nccl_id;
         o.host_allgather = host_ag; o.host_allreduce = host_ar; o.host_user = host_user;
+        o = HipGCNOptions::from_environment(o);                 // every HIPGCN_* variable, read once (host/options.cpp)
         try {
             m->gcn = new HipGCN(gp, &m->data, o);
         } catch (...) {

@@ -55,8 +55,9 @@ HipGCN::HipGCN(GCNParams p, GCNData *input_data, const HipGCNOptions &opt) : par
 
 void HipGCN::init(const HipGCNOptions &opt) {
     device_ = opt.device;
-    // HIPGCN_VERBOSE: where the model build's wall time goes (stderr), phase by phase
-    const bool verbose = getenv("HIPGCN_VERBOSE") != nullptr && opt.rank == 0;
+    opt_ = opt;                 // every switch comes from the options (HipGCNOptions::from_environment for the HIPGCN_* variables)
+    // opt.verbose: where the model build's wall time goes (stderr), phase by phase
+    const bool verbose = opt.verbose && opt.rank == 0;
     auto t_phase = std::chrono::steady_clock::now();
     auto phase = [&](const char *what) {
         if (!verbose) return;
@@ -98,9 +99,6 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // The factored aggregation (gcnhip_graphsum_ex): no per-edge coefficient stream; the gathered matrices are stored
     // pre-multiplied by dinv of their row (the producers fold the factor into a row-wise epilogue or a value array).  The
     // fused f32 path only; HIPGCN_EDGE_COEF restores the reference's per-edge coefficients.
-    if (getenv("HIPGCN_EDGE_COEF")) flags |= HIPGCN_EDGE_COEF;
-    if (getenv("HIPGCN_PACKED_DH1")) flags |= HIPGCN_PACKED_DH1;
-    if (getenv("HIPGCN_BWD_PIPELINE")) flags |= HIPGCN_BWD_PIPELINE;
     if ((flags & (HIPGCN_PACKED_DH1 | HIPGCN_BWD_PIPELINE)) && !gcnhip_experiments()) {
         // measured-slower variants live behind the library's compile-time switch (make EXPERIMENTS=1)
         fprintf(stderr, "gcn-hip: HIPGCN_PACKED_DH1 / HIPGCN_BWD_PIPELINE ignored: libgcnhip.so was built without GCNHIP_EXPERIMENTS\n");
@@ -111,22 +109,19 @@ void HipGCN::init(const HipGCNOptions &opt) {
     const int N = params.num_nodes, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
 
     // ---- node order (several GPUs: by structure when the ids carry no locality), row partition, this rank's slice
-    if (getenv("HIPGCN_STRUCTURE_PARTITION")) flags |= HIPGCN_STRUCTURE_PARTITION;
-    if (getenv("HIPGCN_ID_PARTITION")) flags |= HIPGCN_ID_PARTITION;
     // How remote rows will arrive is decided BEFORE the node order: renumbering exists to turn an all-gather into halo
     // lists, so a run whose exchange is pinned to the all-gather (the flag, HIPGCN_EXCHANGE=allgather, or the default over
     // RCCL until the halo exchange has met a peer) keeps its ids — no second host copy of X, no group search, and rows,
     // dropout decisions and get_var() stay in the dataset's order.
     int exchange_mode = (flags & HIPGCN_EXCHANGE_HALO) ? 2 : ((flags & HIPGCN_EXCHANGE_ALLGATHER) ? 1 : 0);
     {
-        const char *e = getenv("HIPGCN_EXCHANGE");
-        if (e) exchange_mode = !strcmp(e, "halo") ? 2 : (!strcmp(e, "allgather") ? 1 : (!strcmp(e, "auto") ? 0 : exchange_mode));
+        if (opt.exchange >= 0) exchange_mode = opt.exchange;
         // Over RCCL the per-graph decision is opt-in (HIPGCN_EXCHANGE=auto|halo, or the flag): the halo exchange is a grouped
         // ncclSend/ncclRecv that has run against real peers only in gcnhost_rccl_selftest_world, so an unasked-for run takes
         // the in-place all-gather.  bench.py's launcher runs that self-test as a throw-away group of ranks and then asks
         // for `auto`.  (Host-staged transports and tests decide per graph as before.)
         const bool over_rccl = world > 1 && !opt.comm && !opt.host_allgather && !(flags & HIPGCN_NULL_COMM);
-        if (over_rccl && exchange_mode == 0 && !(e && !strcmp(e, "auto"))) exchange_mode = 1;
+        if (over_rccl && exchange_mode == 0 && opt.exchange != 0) exchange_mode = 1;
     }
     // Parity mode (HIPGCN_HOST_MASKS) replays the reference's RNG stream in the DATASET's element order
     // (host_masks_for_epoch): a renumbered run would hand node k's decisions to another node, so it keeps its ids too
@@ -140,14 +135,14 @@ void HipGCN::init(const HipGCNOptions &opt) {
     const int r0 = part.start[rank], r1 = part.start[rank + 1];
     n_local = r1 - r0;
     nnzA_local = (long)gp[r1] - gp[r0];
-    if (getenv("HIPGCN_NO_LABEL_HINT")) flags |= HIPGCN_NO_LABEL_HINT;
     labels_assortative = !(flags & (HIPGCN_NO_ROW_GROUPS | HIPGCN_NO_LABEL_HINT)) && labels_are_assortative(*data, N, C);
     // no usable labels: look for row groups in the graph itself (one pass over the edges per sweep, every rank the same
     // result); whether they are used is decided by timing, like every other schedule (tune_schedule)
     // (on a host thread beside the object builds and H2D copies below: one sweep over an R-MAT graph of scale 22 is 3 s, and its
     //  result is not needed before the schedules are timed)
     std::future<StructureGroups> groups_search;
-    if (!(flags & HIPGCN_NO_ROW_GROUPS) && !labels_assortative && n_local >= 4096 && !getenv("HIPGCN_NO_STRUCTURE_GROUPS"))
+    if (!(flags & HIPGCN_NO_ROW_GROUPS) && !labels_assortative && n_local >= 4096 && opt.structure_groups &&
+        (opt.schedule < 0 || opt.schedule == 3))
         groups_search = std::async(std::launch::async, [&gp, &gi, N]() { return structure_groups(gp.data(), gi.data(), N); });
     struct JoinGroups {                       // never leave the thread running over a dataset that is being torn down
         std::future<StructureGroups> &f;
@@ -212,7 +207,6 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // The last aggregation of a forward computes only the rows the loss and the accuracy read
     // (CrossEntropyLoss::forward skips truth < 0, module.cpp:131-133; get_accuracy, gcn.cpp:86-88):
     // one registered row subset per split.
-    if (getenv("HIPGCN_ALL_ROWS")) flags |= HIPGCN_ALL_ROWS;
     if (!(flags & HIPGCN_ALL_ROWS)) add_split_rowsets(env.ctx, graph, split_rows);
     if (!(flags & HIPGCN_MODULAR)) {
         // the loss walks the rows of the scored split only (it skips the others anyway, module.cpp:131-133)
@@ -320,22 +314,18 @@ void HipGCN::init(const HipGCNOptions &opt) {
     // The output layer's backward aggregates dZ, which is zero outside the training split: the edges that point at those
     // rows leave the operator for good (a third of Reddit's, 95 % of Cora's) — after the row order has been chosen,
     // which the restricted object inherits.
-    if (getenv("HIPGCN_MASKED_BWD")) flags |= HIPGCN_MASKED_BWD;
     if (!(flags & HIPGCN_MASKED_BWD) && n_local > 0)
         GCNHIP_CHECK(gcnhip_graph_create_restricted(env.ctx, &graph_bwd_out, graph, h_train_bits.data()));
-    if (getenv("HIPGCN_OVERLAP_EXCHANGE")) flags |= HIPGCN_OVERLAP_EXCHANGE;
     // decided from world, flags and the storage format only — the same on every rank: the exchange lane's communicator is
     // an ncclCommSplit, a collective over the parent; a rank that owns no rows still creates it (and skips only the cuts)
     if ((flags & HIPGCN_OVERLAP_EXCHANGE) && world > 1 && !env.bf16_tables) build_overlap();
     build_modules();
-    if (getenv("HIPGCN_NO_AGG_FIRST_EVAL")) flags |= HIPGCN_NO_AGG_FIRST_EVAL;
     if (!(flags & (HIPGCN_NO_AGG_FIRST_EVAL | HIPGCN_MODULAR)) && gcnhip_feat_is_dense(feat) && n_local > 0) build_agg_first_eval();
     phase("restricted operator, modules, A^.X");
     if (factored_) apply_factored_scales();
     phase("factored scales");
     // opt-in everywhere: with several GPUs the lane brings a second communicator and the turnstile, which must be measured
     // on a multi-GPU node before they may become a default there (bench.py tries both schedules)
-    if (getenv("HIPGCN_EVAL_LANE")) flags |= HIPGCN_EVAL_LANE;
     if (!(flags & HIPGCN_NO_EVAL_LANE) && (flags & HIPGCN_EVAL_LANE)) {
         try {
             build_eval_lane();
@@ -390,7 +380,7 @@ void HipGCN::renumber_nodes(int world) {
     if ((force || ids.halo_share > 0.75) && N >= 4096) sg = structure_groups(gp.data(), gi.data(), N);
     NodeOrderChoice ch = choose_node_order(gp.data(), gi.data(), N, world, sg.useful ? sg.group.data() : nullptr, force);
     if (ch.order.empty()) return;
-    if (env.comm->rank() == 0 && getenv("HIPGCN_VERBOSE"))
+    if (env.comm->rank() == 0 && opt_.verbose)
         fprintf(stderr, "gcn-hip: nodes renumbered by %s: neediest rank reads %ld rows per exchange instead of %ld (all-gather: %ld)\n",
                 ch.name, ch.chosen.recv_rows_max, ch.ids.recv_rows_max, (long)(world - 1) * ch.ids.rows_max);
     renumbered.reset(new GCNData());
@@ -440,8 +430,20 @@ void HipGCN::add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *
 }
 
 void HipGCN::tune_schedule() {
-    if (n_local < 4096) return;                              // launch-bound graphs: nothing to gain
+    if (n_local < 4096 && opt_.schedule < 0) return;         // launch-bound graphs: nothing to gain
     const int H = params.hidden_dim;
+    gcnhip_graph *g = replicate_l1 ? graph_l1 : graph;       // the layer-1 aggregation, the widest one
+    if (opt_.schedule >= 0) {
+        // pinned (HIPGCN_SCHEDULE): no candidate is timed, so no tuning launch shares a kernel name with the epochs' launches
+        sched_mode = opt_.schedule; sched_groups = opt_.schedule == 2 ? opt_.schedule_groups : 0;
+        if (sched_mode == 3 && structure_group.empty()) sched_mode = 0;      // the search found no usable groups
+        if (sched_mode == 3) sched_groups = structure_n_groups;
+        if (sched_mode != 0) {
+            apply_schedule(env.ctx, graph);
+            if (graph_l1) apply_schedule(env.ctx, graph_l1);
+        }
+        return;
+    }
     HipVariable *in = variables[1].get(), *out = variables[3].get();
     float *src = in->full ? in->full : in->data;
     const size_t src_elems = in->full ? in->full_elems : in->elems();
@@ -455,7 +457,11 @@ void HipGCN::tune_schedule() {
     GCNHIP_CHECK(gcnhip_event_create(&e1));
     float best = 0.f;
     Cand pick = cands[0];
-    gcnhip_graph *g = replicate_l1 ? graph_l1 : graph;       // the layer-1 aggregation, the widest one
+    // the candidates are timed with the launch the epoch uses: the factored operator (no coefficient stream, 6-10 % of a
+    // launch) on the fused f32 path, the reference's per-edge coefficients otherwise
+    gcnhip_gs_opts gso;
+    memset(&gso, 0, sizeof gso);
+    gso.scaling = factored_ ? 2 : 0;
     bool fresh = true;                                       // g still has the schedule it was built with: descending degree = candidate 0
     for (const Cand &c : cands) {
         sched_mode = c.mode; sched_groups = c.groups;
@@ -464,7 +470,7 @@ void HipGCN::tune_schedule() {
         float ms = 0.f;
         for (int it = 0; it < 3; it++) {                     // first run warms the caches and sizes the scratch
             if (it == 1) GCNHIP_CHECK(gcnhip_event_record(env.ctx, e0));
-            GCNHIP_CHECK(gcnhip_graphsum(env.ctx, g, src, in->ld, out->data, out->ld, H));
+            GCNHIP_CHECK(gcnhip_graphsum_ex(env.ctx, g, &gso, src, in->ld, out->data, out->ld, H));
         }
         GCNHIP_CHECK(gcnhip_event_record(env.ctx, e1));
         GCNHIP_CHECK(gcnhip_event_elapsed_ms(e0, e1, &ms));
@@ -560,7 +566,7 @@ void HipGCN::build_modules() {
         }
         // single GPU: the ReLU/dropout mask of H1 leaves the aggregation's store epilogue as one bit per element and the
         // Matmul backward reads those instead of H1 (-119 MB per epoch at Reddit scale); HIPGCN_NO_MASK_BITS: re-read H1
-        if (env.comm->size() == 1 && H % 32 == 0 && !env.bf16_tables && !dh1_pack && !getenv("HIPGCN_NO_MASK_BITS")) {
+        if (env.comm->size() == 1 && H % 32 == 0 && !env.bf16_tables && !dh1_pack && opt_.mask_bits) {
             const int wpr = H / 32;
             d_pos_bits = dev_upload(env.ctx, std::vector<uint32_t>((size_t)N * wpr, 0u).data(), (size_t)N * wpr);
             gs->mask_bits_out = d_pos_bits;
@@ -598,8 +604,7 @@ void HipGCN::build_modules() {
 void HipGCN::build_bwd_pipeline(HipSparseMatmul *sm, HipGraphSum *gs) {
     int rps = 0, n_splits = 0;
     GCNHIP_CHECK(gcnhip_spmm_bwd_plan(env.ctx, feat, params.hidden_dim, &rps, &n_splits));
-    int chunks = 4;
-    if (const char *e = getenv("HIPGCN_BWD_CHUNKS")) chunks = atoi(e);
+    const int chunks = opt_.bwd_chunks;
     if (n_splits < 2 * chunks || chunks < 2) return;
     bwd_pipe.reset(new BackwardPipeline());
     BackwardPipeline &P = *bwd_pipe;
@@ -877,11 +882,8 @@ void HipGCN::host_masks_for_epoch() {
 }
 
 // One GPU: the loss launch fills the metrics row itself (gcnhip_metrics_record_with_next_loss) — its result needs no
-// all-reduce first.  HIPGCN_RECORD_LAUNCH keeps the separate launch (A/B).
-static bool loss_records() {
-    static const bool off = getenv("HIPGCN_RECORD_LAUNCH") != nullptr;
-    return !off;
-}
+// all-reduce first.  HIPGCN_RECORD_LAUNCH (options.loss_records_metrics = false) keeps the separate launch (A/B).
+#define loss_records() (opt_.loss_records_metrics)
 
 void HipGCN::train_begin() {
     // (*env.d_epoch is this epoch's number already: the previous epoch's Adam launch advanced it)
@@ -1143,7 +1145,6 @@ void HipGCN::readback_enqueue(long e, int n, int k, gcnhip_ctx *producer) {
 }
 
 void HipGCN::run() {                            // gcn.cpp:130-158
-    if (getenv("HIPGCN_SYNC_EPOCHS")) flags |= HIPGCN_SYNC_EPOCHS;
     if (params.early_stopping > 0 || (flags & HIPGCN_SYNC_EPOCHS) || params.epochs < 1) run_synchronous();
     else run_pipelined();
     report_test();
@@ -1160,8 +1161,7 @@ void HipGCN::run_pipelined() {
     const bool zipped = lane && !(timers->enabled && env.comm->size() == 1);
     {   // the read-back copies ride on the producer's stream; HIPGCN_READBACK_STREAM=1 gives them their own (measured
         // slower at every size, see readback_enqueue; kept so that the measurement can be repeated)
-        const char *s = getenv("HIPGCN_READBACK_STREAM");
-        readback_create(s && atoi(s) != 0);
+        readback_create(opt_.readback_stream);
     }
     Readback &R = *readback;
     const bool talk = env.comm->rank() == 0;
@@ -1173,13 +1173,13 @@ void HipGCN::run_pipelined() {
     long n_groups = 0;
     int group = 1;                                       // epochs per read-back group
     bool group_settled = false;                          // pinned by HIPGCN_READBACK_GROUP, or set after the calibration epochs
-    if (const char *s = getenv("HIPGCN_READBACK_GROUP")) {
-        group = std::max(1, std::min(atoi(s), (int)READBACK_GROUP_MAX));
+    if (opt_.readback_group > 0) {
+        group = std::max(1, std::min(opt_.readback_group, (int)READBACK_GROUP_MAX));
         group_settled = true;
     }
     double total_train = 0, calib = 0;
     auto t_prev = std::chrono::high_resolution_clock::now();
-    const bool verbose = getenv("HIPGCN_VERBOSE") != nullptr;
+    const bool verbose = opt_.verbose;
     double host_enqueue_s = 0, host_wait_s = 0;
     while (printed < E) {
         const auto t_enq0 = std::chrono::high_resolution_clock::now();

@@ -82,6 +82,26 @@ struct HipGCNOptions {
     gcn_host_allgather_fn host_allgather = nullptr;
     gcn_host_allreduce_fn host_allreduce = nullptr;
     void *host_user = nullptr;
+
+    // ---- switches that have no flag bit.  HipGCN itself never reads the environment: the two places that build a model
+    // from outside (main.cpp, capi.cpp) call from_environment() ONCE and hand the result in.
+    bool verbose = false;                 // HIPGCN_VERBOSE: where the model build's wall time goes, run-loop statistics (stderr)
+    int exchange = -1;                    // HIPGCN_EXCHANGE: -1 unset, 0 auto (per graph), 1 allgather, 2 halo
+    bool structure_groups = true;         // HIPGCN_NO_STRUCTURE_GROUPS clears: never search the graph for row groups
+    bool mask_bits = true;                // HIPGCN_NO_MASK_BITS clears: the Matmul backward re-reads H1 instead of one bit per element
+    bool loss_records_metrics = true;     // HIPGCN_RECORD_LAUNCH clears: the metrics row gets a launch of its own (A/B)
+    int bwd_chunks = 4;                   // HIPGCN_BWD_CHUNKS: row blocks of the opt-in backward pipeline
+    bool readback_stream = false;         // HIPGCN_READBACK_STREAM: run()'s read-back copies on a stream of their own (measured slower)
+    int readback_group = 0;               // HIPGCN_READBACK_GROUP: epochs per read-back group (0: calibrated)
+    // HIPGCN_SCHEDULE=degree|label|dealt[-G]|structure: pin the aggregation's row schedule instead of timing the candidates at
+    // load (-1: timed).  A pinned run launches no tuning kernels, so a kernel-trace profile of it holds the epochs' launches only.
+    int schedule = -1, schedule_groups = 256;
+    // HIPGCN_GEMM=f32|bf16x3: arithmetic of the dense first-layer products (0: exact-f32 MFMA, 1: three-plane bf16 split on the
+    // bf16 MFMA pipe, same f32 error bound; -1: the library's default)
+    int gemm = -1;
+
+    // `base` with every HIPGCN_* variable of the process environment applied (flag variables OR their bit in)
+    static HipGCNOptions from_environment(HipGCNOptions base);
 };
 
 class HipGCN {
@@ -158,6 +178,7 @@ private:
     bool factored_ = false;
     void apply_factored_scales();                              // X, A^.X and the replicated X of this rank -> D^-1/2 . (them)
     int device_ = 0;
+    HipGCNOptions opt_;                                        // the switches of this model (a copy; comm pointers not used after init)
     const float *eval_vals = nullptr;
     HostRng rng;
 

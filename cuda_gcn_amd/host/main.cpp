@@ -105,6 +105,7 @@ int main(int argc, char **argv) {
     else base.flags |= HIPGCN_NO_EVAL_LANE;
     if (env_int("GCN_REFERENCE_ORDER", feedback ? 1 : 0)) base.flags |= HIPGCN_NO_AGG_FIRST_EVAL;
     if (env_int("GCN_SYNC_EPOCHS", 0)) base.flags |= HIPGCN_SYNC_EPOCHS;
+    base = HipGCNOptions::from_environment(base);             // every HIPGCN_* variable, read once (host/options.cpp)
     std::cout << "RUNNING ON GPU" << std::endl;
 
     int rc = EXIT_SUCCESS;

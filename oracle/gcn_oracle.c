@@ -141,15 +141,44 @@ void or_spmm_bwd(const int *indptr, const int *indices, int n_rows,
 /* ---------------------------------------------------------------- GraphSum */
 /* src/seq/module.cpp:83-101 (forward) and :103-119 (backward): the same
  * row-gather.  coef: int product of the two row lengths -> float for sqrtf,
- * "1.0 / x" divides in double, the result narrows to float. */
+ * "1.0 / x" divides in double, the result narrows to float.
+ *
+ * WIDE-DEGREE VARIANT (or_set_wide_degree(1); off by default).  The reference multiplies the two row lengths as `int`
+ * (module.cpp:91-93): undefined behaviour once the product reaches 2^31, i.e. for a node of degree > 46 340 (its own self
+ * loop already: R-MAT scale 20 has a hub of degree 64 619, whose product wraps negative and turns the hub's row into NaN).
+ * SURVEY App. C records the fix the HIP path makes: the product in 64 bits.  With the variant on, the product is formed as
+ * `long` and converted to float exactly as the int product would be — int -> float and long -> float round the same way,
+ * so every coefficient whose product stays below 2^31 is bit-identical (tests/test_oracle_pin.py proves it against
+ * oracle/_ref on every fixture) and only the overflowing ones differ. */
+static int g_wide_degree = 0;
+void or_set_wide_degree(int on) { g_wide_degree = on ? 1 : 0; }
+int or_get_wide_degree(void) { return g_wide_degree; }
+
+static inline float gs_coef(const int *indptr, int src, int dst) {
+    const int a = indptr[src + 1] - indptr[src], b = indptr[dst + 1] - indptr[dst];
+    if (g_wide_degree) return (float)(1.0 / (double)sqrtf((float)((long)a * (long)b)));
+    return (float)(1.0 / (double)sqrtf((float)(a * b)));
+}
+
+/* number of stored edges whose int degree product is not representable (>= 2^31): 0 means or_graphsum is the
+ * reference's defined behaviour on this graph and the two variants agree bit for bit */
+long or_graphsum_overflowing_edges(const int *indptr, const int *indices, int n_rows) {
+    long n = 0;
+    for (int src = 0; src < n_rows; src++)
+        for (int e = indptr[src]; e < indptr[src + 1]; e++) {
+            const int dst = indices[e];
+            if ((long)(indptr[src + 1] - indptr[src]) * (long)(indptr[dst + 1] - indptr[dst]) >= 2147483648L) n++;
+        }
+    return n;
+}
+
 void or_graphsum(const int *indptr, const int *indices, int n_rows,
                  const float *in, float *out, int dim) {
     for (long i = 0; i < (long)n_rows * dim; i++) out[i] = 0;
     for (int src = 0; src < n_rows; src++)
         for (int e = indptr[src]; e < indptr[src + 1]; e++) {
             const int dst = indices[e];
-            const float coef = (float)(1.0 / (double)sqrtf((float)(
-                (indptr[src + 1] - indptr[src]) * (indptr[dst + 1] - indptr[dst]))));
+            const float coef = gs_coef(indptr, src, dst);
             for (int j = 0; j < dim; j++)
                 out[(long)src * dim + j] += coef * in[(long)dst * dim + j];
         }
@@ -172,8 +201,7 @@ int or_graphsum_rows(const int *indptr, const int *indices, const int *rows, int
             const int dst = indices[e];
             const long wide = (long)(indptr[src + 1] - indptr[src]) * (long)(indptr[dst + 1] - indptr[dst]);
             if (wide >= 2147483648L) bad = 1;
-            const float coef = (float)(1.0 / (double)sqrtf((float)(
-                (indptr[src + 1] - indptr[src]) * (indptr[dst + 1] - indptr[dst]))));
+            const float coef = gs_coef(indptr, src, dst);
             for (int j = 0; j < dim; j++)
                 out[(long)k * dim + j] += coef * in[(long)dst * dim + j];
         }

@@ -51,6 +51,11 @@ void or_spmm_bwd(const int *indptr, const int *indices, int n_rows,
 /* GraphSum forward and backward are the same operator        module.cpp:83-119 */
 void or_graphsum(const int *indptr, const int *indices, int n_rows,
                  const float *in, float *out, int dim);
+/* wide-degree variant of the coefficient (64-bit degree product instead of module.cpp:92's int product):
+ * process-wide switch, off by default; bit-identical wherever no product reaches 2^31 */
+void or_set_wide_degree(int on);
+int  or_get_wide_degree(void);
+long or_graphsum_overflowing_edges(const int *indptr, const int *indices, int n_rows);
 /* the same operator for a subset of source rows (out[k,:] = row rows[k]); returns how many of the
  * selected rows contain an edge whose `int` degree product (module.cpp:91-93) would overflow */
 int or_graphsum_rows(const int *indptr, const int *indices, const int *rows, int n_sel,

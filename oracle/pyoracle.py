@@ -135,6 +135,17 @@ class Oracle:
         self.lib.or_graphsum(indptr.ctypes, indices.ctypes, n_rows, x.ctypes, out.ctypes, dim)
         return out.reshape(n_rows, dim)
 
+    def set_wide_degree(self, on: bool):
+        """64-bit degree product in GraphSum's coefficient (the documented divergence from module.cpp:92, SURVEY App. C);
+        process-wide, off by default.  Bit-identical to the int product wherever that is defined."""
+        self.lib.or_set_wide_degree(int(bool(on)))
+
+    def overflowing_edges(self, indptr, indices):
+        """stored edges whose int degree product (module.cpp:92) is >= 2^31"""
+        indptr, indices = _i(indptr), _i(indices)
+        self.lib.or_graphsum_overflowing_edges.restype = C.c_long
+        return int(self.lib.or_graphsum_overflowing_edges(indptr.ctypes, indices.ctypes, int(indptr.size - 1)))
+
     def graphsum_rows(self, indptr, indices, rows, x, dim):
         """rows `rows` of graphsum(indptr, indices, x) -> (out [len(rows), dim], n rows with an overflowing int degree product)"""
         indptr, indices, rows, x = _i(indptr), _i(indices), _i(rows), _f(x)

@@ -100,6 +100,58 @@ def test_rmat_shaped_model_trace_vs_oracle(oracle):
     m.close(); om.close()
 
 
+def test_rmat_model_trace_vs_wide_oracle(oracle):
+    """BASELINE configs[4]'s family WITH a hub whose int degree product overflows: R-MAT scale 20 (1 048 576 nodes, 32.5 M
+    stored edges; the top hub has degree 64 619 > 46 340, so module.cpp:92's int product of its own self loop is undefined —
+    the reference's arithmetic wraps it negative and the hub's row becomes NaN).  The HIP path forms the product in 64 bits
+    (SURVEY App. C); the oracle's wide-degree variant does the same and is pinned bit-for-bit to the reference wherever the
+    int product is defined (tests/test_oracle_pin.py).  Model 32 -> 64 -> 41 (the aggregation is what the hubs exercise —
+    64 columns are one XCD-sliced launch of the hidden-width kernel; the narrow widths keep the CPU side of the test at
+    ~20 s per epoch), 2 epochs + the test split with the reference's dropout decisions replayed.
+
+    What is compared.  Accuracies and the validation / test losses (10 K rows): the oracle's own numbers, at the usual
+    tolerances.  The TRAINING loss is a mean over 1.03 M rows, which the reference accumulates sequentially in one float
+    (module.cpp:144,154): at this count that sum carries ~1e-3 of rounding of its own (measured: +9e-4 at scale 19, +3.7e-3
+    at scale 20 against the float64 mean of the SAME logits; the HIP path adds block partials and stays at 1e-6).  So the
+    training loss is checked against the float64 mean of the ORACLE's logits (+ the L2 term of the weights the forward
+    used), and the training logits themselves element by element."""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+    scale = int(os.environ.get("RMAT_WIDE_SCALE", "20"))
+    ds = datagen.make_dataset(f"rmat-{scale}-32")
+    gp, gi, N = ds["g_indptr"], ds["g_indices"], ds["num_nodes"]
+    assert int(np.diff(gp).max()) > 46340 and oracle.overflowing_edges(gp, gi) >= 1, "no overflowing degree product: the wide variant would not be exercised"
+    truth = np.where(ds["split"] == 1, ds["label"], -1)
+    rows = np.nonzero(truth >= 0)[0]
+
+    def f64_mean_loss(Z):
+        Zr = Z[rows].astype(np.float64)
+        Zr -= Zr.max(1, keepdims=True)
+        return float((np.log(np.exp(Zr).sum(1)) - Zr[np.arange(rows.size), truth[rows]]).mean())
+    oracle.set_wide_degree(True)
+    try:
+        om = oracle.model(ds, seed_time=4, hidden_dim=64, dropout=0.5)
+        m = HipGCNModel(ds, seed=4, flags=HOST_MASKS, hidden_dim=64, dropout=0.5, epochs=2)
+        n_tr, n_va = int((ds["split"] == 1).sum()), int((ds["split"] == 2).sum())
+        for e in range(2):
+            l2 = 5e-4 * float((om.var(2).astype(np.float64) ** 2).sum()) / 2        # gcn.cpp:98-105, the weights this forward uses
+            got_t, want_t = m.train_epoch(), om.train_epoch()
+            Zg, Zo = m.var_reference(6), om.var(6).reshape(N, -1)
+            want_loss = f64_mean_loss(Zo) + l2
+            assert np.isfinite(want_t).all() and np.isfinite(got_t).all(), (e, got_t, want_t)
+            assert abs(got_t[0] - want_loss) <= 2e-4, (e, got_t, want_loss, want_t)
+            assert abs(want_t[0] - want_loss) <= 2e-2, (e, want_t, want_loss)           # the reference's own float accumulation: loose
+            assert abs(got_t[1] - want_t[1]) <= 2.0 / n_tr, (e, got_t, want_t)
+            Zg_s, Zo_s = Zg[rows] - Zg[rows].max(1, keepdims=True), Zo[rows] - Zo[rows].max(1, keepdims=True)
+            assert np.abs(Zg_s - Zo_s).max() <= 1e-3 * max(1.0, float(np.abs(Zo_s).max())), (e, float(np.abs(Zg_s - Zo_s).max()))
+            got_v, want_v = m.eval(2), om.eval(2)
+            assert abs(got_v[0] - want_v[0]) <= 2e-4 and abs(got_v[1] - want_v[1]) <= 2.0 / n_va, (e, got_v, want_v)
+        gt, wt = m.eval(3), om.eval(3)
+        assert abs(gt[0] - wt[0]) <= 2e-4, (gt, wt)
+        m.close(); om.close()
+    finally:
+        oracle.set_wide_degree(False)
+
+
 @pytest.mark.parametrize("name,seed,dropout", [("cora-syn", 1, 0.0), ("cora-syn", 2, 0.5), ("citeseer-syn", 1, 0.0),
                                                ("pubmed-syn", 1, 0.5), ("tiny-syn", 3, 0.5)])
 def test_trace_vs_reference_golden(name, seed, dropout):

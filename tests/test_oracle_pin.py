@@ -207,3 +207,60 @@ def test_live_parser_vs_reference(oracle, ref):
         b = ref.parse(td, "t")
     for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
         eq(a[k], b[k])
+
+
+# ------------------------------------------------- the wide-degree variant (64-bit degree product)
+@pytest.fixture
+def wide(oracle):
+    """the oracle with GraphSum's degree product formed in 64 bits (or_set_wide_degree) for the duration of a test"""
+    oracle.set_wide_degree(True)
+    yield oracle
+    oracle.set_wide_degree(False)
+
+
+@pytest.mark.parametrize("g", ["karate", "tiny", "ragged"])
+@pytest.mark.parametrize("dim", [1, 7, 16, 41])
+def test_wide_degree_graphsum_golden(wide, mods, g, dim):
+    """no degree product of the fixtures reaches 2^31: the variant must reproduce the reference's tensors bit for bit"""
+    assert wide.overflowing_edges(mods[f"gs_{g}_indptr"], mods[f"gs_{g}_indices"]) == 0
+    test_graphsum_golden(wide, mods, g, dim)
+
+
+@pytest.mark.parametrize("name,seeds,epochs", [("tiny-syn", (1, 2), 100), ("cora-syn", (1,), 100), ("pubmed-syn", (1,), 20)])
+def test_wide_degree_trace_golden(wide, traces, name, seeds, epochs):
+    """... and the reference-generated 100-epoch traces, weights included"""
+    test_trace_golden(wide, traces, name, seeds, epochs)
+
+
+def test_wide_degree_live_vs_reference(wide, ref):
+    test_live_modules_vs_reference(wide, ref)
+    test_live_model_vs_reference(wide, ref)
+
+
+def test_wide_degree_differs_only_where_the_int_product_overflows(oracle):
+    """a star whose hub has degree 50 001 (> 46 340): the hub's self-loop product 50 001^2 does not fit an int (module.cpp:92
+    is undefined there, so the int form is NOT executed); the wide form gives 1/sqrtf((float)product) for every edge"""
+    n = 50001
+    gp = np.concatenate([[0, n], n + 2 * np.arange(1, n)]).astype(np.int32)          # hub row: itself + every leaf; leaf rows: itself + hub
+    gi = np.empty(gp[-1], np.int32)
+    gi[:n] = np.arange(n)
+    gi[n::2] = np.arange(1, n)
+    gi[n + 1::2] = 0
+    assert oracle.overflowing_edges(gp, gi) == 1
+    x = np.random.default_rng(3).standard_normal((n, 2)).astype(np.float32)
+    oracle.set_wide_degree(True)
+    try:
+        got = oracle.graphsum(gp, gi, x, 2)
+    finally:
+        oracle.set_wide_degree(False)
+    deg = np.diff(gp).astype(np.int64)
+
+    def coef(a, b):
+        return np.float32(1.0 / np.float64(np.sqrt(np.float32(deg[a] * deg[b]))))
+    want_leaf = coef(1, 1) * x[1] + coef(1, 0) * x[0]                                   # row 1: self first, then the hub
+    assert np.array_equal(got[1], want_leaf.astype(np.float32))
+    acc = np.zeros(2, np.float32)
+    for j in range(n):                                                                  # the hub's row, in CSR order, f32 accumulation
+        acc = (acc + coef(0, j) * x[j]).astype(np.float32)
+    assert np.array_equal(got[0], acc)
+    assert np.isfinite(got).all()

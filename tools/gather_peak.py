@@ -41,9 +41,25 @@ def load_lib():
     return lib
 
 
-def product_order(ds, group_major=True):
+def schedule_key(ds, schedule):
+    """the row-group key csrc/ctx.hip sorts the task list by (gcnhip_graph_set_schedule): labels, nothing, or degree rank dealt
+    into G groups"""
+    n = ds["num_nodes"]
+    deg = np.diff(ds["g_indptr"].astype(np.int64))
+    if schedule == "label-major":
+        return ds["label"].astype(np.int64)
+    if schedule.startswith("dealt-"):
+        G = int(schedule.split("-")[1])
+        order = np.argsort(-deg, kind="stable")
+        key = np.empty(n, np.int64)
+        key[order] = np.arange(n) % G
+        return key
+    return np.zeros(n, np.int64)
+
+
+def product_order(ds, group_major=True, key=None):
     """the task list and index array as csrc/ctx.hip builds them: neighbours of a row by descending degree (stable),
-    rows by (label, descending degree) when group_major else by descending degree; rows above 1024 edges in 1024-edge segments"""
+    rows by (group key, descending degree) — key = label when group_major, else none; rows above 1024 edges in 1024-edge segments"""
     gp, gi = ds["g_indptr"].astype(np.int64), ds["g_indices"]
     n = gp.size - 1
     deg = np.diff(gp)
@@ -51,7 +67,8 @@ def product_order(ds, group_major=True):
     # per row: neighbours sorted by (-degree, id) — std::sort of pairs (-deg, id) in graph_create_impl
     order = np.lexsort((gi, -deg[gi], row_of))
     idx = gi[order].astype(np.int32)
-    key = ds["label"].astype(np.int64) if group_major else np.zeros(n, np.int64)
+    if key is None:
+        key = ds["label"].astype(np.int64) if group_major else np.zeros(n, np.int64)
     rows = np.lexsort((np.arange(n), -deg, key))                 # stable: (key asc, degree desc)
     e0, e1, tr = [], [], []
     for r in rows.tolist():
@@ -71,6 +88,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--best-only", action="store_true", help="only the best configuration of each stream (for a PMC pass)")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--schedule", default="label-major", help="row schedule of the product's own stream: label-major | degree | dealt-<G> (what HipGCN picked for this graph)")
     ap.add_argument("--coef", action="store_true", help="also time the gather with a coefficient stream (separate array / interleaved pairs)")
     a = ap.parse_args()
     lib = load_lib()
@@ -78,14 +96,20 @@ def main():
     ds = datagen.make_dataset(a.dataset)
     n = ds["num_nodes"]
     nnz = int(ds["g_indices"].size)
-    e0, e1, tr, idx = product_order(ds, True)
+    e0, e1, tr, idx = product_order(ds, key=schedule_key(ds, a.schedule))
     print(f"[gather_peak] {a.dataset}: {n} rows, {nnz} stored edges, {e0.size} tasks; host preparation {time.time() - t0:.1f} s", flush=True)
     rng = np.random.default_rng(1)
-    streams = {"own index stream, label-major row order (the product's schedule)": (e0, e1, tr, idx),
-               "own index stream, descending-degree row order": product_order(ds, False),
-               "uniformly random rows, same row lengths": (e0, e1, tr, rng.integers(0, n, nnz).astype(np.int32))}
+    own = f"own index stream, {a.schedule} row order (the product's schedule)"
+    streams = {own: (e0, e1, tr, idx)}
+    if a.schedule != "degree":
+        streams["own index stream, descending-degree row order"] = product_order(ds, False)
+    streams["uniformly random rows, same row lengths"] = (e0, e1, tr, rng.integers(0, n, nnz).astype(np.int32))
     tables = [("d=128 (ld 128, 256-byte slices on XCD pairs)", 128, 128), ("d=41 (ld 48)", 48, 41)]
-    doc = {"dataset": a.dataset, "rows": n, "stored_edges": nnz, "tasks": int(e0.size),
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
+    except Exception:
+        commit = None
+    doc = {"dataset": a.dataset, "rows": n, "stored_edges": nnz, "tasks": int(e0.size), "schedule": a.schedule, "_meta": {"commit": commit},
            "kernel": "tools/gather_peak.hip: gather + sum only (no coefficient stream, no multiply, no epilogue); one wave per task, XCD-sliced like graphsum_vec_kernel",
            "unit": "GB/s of gathered row bytes = 4 * dim * edges / avg launch time", "results": []}
     sweeps_u = (4,) if a.best_only else ((2, 4) if a.quick else (1, 2, 4, 8))
@@ -112,7 +136,7 @@ def main():
                         if best is None or gbps > best["GBps"]:
                             best = r
             doc.setdefault("best", []).append(best)
-            if a.coef and sname.startswith("own index stream, label-major"):
+            if a.coef and sname == own:
                 # what the product's coefficient stream costs on top of the pure gather, and whether interleaving it with the
                 # indices (one 8-byte load per lane instead of two 4-byte loads) gets that back
                 for mode, label in ((0, "no coefficients"), (1, "coefficients from their own array"), (2, "(index, coefficient) pairs, one array")):
@@ -122,7 +146,7 @@ def main():
                     print(f"[gather_peak] coefficient stream, {tname[:6]}: {label}: {ms.value:.3f} ms", flush=True)
         lib.gp_destroy(h)
     # the ceilings bench.py uses: the product's own stream and schedule, best configuration, per table
-    doc["ceiling_GBps"] = {b["table"].split(" ")[0]: b["GBps"] for b in doc["best"] if b["stream"].startswith("own index stream, label-major")}
+    doc["ceiling_GBps"] = {b["table"].split(" ")[0]: b["GBps"] for b in doc["best"] if b["stream"] == own}
     doc["ceiling_uniform_random_GBps"] = {b["table"].split(" ")[0]: b["GBps"] for b in doc["best"] if b["stream"].startswith("uniformly")}
     txt = json.dumps(doc, indent=1)
     if a.out:

@@ -1,0 +1,164 @@
+// gemm_bf16x3.hip — pricing of the three-plane bf16 form of the dense first-layer products (csrc/dense_bf16x3.h) beside the
+// exact-f32 MFMA kernels the product has run since round 3 (csrc/dense_persist.h), at the benchmark's shape
+// (m = 232 965, K = 602, p = 128; reference: SparseMatmul::forward, /root/reference/src/seq/module.cpp:47-61):
+// time per launch (HIP events, back to back) and the error of both against a float64 product on sampled rows, in units of
+// eps_f32 * sum_k |x_k w_k| (the bound the parity tests use is 8 of those units).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icuda_gcn_amd/csrc tools/gemm_bf16x3.hip -o build/gemm_bf16x3
+//   build/gemm_bf16x3 [m] [K] [iters]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <random>
+#include <vector>
+#include "dense_bf16x3.h"
+
+int gcnhip_fail(const char *d) { fprintf(stderr, "%s\n", d ? d : ""); return -1; }
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s at line %d\n", hipGetErrorString(_e), __LINE__); return 1; } } while (0)
+
+template <class F>
+static float time_ms(int iters, F f) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) f();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; i++) f();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / iters;
+}
+
+// does global_load_lds_dwordx3 lay the wave's 64 x 12 bytes out contiguously (lane * 12) from the M0 base?
+__global__ void glds12_probe(const uint32_t *src, uint32_t *dst) {
+    __shared__ __attribute__((aligned(1024))) uint32_t buf[512];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 512; i += 64) buf[i] = 0xDEADBEEFu;
+    __syncthreads();
+    {
+        uint32_t keep;
+        const void *gsrc = reinterpret_cast<const unsigned char *>(src) + lane * 12;
+        const uint32_t lds_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)buf;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = lane; i < 512; i += 64) dst[i] = buf[i];
+}
+
+int main(int argc, char **argv) {
+    const int m = argc > 1 ? atoi(argv[1]) : 232965, K = argc > 2 ? atoi(argv[2]) : 602, iters = argc > 3 ? atoi(argv[3]) : 20;
+    const int p = 128, ldx = (K + 31) / 32 * 32, n_chunks = ldx / 32, n_rb = (m + 31) / 32;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    printf("m=%d K=%d (ldx %d) p=%d  CUs=%d  %.2f GFLOP per product\n", m, K, ldx, p, n_cu, 2.0 * m * K * p / 1e9);
+    {
+        uint32_t *ps, *pd;
+        std::vector<uint32_t> h(512), o(512);
+        for (int i = 0; i < 512; i++) h[i] = i;
+        CK(hipMalloc(&ps, 2048)); CK(hipMalloc(&pd, 2048));
+        CK(hipMemcpy(ps, h.data(), 2048, hipMemcpyHostToDevice));
+        glds12_probe<<<1, 64>>>(ps, pd);
+        CK(hipMemcpy(o.data(), pd, 2048, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < 192; i++) bad += o[i] != (uint32_t)i;
+        printf("global_load_lds_dwordx3 probe: %d of 192 dwords differ from the lane*12 layout; dwords 0..7 = %u %u %u %u %u %u %u %u; dword 192 = %x\n", bad,
+               o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[192]);
+    }
+    std::vector<float> hx((size_t)m * ldx, 0.f), hw((size_t)K * p);
+    std::mt19937_64 rng(7);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (int i = 0; i < m; i++) for (int k = 0; k < K; k++) hx[(size_t)i * ldx + k] = nd(rng);
+    const float wscale = sqrtf(6.f / (K + p));
+    std::uniform_real_distribution<float> ud(-wscale, wscale);
+    for (auto &v : hw) v = ud(rng);
+    std::vector<uint32_t> hbits(((size_t)m * K + 31) / 32 + 8);
+    for (auto &v : hbits) v = (uint32_t)rng();
+    float *dx, *dw, *dout, *dout2, *dwp32;
+    uint4 *dwp;
+    uint32_t *dbits;
+    CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&dw, hw.size() * 4));
+    CK(hipMalloc(&dout, (size_t)m * p * 4)); CK(hipMalloc(&dout2, (size_t)m * p * 4));
+    CK(hipMalloc(&dwp, (size_t)n_chunks * 2 * BX_BH_BYTES)); CK(hipMalloc(&dwp32, (size_t)n_chunks * 4 * 1024 * 4));
+    CK(hipMalloc(&dbits, hbits.size() * 4));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbits, hbits.data(), hbits.size() * 4, hipMemcpyHostToDevice));
+
+    // sampled rows for the error check
+    std::vector<int> rows;
+    for (int i = 0; i < 96; i++) rows.push_back((int)((uint64_t)i * 2654435761u % (uint64_t)m));
+    rows.push_back(0); rows.push_back(m - 1); rows.push_back(m - 33); rows.push_back(std::min(m - 1, 255)); rows.push_back(std::min(m - 1, 256));
+    auto check = [&](const float *d_out, const char *what, bool drop, float scale) {
+        std::vector<float> ho((size_t)m * p);
+        hipMemcpy(ho.data(), d_out, ho.size() * 4, hipMemcpyDeviceToHost);
+        double worst = 0, sumsq = 0; long cnt = 0;
+        long nonfinite = 0; int first_bad = -1;
+        for (size_t i = 0; i < ho.size(); i++) if (!std::isfinite(ho[i])) { nonfinite++; if (first_bad < 0) first_bad = (int)(i / p); }
+        if (nonfinite) printf("  !! %ld non-finite outputs, first in row %d\n", nonfinite, first_bad);
+        for (int r : rows) for (int c = 0; c < p; c++) {
+            double ref = 0, mag = 0;
+            for (int k = 0; k < K; k++) {
+                const size_t e = (size_t)r * K + k;
+                const bool keep = !drop || ((hbits[e >> 5] >> (e & 31)) & 1);
+                const double t = keep ? (double)hx[(size_t)r * ldx + k] * (double)(hw[(size_t)k * p + c] * scale) : 0.0;
+                ref += t; mag += fabs(t);
+            }
+            const double u = fabs((double)ho[(size_t)r * p + c] - ref) / (1.1920929e-7 * (mag > 0 ? mag : 1));
+            worst = std::max(worst, u); sumsq += u * u; cnt++;
+        }
+        printf("  %-44s error vs float64: max %.4f, rms %.4f  (units of eps_f32 * sum|x w|; parity bound 8)\n", what, worst, sqrt(sumsq / cnt));
+        return worst;
+    };
+
+    // ---- exact-f32 MFMA, persistent LDS-DMA kernel (the product's default since round 3)
+    {
+        const int n_kg = n_chunks * 4;
+        PersistFwdArgs a{dx, ldx, dwp32, dout2, p, m, K, n_chunks, n_rb, nullptr, 0, 0};
+        for (int drop = 0; drop < 2; drop++) {
+            a.bits = drop ? dbits : nullptr;
+            const float scale = drop ? 2.f : 1.f;
+            auto run = [&]() {
+                pg_pack_w_kernel<<<(n_kg * 256 + 255) / 256, 256>>>(dw, p, K, n_kg, dwp32, scale);
+                if (drop) dense_fwd_persist_kernel<true><<<n_cu, 512>>>(a); else dense_fwd_persist_kernel<false><<<n_cu, 512>>>(a);
+            };
+            const float ms = time_ms(iters, run);
+            CK(hipGetLastError());
+            printf("f32 MFMA persistent forward, dropout %d:      %.4f ms  %.1f TF/s\n", drop, ms, 2.0 * m * K * p / ms / 1e9);
+            check(dout2, "f32 MFMA (k-ordered fmaf chain)", drop, scale);
+        }
+    }
+    // ---- three bf16 planes
+    {
+        Bx3FwdArgs a{dx, ldx, dwp, dout, p, m, K, n_chunks, n_rb, nullptr, 0};
+        // where the time goes: each ablation drops one cost (results wrong): 1 no X loads, 2 no W DMA, 4 no split, 8 no W LDS reads
+        printf("  ablation  1 (no X loads):     %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 1><<<n_cu, 512>>>(a); }));
+        printf("  ablation  2 (no W DMA):       %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 2><<<n_cu, 512>>>(a); }));
+        printf("  ablation  4 (no split):       %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 4><<<n_cu, 512>>>(a); }));
+        printf("  ablation  8 (no W LDS reads): %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 8><<<n_cu, 512>>>(a); }));
+        printf("  ablation 15 (all of them):    %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 15><<<n_cu, 512>>>(a); }));
+        for (int np = 6; np <= 8; np += 2)
+            for (int drop = 0; drop < 2; drop++) {
+                a.bits = drop ? dbits : nullptr;
+                const float scale = drop ? 2.f : 1.f;
+                auto run = [&]() {
+                    bx_pack_w_kernel<<<(n_chunks * 512 + 255) / 256, 256>>>(dw, p, K, 2 * n_chunks, dwp, scale);
+                    if (np == 6) { if (drop) dense_fwd_bf16x3_kernel<true, 6><<<n_cu, 512>>>(a); else dense_fwd_bf16x3_kernel<false, 6><<<n_cu, 512>>>(a); }
+                    else { if (drop) dense_fwd_bf16x3_kernel<true, 8><<<n_cu, 512>>>(a); else dense_fwd_bf16x3_kernel<false, 8><<<n_cu, 512>>>(a); }
+                };
+                CK(hipMemset(dout, 0xFF, (size_t)m * p * 4));
+                const float ms = time_ms(iters, run);
+                CK(hipGetLastError());
+                printf("bf16x3 forward, %d plane products, dropout %d: %.4f ms  %.1f TF/s algorithmic, %.0f TF/s of bf16 MFMA issued\n", np, drop, ms,
+                       2.0 * m * K * p / ms / 1e9, np * 2.0 * m * ldx * p / ms / 1e9);
+                char what[64];
+                snprintf(what, sizeof what, "bf16x3, %d plane products", np);
+                check(dout, what, drop, scale);
+            }
+    }
+    return 0;
+}
