@@ -56,7 +56,7 @@ PMC_FILES = ["r05_graphsum_pmc.json", "r04_graphsum_pmc.json", "r03_graphsum_pmc
 PMC_RMAT_FILES = ["r05_graphsum_pmc_rmat.json", "r04_graphsum_pmc_rmat.json", "r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
 PMC_RMAT22_FILES = ["r04_graphsum_pmc_rmat22.json"]                      # the in-model launch of BASELINE configs[4] (scale 22, 2 GiB table)
 GATHER_PEAK_FILES = ["r05_gather_peak.json", "r04_gather_peak.json"]     # measured ceiling of the cache-regime gather (tools/gather_peak.py)
-GEMM_PMC_FILES = ["r05_gemm_pmc.json"]                                   # SQ_VALU_MFMA_BUSY_CYCLES etc. of the dense first-layer kernels (tools/pmc_gemm.sh)
+GEMM_PMC_FILES = ["r05_gemm_bf16x3_pmc.json", "r05_gemm_pmc.json"]                                   # SQ_VALU_MFMA_BUSY_CYCLES etc. of the dense first-layer kernels (tools/pmc_gemm.sh)
 STRUCTURE_LEGS = [("value_structure_free", "reddit-syn-h0"), ("value_h03", "reddit-syn-h03"), ("value_zipf", "reddit-syn-zipf")]
 GS_KERNEL = "graphsum_vec_kernel<16, 4, true, false>"       # the hidden-width launch on a cache-resident table (graphsum.hip, launch_vec)
 GS_KERNEL_HBM = "graphsum_vec_kernel<16, 2, true, false>"   # ... past the Infinity Cache (two row loads in flight)
@@ -430,7 +430,7 @@ def dense_leg(ds, hidden, device, iters=10):
         _ck(lib, lib.gcnhip_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
         return ms.value / iters
     v = C.c_int(0)
-    method = "bf16x3" if (lib.gcnhip_ctx_get_option(dev.ctx, b"gemm_bf16x3", C.byref(v)) == 0 and v.value == 1) else "f32"
+    method = "bf16x3" if (lib.gcnhip_ctx_get_option(dev.ctx, b"gemm_bf16x3", C.byref(v)) == 0 and v.value >= 1) else "f32"
     peak = BF16_MFMA_PEAK_TF if method == "bf16x3" else F32_MFMA_PEAK_TF
     flop = 2.0 * N * F * hidden
     # MFMA work per launch: the exact-f32 kernels issue one f32 MFMA flop per algorithmic flop; the bf16x3 kernels issue 6 bf16
@@ -567,6 +567,7 @@ def main():
     model, t_build = build(base_flags | (NO_ROW_GROUPS if args.no_row_groups else 0))
     info = model.info()
     exchange = model.exchange() if world > 1 else None
+    transport = model.transport() if world > 1 else None
     model.run_epochs(args.warmup, want_trace=False)
     dt, trace = timed_region(model, args.steps)      # <- the headline: default product path, per-op timers off
     burst_eps = [args.steps / dt]
@@ -619,10 +620,13 @@ def main():
         s_b, n_b = model.timer("graphsum_bw")
         s_wide, n_wide = s_f + s_b, n_f + n_b
     breakdown = {}
+    comm_calls = 0
     for name in ("spmatmul_fw", "spmatmul_bw", "graphsum_fw", "graphsum_bw", "matmul_fw", "matmul_bw", "loss_fw", "adam", "comm"):
         s, n = model.timer(name)
         if n:
             breakdown[name] = round(1e3 * s / n_tm, 4)      # ms per epoch
+        if name == "comm":
+            comm_calls = n                                  # exchanges + all-reduces timed with device events on the stream they run on
     model.set_timers(False)
     # train-only epochs (no validation forward; one host read-back per epoch), outside the timed region
     n_tr = min(args.steps, 20)
@@ -633,6 +637,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     train_only_ms = 1e3 * (time.perf_counter() - t1) / n_tr
     schedule = model.schedule()
+    slice_floats = model.slice_floats()
     model.close()
 
     out = None
@@ -718,6 +723,8 @@ def main():
             # device time is not all exposed
             comm_ms = breakdown.get("comm", 0.0)
             roof.update({"comm_ms_per_epoch": comm_ms, "comm_share_of_timers_pass": comm_ms / max(1e3 * dt_tm / n_tm, 1e-9),
+                         "collectives_per_epoch": comm_calls / max(n_tm, 1),
+                         "comm_us_per_collective": 1e3 * comm_ms / max(comm_calls / max(n_tm, 1), 1e-9),
                          "per_rank": "rank 0's launches on its row block"})
         n_lab = int((ds["split"] == 1).sum())
         out = {
@@ -730,12 +737,14 @@ def main():
                                    "step = train_epoch + eval(val)" + structure_note(ds),
                        "graph_structure": graph_structure(ds),
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
-                       "train_nodes": n_lab, "aggregation_schedule": schedule,
+                       "train_nodes": n_lab, "aggregation_schedule": schedule, "aggregation_slice_floats": slice_floats,
                        "eval_lane": "on" if lane_on else "off",
                        "overlap_exchange": "on" if overlap_on else "off",
                        "schedule": ("plain one-stream" if not (lane_on or overlap_on) else
                                     " + ".join(x for x in ["exchange overlap" if overlap_on else "", "validation lane" if lane_on else ""] if x)),
                        "exchange": exchange,       # rank 0's view: all-gather of row blocks or halo lists, rows moved per exchange
+                       "transport": transport[0] if transport else None,
+                       "rccl_ranks": transport[1] if (transport and transport[0] == "rccl") else None,     # ncclCommCount of the model's communicator
                        "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
                                        "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",
                        "logit_rows": "all" if os.environ.get("HIPGCN_ALL_ROWS") else "rows of the scored split only"},
@@ -799,6 +808,7 @@ def main():
                 m2.set_timers(False)
                 inf2 = m2.info()
                 legs[name] = {"epochs_per_s": args.steps / dd, "ms_per_epoch": 1e3 * dd / args.steps, "aggregation_schedule": m2.schedule(),
+                              "aggregation_slice_floats": m2.slice_floats(),
                               "hidden_width_launch_ms": 1e3 * sw / max(nw, 1),
                               "hidden_width_gathered_GBps": 4.0 * inf2["local_edges"] * args.hidden / (sw / max(nw, 1)) / 1e9,
                               "graph_structure": graph_structure(d2), "final_val_acc": float(tr2[-1, 3]),
@@ -806,7 +816,7 @@ def main():
                 out[key] = args.steps / dd
                 m2.close()
                 del d2
-                log(f"{name}: {args.steps / dd:.2f} epochs/s, schedule {legs[name]['aggregation_schedule']}, hidden-width launch {legs[name]['hidden_width_launch_ms']:.3f} ms")
+                log(f"{name}: {args.steps / dd:.2f} epochs/s, schedule {legs[name]['aggregation_schedule']} / {legs[name]['aggregation_slice_floats']}-float slices, hidden-width launch {legs[name]['hidden_width_launch_ms']:.3f} ms")
             except Exception as e:      # an extra: report its failure, keep the headline
                 legs[name] = {"error": repr(e)}
                 out[key] = None

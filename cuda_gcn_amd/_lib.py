@@ -197,6 +197,8 @@ GCNHOST_SYMBOLS = {
     "gcnhost_model_sync": (I, [P]),
     "gcnhost_model_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I64)]),
     "gcnhost_model_schedule": (I, [P, C.POINTER(I), C.POINTER(I)]),
+    "gcnhost_model_slice_floats": (I, [P, C.POINTER(I)]),
+    "gcnhost_model_transport": (I, [P, C.POINTER(I), C.c_char_p]),
     "gcnhost_model_row_ids": (I, [P, P, C.POINTER(I)]),
     "gcnhost_model_row_scale": (I, [P, P, C.POINTER(I)]),
     "gcnhost_model_get_var": (I, [P, I, I, P, C.POINTER(I), C.POINTER(I)]),

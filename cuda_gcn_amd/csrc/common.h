@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/gcnhip.h"
+#include "../../include/gcnhip_experimental.h"
 
 #define GCNHIP_TRY(expr)                                   \
     do {                                                   \
@@ -30,6 +31,8 @@ struct GcnOptions {
     int gs_fold;            // 1: split rows are summed inside the aggregation launch (same bits; no faster)
     int gs_l;               // 8 / 4: column slices of 32 / 16 floats in the XCD-sliced aggregation (default 0: 64 floats)
     int gemm_tiles;         // 1: first-layer forward by the tile kernels instead of the persistent form
+    int gemm_bf16x3;        // dense first-layer products (p = 128) from three bf16 planes on the bf16 MFMA pipe: 2 (default) on, also on a
+                            // co-running stream; 1 on, the co-running stream keeps the f32 tiles; 0 off: the exact-f32 MFMA kernels
     int gemm_w4;            // 1: four-wave forward tiles
     int gemm_persist_bwd;   // 1: persistent first-layer weight gradient (measured slower)
     int dbg_linear;         // timing experiment only: the persistent forward reads X as if tile-major (wrong results)

@@ -20,7 +20,7 @@ int gcnhip_fail(const char *detail) {
 
 const GcnOptionEntry GCN_OPTION_TABLE[] = {
     {"gs_pipe", &GcnOptions::gs_pipe, 0}, {"gs_u", &GcnOptions::gs_u, 0}, {"gs_nt", &GcnOptions::gs_nt, 0}, {"gs_fold", &GcnOptions::gs_fold, 0}, {"gs_l", &GcnOptions::gs_l, 0},
-    {"gemm_tiles", &GcnOptions::gemm_tiles, 0}, {"gemm_w4", &GcnOptions::gemm_w4, 0}, {"gemm_persist_bwd", &GcnOptions::gemm_persist_bwd, 0},
+    {"gemm_tiles", &GcnOptions::gemm_tiles, 0}, {"gemm_bf16x3", &GcnOptions::gemm_bf16x3, 2}, {"gemm_w4", &GcnOptions::gemm_w4, 0}, {"gemm_persist_bwd", &GcnOptions::gemm_persist_bwd, 0},
     {"dbg_linear", &GcnOptions::dbg_linear, 0}, {"xent_finalize", &GcnOptions::xent_finalize, 0}, {"xent_wave", &GcnOptions::xent_wave, 0},
     {"adam_sum_launch", &GcnOptions::adam_sum_launch, 0}, {"atb_cap_mb", &GcnOptions::atb_cap_mb, 12}, {"rs_wgs", &GcnOptions::rs_wgs, 0},
     {"spmm_lds", &GcnOptions::spmm_lds, 0}, {"spmm_rows", &GcnOptions::spmm_rows, 0}, {"spmm_general", &GcnOptions::spmm_general, 0}, {"spmm_nw", &GcnOptions::spmm_nw, 0}, {"split_edges", &GcnOptions::split_edges, 0},
@@ -892,7 +892,7 @@ int gcnhip_feat_destroy(gcnhip_ctx *c, gcnhip_feat *f) {
     return 0;
 }
 int gcnhip_feat_is_dense(const gcnhip_feat *f) { return f && f->dense ? 1 : 0; }
-float *gcnhip_feat_values(gcnhip_feat *f) { return f ? f->values : nullptr; }
+const float *gcnhip_feat_values(const gcnhip_feat *f) { return f ? f->values : nullptr; }
 int64_t gcnhip_feat_nnz(const gcnhip_feat *f) { return f ? f->nnz : 0; }
 
 }  // extern "C"

@@ -29,13 +29,22 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BX_BK = 32;                                    // K per chunk of X (two MFMA k-steps of 16 = two half-items)
 constexpr int BX_BH_BYTES = 3 * 4 * 1024;                    // 12288: one k-step of W: [plane][column block][lane] x 16 bytes
-constexpr int BX_NB = 8;                                     // ring of W k-steps in LDS
-constexpr int BX_PD = 4;                                     // ... issued this many half-items ahead of their use
-constexpr int BX_SMEM = BX_NB * BX_BH_BYTES;                 // 98304
+constexpr int BX_NB = 10;                                    // ring of W k-steps in LDS
+constexpr int BX_PD = 6;                                     // ... issued this many half-items ahead of their use
+constexpr int BX_SMEM = BX_NB * BX_BH_BYTES;                 // 122880
 
 // (global_load_lds_dwordx3 is no way to move a 12 KB block in 768-byte pieces: measured on gfx950, tools/gemm_bf16x3.hip's probe,
 // it writes each lane's 12 bytes at LDS base + lane * 16 and leaves the fourth dword of every 16 untouched.  The W k-step
-// therefore travels as twelve 1 KB dwordx4 pieces: waves 0-3 issue two, waves 4-7 one; the counted waits below know.)
+// therefore travels as twelve 1 KB dwordx4 pieces; every wave issues two — waves 4-7 their own and, again, one of pieces 0-3 —
+// so that the counted waits are the same for all.)
+//
+// COUNTED WAITS, and what they may assume (measured, round 5: tools/gemm_bf16x3.hip "beside a co-running kernel").  vmcnt counts
+// this wave's loads, LDS-DMA pieces and stores together, but an LDS-DMA piece served by L2 COMPLETES AHEAD of an older register
+// load still waiting for HBM (and stores complete ahead of loads): "at most N outstanding" says the N youngest of EACH KIND
+// may be outstanding, not the N youngest overall.  A first version counted the younger operations of both kinds together; alone
+// on the chip every load had landed long before its wait and all tests passed — beside a second kernel (the validation lane)
+// the X loads were slow, the wait fell through on the early DMA completions, and rows of garbage came out.  So a wait for an
+// operation of one kind allows only the number of YOUNGER OPERATIONS OF THE SAME KIND: operations of a kind do complete in order.
 
 // two f32 -> their bf16 roundings (one v_cvt_pk_bf16_f32) as a packed word
 __device__ __forceinline__ uint32_t bx_cvt2(float a, float b) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
     const int n_rounds = (nb + 7) >> 3;
     const int n_items = n_rounds * a.n_chunks;                   // chunks of this wave, all rounds
     const int n_hs = 2 * a.n_chunks;
-    const bool two_pieces = wave < 4;                            // pieces of a W k-step this wave issues: 2 (waves 0-3) or 1
+    const int piece2 = wave < 4 ? wave + 8 : wave - 4;           // second DMA piece of this wave (waves 4-7: a duplicate of one of pieces 0-3)
 
     // the X values (and keep words) of chunk (round t, chunk c) of this lane's row
     auto load_raw = [&](BxRaw &r, int t, int c) __attribute__((always_inline)) {
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         const uint32_t dst = lds0 + (hq % BX_NB) * BX_BH_BYTES;
         const uint4 *src = a.wp + (size_t)hs * (BX_BH_BYTES / 16);
         pg_glds16(src + wave * 64 + lane, dst + wave * 1024);
-        if (two_pieces) pg_glds16(src + (wave + 8) * 64 + lane, dst + (wave + 8) * 1024);
+        pg_glds16(src + piece2 * 64 + lane, dst + piece2 * 1024);
     };
 
     f32x16 acc[4];
@@ -269,7 +278,6 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
     BxB3 Bc, Bn;
     read_b(Bc, 0, BxN<0>());
     BX_WAIT_LDS(Bc);
-    int since_store = 1000;                                      // half-items since this wave's last epilogue (its 64 stores sit in the queue)
 
     // one chunk = two half-items.  Ra = raw[g] (its second half still to be split), Rb = raw[g+1] (landed by the second
     // half-item), Rc = the buffer raw[g+2] goes into
@@ -298,11 +306,10 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         BX_PIN(P1, 1);
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
-        // W k-step h0+1 has landed (issued BX_PD-1 half-items ago; younger: BX_PD-2 W issues and the X loads of one chunk, or
-        // this wave's 64 stores), every wave is past half-item h0-1: its ring slot takes k-step h0+BX_PD
-        if (since_store <= 2) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
-        else if (two_pieces) { if (DROP) PG_WAIT_BARRIER(9); else PG_WAIT_BARRIER(8); }
-        else { if (DROP) PG_WAIT_BARRIER(7); else PG_WAIT_BARRIER(6); }
+        // W k-step h0+1 has landed: issued BX_PD-1 half-items ago, BX_PD-2 younger k-steps of two pieces each.  Every wave is past
+        // half-item h0-1: its ring slot takes k-step h0+BX_PD
+        if (ABL & 16) PG_WAIT_BARRIER(0); else PG_WAIT_BARRIER(8);
+        static_assert(2 * (BX_PD - 2) == 8, "the W wait above allows the younger W pieces: 2 per k-step");
         issue_b(h0 + BX_PD);
         load_raw(Rc, t2, c2);
         read_b(Bn, h0, BxN<3>());
@@ -321,12 +328,11 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         BX_PIN(P1, 3);
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
-        since_store++;
         // ================= half-item (g, 1): MFMAs on P1; raw[g+1]'s first half -> P0
-        // raw[g+1] has landed: issued three half-items ago; younger: two W issues and the X loads of raw[g+2]
-        if (since_store <= 2) BX_WAIT_RAW(63, Rb);
-        else if (two_pieces) { if (DROP) BX_WAIT_RAW(9, Rb); else BX_WAIT_RAW(8, Rb); }
-        else { if (DROP) BX_WAIT_RAW(7, Rb); else BX_WAIT_RAW(6, Rb); }
+        // raw[g+1] has landed: issued three half-items ago; the younger loads of its kind are raw[g+2]'s
+        if (ABL & 16) BX_WAIT_RAW(0, Rb);
+        else if (DROP) BX_WAIT_RAW(5, Rb);
+        else BX_WAIT_RAW(4, Rb);
         const uint32_t wb = window(Rb, t1, c1);
         read_b(Bn, h0 + 1, BxN<1>());
         __builtin_amdgcn_sched_barrier(0);
@@ -344,11 +350,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         BX_PIN(P0, 1);
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
-        // (here the W k-step waited for was issued at an even half-item, in FRONT of that half-item's X loads: two W issues and
-        //  the X loads of two chunks are younger)
-        if (since_store <= 2) asm volatile("s_waitcnt vmcnt(63)\n\ts_barrier" ::: "memory");
-        else if (two_pieces) { if (DROP) PG_WAIT_BARRIER(14); else PG_WAIT_BARRIER(12); }
-        else { if (DROP) PG_WAIT_BARRIER(12); else PG_WAIT_BARRIER(10); }
+        if (ABL & 16) PG_WAIT_BARRIER(0); else PG_WAIT_BARRIER(8);
         issue_b(h0 + 1 + BX_PD);
         read_b(Bn, h0 + 1, BxN<3>());
         __builtin_amdgcn_sched_barrier(0);
@@ -366,12 +368,10 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         BX_PIN(P0, 3);
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
-        since_store++;
         if (c == a.n_chunks - 1) {
             const bool live = 8 * t + wave < nb;
 #pragma unroll
             for (int n = 0; n < 4; n++) store_block(acc[n], (rb_lo + 8 * t + wave) * 32, 32 * n + li, live);
-            since_store = 0;
         }
     };
     int g = 0;
@@ -382,5 +382,239 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
     }
     if (g < n_items) { chunk(R0, R1, R2, g); g++; }
     if (g < n_items) { chunk(R1, R2, R0, g); g++; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing of this wave may still be landing in LDS when it ends
+    // Nothing of this wave may still be landing when it ends — and the raw buffers stay allocated until here: the loads issued
+    // past the end of the share are never used, so hipcc would otherwise hand their destination registers to the epilogue
+    // while the loads are still in flight (an asm output counts as written when the statement is issued).
+    BX_WAIT_RAW(0, R0);
+    BX_WAIT_RAW(0, R1);
+    BX_WAIT_RAW(0, R2);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dW[K x 128] = X~^T[K x m] . dH0[m x 128]: the rows are the reduction.  Grid (feature range of 128, row split); a workgroup is
+// FOUR waves: wave w owns the 32 features F0 = 128 fr + 32 w (x all 128 columns: 4 accumulator blocks) — and produces the
+// planes of column block w of dH0 for all four.  A step is 16 rows:
+//   * MFMA operand A = X~^T: lane (f, h) holds X[r0 + 8h + j][F0 + f], j = 0..7 — eight dword loads, each a whole 128-byte line
+//     across the 32 lanes of a half-wave; no transposition, no LDS.  With dropout a lane also loads, per value, the word of
+//     the keep-bit array that holds its bit (neighbouring lanes share it: one or two L1 lines per row).
+//   * operand B = dH0: lane (c, h) of wave w loads dH0[r0 + 8h + j][32w + c] the same way, splits it and writes the three
+//     16-byte plane pieces into the step's LDS image (12 KB: [plane][column block][lane], as the forward's W k-steps); a
+//     barrier per step publishes it; every wave reads all four column blocks back.
+//   Both operands' values of step s+1 are split (8 pairs) while step s's 24 MFMAs run; loads run two steps ahead.
+// Rows past the split's end contribute zero (lane masks); rows past m are outside the buffer descriptors and read as zero.
+// One f32 slab [K x 128] per row split, summed in split order by slab_reduce_kernel (no atomics: the same bits every run).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Bx3BwdArgs {
+    const float *x; int ldx;          // X [m x ldx], ldx >= 128 * gridDim.x, zero padded past K
+    const float *dout; int ldd;       // dH0 [m x 128]
+    float *slab; int p_ld;            // [gridDim.y][K][p_ld]
+    int m, K, rps;                    // rows per split: a multiple of 16
+    int split0;                       // blockIdx.y == 0 is row split number split0 (a launch may cover a range of the splits)
+    const uint32_t *bits;             // keep bits of X (element row*K + col), NULL: no dropout
+    float scale;                      // 1 / (1 - p) with dropout, applied to the stored partial
+};
+
+__device__ __forceinline__ u32x4 bx_make_rsrc(const void *p, uint32_t bytes) {
+    const uint64_t q = (uint64_t)(uintptr_t)p;
+    return (u32x4){(uint32_t)q, (uint32_t)(q >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void bx_bload4(float &dst, uint32_t voff, u32x4 rsrc, uint32_t soff) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void bx_ldswrite16(uint32_t addr, u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ float bx_keep(float x, uint64_t lane_mask) {     // x where the lane's bit is set, else 0
+    float y;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(y) : "v"(x), "s"(lane_mask));
+    return y;
+}
+struct BxRaw8 { float a[8], b[8]; uint32_t k[8]; };          // k: with dropout, the word of the keep-bit array that holds the bit of a[j]
+#define BX_WAIT_RAW8(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((r).a[0]), "+v"((r).a[1]), "+v"((r).a[2]), "+v"((r).a[3]), "+v"((r).a[4]), "+v"((r).a[5]), "+v"((r).a[6]), "+v"((r).a[7]), \
+                                                                   "+v"((r).b[0]), "+v"((r).b[1]), "+v"((r).b[2]), "+v"((r).b[3]), "+v"((r).b[4]), "+v"((r).b[5]), "+v"((r).b[6]), "+v"((r).b[7]), \
+                                                                   "+v"((r).k[0]), "+v"((r).k[1]), "+v"((r).k[2]), "+v"((r).k[3]), "+v"((r).k[4]), "+v"((r).k[5]), "+v"((r).k[6]), "+v"((r).k[7]) :: "memory")
+
+template <bool DROP, int NP>
+__global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BX_BH_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    if (a.m < 0) smem[tid] = 0;       // never taken: the array is otherwise touched by inline asm only
+    const int fr = blockIdx.x, split = blockIdx.y + a.split0;
+    const int F0 = 128 * fr + 32 * wave;
+    const int r_lo = split * a.rps, r_hi = min(a.m, r_lo + a.rps);
+    const int n_steps = r_hi > r_lo ? (r_hi - r_lo + 15) >> 4 : 0;
+
+    const u32x4 rs_x = bx_make_rsrc(a.x, (uint32_t)a.m * (uint32_t)a.ldx * 4u);
+    const u32x4 rs_d = bx_make_rsrc(a.dout, (uint32_t)a.m * (uint32_t)a.ldd * 4u);
+    uint32_t so_x[8], so_d[8];                                   // row j of a lane's eight: scalar byte offsets
+#pragma unroll
+    for (int j = 0; j < 8; j++) { so_x[j] = (uint32_t)j * (uint32_t)a.ldx * 4u; so_d[j] = (uint32_t)j * (uint32_t)a.ldd * 4u; }
+    const uint32_t vo_x0 = ((uint32_t)(r_lo + 8 * hh) * (uint32_t)a.ldx + (uint32_t)(F0 + li)) * 4u;
+    const uint32_t vo_d0 = ((uint32_t)(r_lo + 8 * hh) * (uint32_t)a.ldd + (uint32_t)(32 * wave + li)) * 4u;
+    const uint32_t step_x = 16u * (uint32_t)a.ldx * 4u, step_d = 16u * (uint32_t)a.ldd * 4u;
+    const u32x4 rs_k = bx_make_rsrc(a.bits, ((uint32_t)(((uint64_t)a.m * a.K) >> 5) + 2u) * 4u);
+    const uint32_t e_lane0 = (uint32_t)(r_lo + 8 * hh) * (uint32_t)a.K + (uint32_t)(F0 + li);   // element index of value j = 0 of step 0 (m * K < 2^32: checked at the launch site)
+    constexpr int LR = DROP ? 24 : 16;                           // vector-memory operations of one load_raw
+    auto load_raw = [&](BxRaw8 &r, int s) __attribute__((always_inline)) {
+        const uint32_t vx = vo_x0 + (uint32_t)s * step_x, vd = vo_d0 + (uint32_t)s * step_d;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bx_bload4(r.a[j], vx, rs_x, so_x[j]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) bx_bload4(r.b[j], vd, rs_d, so_d[j]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (DROP) {
+                const uint32_t e = e_lane0 + (uint32_t)(16 * s + j) * (uint32_t)a.K;
+                uint32_t w;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(w) : "v"((e >> 5) << 2), "s"(rs_k) : "memory");
+                r.k[j] = w;
+            } else {
+                r.k[j] = 0u;
+            }
+        }
+    };
+    // lane masks of step s: bit l of M[j] = value j of lane l counts (its row is inside the split; with dropout: and is kept)
+    struct Masks { uint64_t m[8]; };
+    auto field = [&](int row) __attribute__((always_inline)) -> uint32_t {       // all ones when `row` is inside this split
+        return row < r_hi ? 0xFFFFFFFFu : 0u;
+    };
+    auto make_masks = [&](Masks &M, int s) __attribute__((always_inline)) {
+        const int r0 = r_lo + 16 * s;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            M.m[j] = (uint64_t)field(r0 + j) | ((uint64_t)field(r0 + 8 + j) << 32);
+            asm volatile("" : "+s"(M.m[j]));                     // an SGPR pair whatever the value (v_cndmask takes no literal mask)
+        }
+    };
+    auto split_a_pair = [&](BxPlanes &P, const BxRaw8 &r, const Masks &M, int s, int i) __attribute__((always_inline)) {
+        float x0 = bx_keep(r.a[2 * i], M.m[2 * i]), x1 = bx_keep(r.a[2 * i + 1], M.m[2 * i + 1]);
+        if (DROP) {
+            const uint32_t e0 = e_lane0 + (uint32_t)(16 * s + 2 * i) * (uint32_t)a.K, e1 = e0 + (uint32_t)a.K;
+            x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)(((int32_t)((r.k[2 * i] >> (e0 & 31)) << 31)) >> 31));
+            x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)(((int32_t)((r.k[2 * i + 1] >> (e1 & 31)) << 31)) >> 31));
+        }
+        bx_split2(x0, x1, P.w[0][i], P.w[1][i], P.w[2][i]);
+    };
+    auto split_b_pair = [&](BxPlanes &P, const BxRaw8 &r, int i) __attribute__((always_inline)) {
+        bx_split2(r.b[2 * i], r.b[2 * i + 1], P.w[0][i], P.w[1][i], P.w[2][i]);
+    };
+    // this wave's column block of the step's B image
+    auto write_b = [&](const BxPlanes &P, int slot) __attribute__((always_inline)) {
+        const uint32_t addr = lds0 + slot * BX_BH_BYTES + (wave * 64 + lane) * 16;
+        bx_ldswrite16<0 * 4096>(addr, (u32x4){P.w[0][0], P.w[0][1], P.w[0][2], P.w[0][3]});
+        bx_ldswrite16<1 * 4096>(addr, (u32x4){P.w[1][0], P.w[1][1], P.w[1][2], P.w[1][3]});
+        bx_ldswrite16<2 * 4096>(addr, (u32x4){P.w[2][0], P.w[2][1], P.w[2][2], P.w[2][3]});
+    };
+    auto read_b = [&](BxB3 &b, int slot, auto n_tag) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_tag)::value;
+        const uint32_t addr = lds0 + slot * BX_BH_BYTES + lane * 16;
+        bx_ldsread16<(0 * 4 + N) * 1024>(b.h, addr);
+        bx_ldsread16<(1 * 4 + N) * 1024>(b.m, addr);
+        bx_ldsread16<(2 * 4 + N) * 1024>(b.l, addr);
+    };
+    auto mac = [&](f32x16 &c, const BxPlanes &A, const BxB3 &B) __attribute__((always_inline)) {
+        const bf16x8 ah = bx_plane(A, 0), am = bx_plane(A, 1), al = bx_plane(A, 2);
+        if (NP >= 8) { c = MFMA_BF16(al, B.m, c); c = MFMA_BF16(am, B.l, c); }
+        c = MFMA_BF16(al, B.h, c);
+        c = MFMA_BF16(am, B.m, c);
+        c = MFMA_BF16(ah, B.l, c);
+        c = MFMA_BF16(am, B.h, c);
+        c = MFMA_BF16(ah, B.m, c);
+        c = MFMA_BF16(ah, B.h, c);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+
+    if (n_steps > 0) {
+        // ---- prologue: steps 0 and 1 requested; step 0 split, its B image published
+        BxRaw8 R0, R1;
+        load_raw(R0, 0);
+        load_raw(R1, 1);                                         // (past the split's end: masked; past m: zeros)
+        if (DROP) BX_WAIT_RAW8(24, R0); else BX_WAIT_RAW8(16, R0);
+        BxPlanes PA0, PA1, PB;
+        Masks M;
+        make_masks(M, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { split_a_pair(PA0, R0, M, 0, i); split_b_pair(PB, R0, i); }
+        write_b(PB, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        BxB3 Bc, Bn;
+        read_b(Bc, 0, BxN<0>());
+        BX_WAIT_LDS(Bc);
+        // one step: MFMAs on PAc and the B image in `slot`; Rn = raw(s+1) (landing) -> PAn and the image in slot ^ 1; Rf = the buffer raw(s+2) goes into
+        auto step = [&](BxPlanes &PAc, BxPlanes &PAn, BxRaw8 &Rn, BxRaw8 &Rf, int s) __attribute__((always_inline)) {
+            const int slot = s & 1;
+            load_raw(Rf, s + 2);
+            make_masks(M, s + 1);
+            if (DROP) BX_WAIT_RAW8(24, Rn); else BX_WAIT_RAW8(16, Rn);   // raw(s+1): issued a step ago; younger: the loads just issued
+            read_b(Bn, slot, BxN<1>());
+            __builtin_amdgcn_sched_barrier(0);
+            split_b_pair(PB, Rn, 0); split_b_pair(PB, Rn, 1);
+            mac(acc[0], PAc, Bc);
+            interleave();
+            BX_PIN(PB, 0); BX_PIN(PB, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            BX_WAIT_LDS(Bn);
+            read_b(Bc, slot, BxN<2>());
+            __builtin_amdgcn_sched_barrier(0);
+            split_b_pair(PB, Rn, 2); split_b_pair(PB, Rn, 3);
+            mac(acc[1], PAc, Bn);
+            interleave();
+            BX_PIN(PB, 2); BX_PIN(PB, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            BX_WAIT_LDS(Bc);
+            write_b(PB, slot ^ 1);                               // the image of step s+1: its slot was last read in step s-1
+            read_b(Bn, slot, BxN<3>());
+            __builtin_amdgcn_sched_barrier(0);
+            split_a_pair(PAn, Rn, M, s + 1, 0); split_a_pair(PAn, Rn, M, s + 1, 1);
+            mac(acc[2], PAc, Bc);
+            interleave();
+            BX_PIN(PAn, 0); BX_PIN(PAn, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            BX_WAIT_LDS(Bn);                                     // (covers the three plane writes as well)
+            split_a_pair(PAn, Rn, M, s + 1, 2); split_a_pair(PAn, Rn, M, s + 1, 3);
+            mac(acc[3], PAc, Bn);
+            interleave();
+            BX_PIN(PAn, 2); BX_PIN(PAn, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's piece of image s+1 is in LDS; all are done with image s
+            read_b(Bc, slot ^ 1, BxN<0>());
+            BX_WAIT_LDS(Bc);
+        };
+        int s = 0;
+        for (; s + 2 <= n_steps; s += 2) {
+            step(PA0, PA1, R1, R0, s);
+            step(PA1, PA0, R0, R1, s + 1);
+        }
+        if (s < n_steps) step(PA0, PA1, R1, R0, s);
+        // the loads requested past the split's end are never used: their destination registers stay allocated until they have
+        // landed (hipcc would otherwise reuse them for the epilogue below while the loads are in flight)
+        BX_WAIT_RAW8(0, R0);
+        BX_WAIT_RAW8(0, R1);
+    }
+    // ---- this split's partial [128 features x 128 columns] of the slab
+    float *slab = a.slab + (size_t)split * a.K * a.p_ld;
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int feat = F0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (feat < a.K) slab[(size_t)feat * a.p_ld + 32 * n + li] = acc[n][r] * a.scale;
+        }
 }

@@ -273,9 +273,10 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_persist_kernel(PersistFwdArg
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
             // the next chunk's pieces are this wave's only outstanding DMA — and, right after a tile's epilogue, 64 younger
-            // stores (vmcnt counts in issue order and tops out at 63: 63 forces the pieces and lets the stores fly)
-            if (stores_behind) PG_WAIT_BARRIER(63);
-            else PG_WAIT_BARRIER(0);
+            // stores.  (Rounds 3-4 waited vmcnt(63) there, "63 forces the pieces and lets the stores fly": that assumes stores
+            // complete behind older loads.  They need not — round 5 measured LDS-DMA pieces completing ahead of older register
+            // loads, dense_bf16x3.h — so the wait is for everything: four store drains per launch.)
+            PG_WAIT_BARRIER(0);
             stores_behind = false;
         }
         f1 = load_frags(rem_tag, st, 3);

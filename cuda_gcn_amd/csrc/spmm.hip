@@ -14,6 +14,7 @@
 #include "dense_kernels.h"
 #include "dense_tile128.h"
 #include "dense_persist.h"
+#include "dense_bf16x3.h"
 #include "spmm_sparse.h"
 
 // ------------------------------------------------------------- dense forward
@@ -203,6 +204,33 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         // 32-row blocks, three-stage ring.  GCNHIP_GEMM_TILES keeps the tile kernels below for A/B runs.
         const bool tiles_only = c->opt.gemm_tiles != 0;
         const int n_chunks = (t.K + PG_BK - 1) / PG_BK;
+        // Option gemm_bf16x3 (round 5; 1: wherever the persistent f32 form would run, 2: also on a co-running stream): the same
+        // product on the bf16 matrix pipe from three exact bf16 planes per f32 operand (dense_bf16x3.h) — f32 results inside the
+        // f32 summation bound, 0.21 ms instead of 0.35 at Reddit scale.  0 keeps the exact-f32 MFMA kernels.
+        const int bx = c->opt.gemm_bf16x3;
+        if (fast && p == 128 && !tiles_only && bx && (bx >= 2 || !c->corun) && aligned16(t.x) && aligned16(out) &&
+            (uint64_t)(t.m + 256) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 2 * BX_BH_BYTES <= c->wpack_bytes) {
+            const int n_hs = 2 * n_chunks;
+            uint4 *wp3 = reinterpret_cast<uint4 *>(c->wpack);
+            if (d.on && keep_bits_by_block(d)) {         // keep bits and the packed planes of W from one launch
+                const int n_bits_wgs = (int)ceil_div(((f->nnz + 31) / 32 + 3) / 4, (int64_t)256);
+                dropbits_bx_pack_w_kernel<<<n_bits_wgs + n_hs, 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7, n_bits_wgs,
+                                                                                     w, ld_w, t.K, n_hs, wp3, t.scale);
+            } else {
+                if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
+                bx_pack_w_kernel<<<n_hs, 256, 0, c->stream>>>(w, ld_w, t.K, n_hs, wp3, t.bits ? t.scale : 1.f);
+            }
+            GCNHIP_LAUNCH_CHECK();
+            Bx3FwdArgs ba;
+            ba.x = t.x; ba.ldx = t.ldx; ba.wp = wp3; ba.out = out; ba.ldo = ld_out;
+            ba.m = t.m; ba.K = t.K; ba.n_chunks = n_chunks; ba.n_rb = ceil_div(t.m, 32);
+            ba.bits = t.bits; ba.relu = relu;
+            const int wgs = std::max(1, std::min(c->n_cu, ba.n_rb));
+            if (ba.bits) dense_fwd_bf16x3_kernel<true, 6><<<wgs, 512, 0, c->stream>>>(ba);
+            else dense_fwd_bf16x3_kernel<false, 6><<<wgs, 512, 0, c->stream>>>(ba);
+            GCNHIP_LAUNCH_CHECK();
+            return 0;
+        }
         if (fast && p == 128 && !tiles_only && !c->corun && aligned16(t.x) && aligned16(out) &&
             (uint64_t)(t.m + PG_ROWS) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 4096 * sizeof(float) <= c->wpack_bytes) {
             if (d.on && keep_bits_by_block(d)) {         // keep bits and the packed W from one launch
@@ -412,6 +440,24 @@ static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals
     const int p_ld = (p + 3) / 4 * 4;
     const int rc = ensure_slab(c, (size_t)S * f->n_cols * p_ld * sizeof(float));
     if (rc) return rc;
+    // Option gemm_bf16x3: the same split-K product from three bf16 planes per operand (dense_bf16x3.h): every split's slab,
+    // then the same ordered slab sum.  The padded copy of X (row stride a multiple of 128, zeros past K) is what it reads.
+    {
+        const int bx = c->opt.gemm_bf16x3;
+        const bool padded = vals == f->values && f->values_pad && f->ld_pad >= kt * 128;
+        if (bx && (bx >= 2 || !c->corun) && p == 128 && padded && rps % 16 == 0 && ld_dout % 4 == 0 && aligned16(dout) &&
+            (uint64_t)f->n_rows * (uint64_t)f->ld_pad * 4u < (1ull << 32) && (uint64_t)f->n_rows * (uint64_t)ld_dout * 4u < (1ull << 32) &&
+            (uint64_t)f->n_rows * (uint64_t)f->n_cols < (1ull << 32)) {
+            Bx3BwdArgs b;
+            b.x = f->values_pad; b.ldx = f->ld_pad; b.dout = dout; b.ldd = ld_dout; b.slab = c->slab; b.p_ld = p_ld;
+            b.m = f->n_rows; b.K = f->n_cols; b.rps = rps; b.split0 = s0; b.bits = d.on ? f->keep_bits : nullptr; b.scale = d.on ? d.scale : 1.f;
+            const dim3 grid(kt, s1 - s0);
+            if (b.bits) dense_bwd_bf16x3_kernel<true, 6><<<grid, 256, 0, c->stream>>>(b);
+            else dense_bwd_bf16x3_kernel<false, 6><<<grid, 256, 0, c->stream>>>(b);
+            GCNHIP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     Tile128Args t;
     t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
     int vx = x_vec_width(f, vals);

@@ -61,7 +61,14 @@ __device__ inline void xent_block_tail(const XentArgs &a, float bl, int bc, int 
         // ordering the write-through stores already give on gfx9.  Adam's hand-off (elementwise.hip), whose launch leaves
         // ~1 MB dirty, does carry the release.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the relaxed ticket is a gfx9-family shortcut — agent-scope stores are write-through there; any other target gets the
+        //  release the memory model asks for.  tests/test_ops_gpu.py::test_loss_final_reduction_in_the_launch_equals_the_second_launch
+        //  pins it: 600 blocks, changing inputs, bit-compared against the two-launch form.)
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx940__) || defined(__gfx90a__)
         const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         sh_last = prev == gridDim.x - 1;
         if (sh_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it
     }

@@ -136,6 +136,15 @@ int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups) {
         if (n_groups) *n_groups = m->gcn->schedule_groups();
     })
 }
+int gcnhost_model_transport(gcnhost_model *m, int *ranks, char name[32]) {
+    API_TRY({
+        if (ranks) *ranks = m->gcn->transport_ranks();
+        if (name) { strncpy(name, m->gcn->transport(), 31); name[31] = 0; }
+    })
+}
+int gcnhost_model_slice_floats(gcnhost_model *m, int *floats) {
+    API_TRY({ if (floats) *floats = m->gcn->schedule_slice_floats(); })
+}
 int gcnhost_model_get_var(gcnhost_model *m, int k, int grad, float *out, int *rows, int *cols) {
     API_TRY({
         std::vector<float> v;

@@ -145,6 +145,12 @@ struct RcclComm : Comm {
     }
     int rank() const override { return r; }
     int size() const override { return w; }
+    const char *transport() const override { return "rccl"; }
+    int transport_ranks() const override {
+        int n = 0;
+        NCCL_CHECK(ncclCommCount(comm, &n));
+        return n;
+    }
     void allgather_rows(float *base, size_t block) override {
         // in place: sendbuff == recvbuff + rank * count
         enter();
@@ -196,6 +202,7 @@ struct HostComm : Comm {
         : ctx(c), r(rank), w(world), ag(a), ar(b), user(u) {}
     int rank() const override { return r; }
     int size() const override { return w; }
+    const char *transport() const override { return "host callbacks"; }
     void allgather_rows(float *base, size_t block) override {
         stage.resize(block * w);
         GCNHIP_CHECK(gcnhip_d2h(ctx, stage.data() + block * r, base + block * r, block * sizeof(float)));

@@ -28,6 +28,10 @@ struct Comm {
     virtual ~Comm() {}
     virtual int rank() const = 0;
     virtual int size() const = 0;
+    // what moves the bytes ("rccl", "host callbacks", "none") and how many ranks THAT layer counts (RCCL: ncclCommCount of
+    // the communicator) — so that a benchmark record states that the collectives really spanned the ranks it claims
+    virtual const char *transport() const { return "none"; }
+    virtual int transport_ranks() const { return size(); }
     virtual void allgather_rows(float *base, size_t block_elems) = 0;
     // Complete a gathered table [plan.table_rows x ld_words 4-byte words] whose own block (plan.own_offset ..
     // + n_local) this rank has just written: ALLGATHER plans -> allgather_rows; HALO plans -> pack the rows each

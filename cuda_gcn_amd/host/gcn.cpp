@@ -429,6 +429,50 @@ void HipGCN::add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *
     }
 }
 
+// Column-slice width of the XCD-sliced hidden-width launch (round 5): 64-float slices (two per 128-wide row: each XCD's L2
+// sees half the table) or 32-float slices (four: a quarter of the table per L2, twice the re-reads of the index stream,
+// 128-byte requests).  Which wins depends on where the graph's reuse sits (tools/exp_structure.py, bench.py's structure legs):
+// with row groups that fit an L2 and hold most of the edges the wide slices do (reddit-syn: 0.76 vs 0.84 ms); on a graph whose
+// reuse is its hub rows the narrow ones (reddit-syn-h0: 1.22 vs 1.11 ms; -h03 1.02 vs 0.98; -zipf 0.97 vs 0.89); past the
+// Infinity Cache the wide ones again (R-MAT scale 21: 4.57 vs 5.20 ms).  The two widths split a row's sum over 4 or 8 lane
+// groups, i.e. associate it differently, so the choice must NOT depend on a timing (two runs of one dataset print the same
+// bits): it is a rule on the graph — narrow when the gathered table is cache-resident and less than 45 % of the stored
+// edges stay inside a row group (label or found community) whose 256-byte slices fit half an L2 (8192 rows).
+void HipGCN::choose_slice_width() {
+    const int N = params.num_nodes, H = params.hidden_dim;
+    slice_floats = 64;
+    int cur_gl = 0;
+    GCNHIP_CHECK(gcnhip_ctx_get_option(env.ctx, "gs_l", &cur_gl));
+    if (cur_gl != 0 || !opt_.slice_tuning || H % 64 != 0 || H / 32 > 8 || 8 % (H / 32) != 0) return;
+    if ((size_t)N * H * sizeof(float) > ((size_t)256 << 20)) return;                 // HBM regime: wide
+    // (the groups the schedule candidates were built from — labels when they are communities of the graph, else what the
+    //  group search found — NOT the candidate the timing picked: every schedule gives the same bits, the slice width does not)
+    const int *group = labels_assortative ? data->label.data() : (!structure_group.empty() ? structure_group.data() : nullptr);
+    double share = 0.0;
+    if (group) {
+        std::vector<int> size;
+        for (int i = 0; i < N; i++) {
+            if (group[i] < 0) continue;
+            if ((size_t)group[i] >= size.size()) size.resize((size_t)group[i] + 1, 0);
+            size[group[i]]++;
+        }
+        const std::vector<int> &gp = data->graph.indptr, &gi = data->graph.indices;
+        long inside = 0, total = 0;
+        for (int i = 0; i < N; i++)
+            for (int e = gp[i]; e < gp[i + 1]; e++) {
+                if (gi[e] == i) continue;
+                total++;
+                inside += group[i] >= 0 && group[gi[e]] == group[i] && size[group[i]] <= 8192;
+            }
+        share = total ? (double)inside / (double)total : 0.0;
+    }
+    slice_floats = share < 0.45 ? 32 : 64;
+    GCNHIP_CHECK(gcnhip_ctx_set_option(env.ctx, "gs_l", slice_floats == 32 ? 8 : 0));
+    if (opt_.verbose && env.comm->rank() == 0)
+        fprintf(stderr, "gcn-hip: hidden-width aggregation: %.0f %% of the edges inside a row group that fits an L2 -> %d-float column slices\n",
+                100 * share, slice_floats);
+}
+
 void HipGCN::tune_schedule() {
     if (n_local < 4096 && opt_.schedule < 0) return;         // launch-bound graphs: nothing to gain
     const int H = params.hidden_dim;
@@ -442,6 +486,7 @@ void HipGCN::tune_schedule() {
             apply_schedule(env.ctx, graph);
             if (graph_l1) apply_schedule(env.ctx, graph_l1);
         }
+        choose_slice_width();
         return;
     }
     HipVariable *in = variables[1].get(), *out = variables[3].get();
@@ -476,12 +521,13 @@ void HipGCN::tune_schedule() {
         GCNHIP_CHECK(gcnhip_event_elapsed_ms(e0, e1, &ms));
         if (best == 0.f || ms < best) { best = ms; pick = c; }
     }
-    gcnhip_event_destroy(e0);
-    gcnhip_event_destroy(e1);
     const bool g_has_pick = sched_mode == pick.mode && sched_groups == pick.groups;    // the last candidate timed is still applied to g
     sched_mode = pick.mode; sched_groups = pick.groups;
     if (!(g == graph && g_has_pick)) apply_schedule(env.ctx, graph);
     if (graph_l1 && !(g == graph_l1 && g_has_pick)) apply_schedule(env.ctx, graph_l1);
+    choose_slice_width();
+    gcnhip_event_destroy(e0);
+    gcnhip_event_destroy(e1);
     GCNHIP_CHECK(gcnhip_memset_async(env.ctx, out->data, 0, out->elems() * sizeof(float)));
 }
 
@@ -683,6 +729,7 @@ void HipGCN::build_eval_lane() {
     EvalLane &L = *lane;
     GCNHIP_CHECK(gcnhip_ctx_create(&L.env.ctx, /*device of the main context*/ device_, nullptr));
     GCNHIP_CHECK(gcnhip_ctx_set_corun(L.env.ctx, 1));           // the lane's kernels share the chip with the training pass
+    if (slice_floats == 32) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gs_l", 8));   // as tuned on the training context
     L.timers.reset(new DeviceTimers(L.env.ctx));
     L.timers->enabled = timers->enabled;
     L.env.timers = L.timers.get();

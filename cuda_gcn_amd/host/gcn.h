@@ -96,6 +96,8 @@ struct HipGCNOptions {
     // HIPGCN_SCHEDULE=degree|label|dealt[-G]|structure: pin the aggregation's row schedule instead of timing the candidates at
     // load (-1: timed).  A pinned run launches no tuning kernels, so a kernel-trace profile of it holds the epochs' launches only.
     int schedule = -1, schedule_groups = 256;
+    bool slice_tuning = true;             // HIPGCN_NO_SLICE_TUNING clears: the hidden-width aggregation keeps 64-float column slices
+                                          // (default: chosen per graph by a rule on its structure, HipGCN::choose_slice_width)
     // HIPGCN_GEMM=f32|bf16x3: arithmetic of the dense first-layer products (0: exact-f32 MFMA, 1: three-plane bf16 split on the
     // bf16 MFMA pipe, same f32 error bound; -1: the library's default)
     int gemm = -1;
@@ -129,7 +131,10 @@ public:
     int rank() const { return env.comm->rank(); }
     int schedule_mode() const { return sched_mode; }
     int schedule_groups() const { return sched_groups; }
+    int schedule_slice_floats() const { return slice_floats; }  // column-slice width the hidden-width aggregation was tuned to (64 or 32)
     int world() const { return env.comm->size(); }
+    const char *transport() const { return env.comm->transport(); }
+    int transport_ranks() const { return env.comm->transport_ranks(); }
     int local_rows() const { return n_local; }
     int row_start() const { return part.start[env.comm->rank()]; }
     const RowPartition &partition() const { return part; }
@@ -299,11 +304,12 @@ private:
     void train_end();
 
     // row schedule of the aggregation (gcnhip_graph_set_schedule): candidates timed once, fastest kept
-    int sched_mode = 0, sched_groups = 0;
+    int sched_mode = 0, sched_groups = 0, slice_floats = 64;
     bool labels_assortative = false;
     std::vector<int> structure_group;                          // per node: group found in the graph (cluster.h); empty: none useful
     int structure_n_groups = 0;
     void tune_schedule();
+    void choose_slice_width();
     void apply_schedule(gcnhip_ctx *ctx, gcnhip_graph *g);
     void add_split_rowsets(gcnhip_ctx *ctx, gcnhip_graph *g, gcnhip_rowset *out[4]);
     void build_modules();

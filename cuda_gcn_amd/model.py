@@ -152,6 +152,18 @@ class HipGCNModel:
         _ck(self.lib, self.lib.gcnhost_model_schedule(self.h, C.byref(m), C.byref(g)), "schedule")
         return {0: "degree", 1: "label-major", 2: f"dealt-{g.value}", 3: f"structure-major ({g.value} groups)"}[m.value]
 
+    def transport(self):
+        """(name of the layer that moves rows between ranks, ranks that layer counts — ncclCommCount under RCCL)"""
+        n, buf = C.c_int(), C.create_string_buffer(32)
+        _ck(self.lib, self.lib.gcnhost_model_transport(self.h, C.byref(n), buf), "transport")
+        return buf.value.decode(), n.value
+
+    def slice_floats(self):
+        """column-slice width (floats) of the XCD-sliced hidden-width aggregation, timed at load: 64 or 32"""
+        f = C.c_int()
+        _ck(self.lib, self.lib.gcnhost_model_slice_floats(self.h, C.byref(f)), "slice_floats")
+        return f.value
+
     def timer(self, name_or_id):
         i = TIMER_NAMES.index(name_or_id) if isinstance(name_or_id, str) else int(name_or_id)
         s, n = C.c_double(), C.c_long()

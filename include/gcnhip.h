@@ -276,7 +276,11 @@ int gcnhip_feat_create(gcnhip_ctx *ctx, gcnhip_feat **f, const int *h_indptr, co
 int gcnhip_feat_create_aggregated(gcnhip_ctx *ctx, gcnhip_feat **f, gcnhip_graph *g, const gcnhip_feat *x);
 int gcnhip_feat_destroy(gcnhip_ctx *ctx, gcnhip_feat *f);
 int gcnhip_feat_is_dense(const gcnhip_feat *f);
-float *gcnhip_feat_values(gcnhip_feat *f);              /* device pointer, nnz floats (pristine X) */
+/* device pointer, nnz floats: the pristine X.  READ-ONLY: the object keeps derived copies of these values (a padded image for
+ * the MFMA kernels, the CSC-ordered copy the sparse weight gradient reads) that only gcnhip_feat_scale_rows keeps in step —
+ * a caller that wants modified values passes its own buffer as `vals` to gcnhip_spmm_fwd / _bwd instead (the modular path
+ * does: set_input copies, Dropout mutates the copy, gcn.cpp:23,73-76). */
+const float *gcnhip_feat_values(const gcnhip_feat *f);
 int64_t gcnhip_feat_nnz(const gcnhip_feat *f);
 
 /* ---- SparseMatmul (CUDASparseMatmul: cuda_module.cu:42-70; kernels
@@ -357,22 +361,8 @@ int gcnhip_matmul_bwd_ex(gcnhip_ctx *ctx, const float *a, int lda, const float *
                          int m, int n, int p, float relu_dropout_scale, const uint32_t *pos_bits, int words_per_row,
                          const float *d_da_row_scale);
 
-/* Packed dH1 (exact).  ReLU and dropout zero about three quarters of dH1 = mask . (dZ0 . W2^T), at positions known
- * from H1, and its only reader is the hidden layer's backward aggregation (module.cpp:103-119), which pays per
- * 128-byte line gathered.  gcnhip_matmul_bwd_packed is gcnhip_matmul_bwd_fused writing every 64-column half of a row
- * as ONE 128-byte slot (64-bit mask + the masked-in f32 values in column order, at most 30); a half with more
- * masked-in columns is written to da_dense as usual and its slot holds only the mask.  gcnhip_graphsum_packed gathers
- * from the slots (falling back to `dense` for halves that did not fit): half the lines per edge, and — same lane
- * groups, same order of the non-zero terms — bit-identical to gcnhip_graphsum on the dense matrix.  cols % 64 == 0.
- * gcnhip_rowpack_expand rebuilds the dense image in place (tests, introspection). */
-int gcnhip_rowpack_create(gcnhip_ctx *ctx, gcnhip_rowpack **p, int rows, int cols);
-int gcnhip_rowpack_destroy(gcnhip_ctx *ctx, gcnhip_rowpack *p);
-int gcnhip_rowpack_expand(gcnhip_ctx *ctx, const gcnhip_rowpack *p, float *dense, int ld);
-int gcnhip_matmul_bwd_packed(gcnhip_ctx *ctx, const float *a, int lda, const float *b, int ldb,
-                             const float *dc, int lddc, float *da_dense, int ldda, gcnhip_rowpack *pack,
-                             float *db, int lddb, int m, int n, int p, float relu_dropout_scale);
-int gcnhip_graphsum_packed(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_rowpack *p, const float *dense, int ld_dense,
-                           float *out, int ld_out);
+/* (The packed-dH1 entry points — gcnhip_rowpack_*, gcnhip_matmul_bwd_packed, gcnhip_graphsum_packed: built, bit-identical,
+ * measured slower, compiled only by `make EXPERIMENTS=1` — are declared in gcnhip_experimental.h, not in this header.) */
 
 /* Multi-GPU form of the same backward.  dH1 = mask . (dZ0 . W2^T) is cheap to recompute and 128 floats wide,
  * while its inputs are 48 floats (dZ0) and 1 bit per element (mask = H1 > 0): ranks all-gather those and each

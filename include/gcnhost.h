@@ -108,6 +108,11 @@ int gcnhost_model_row_ids(gcnhost_model *m, int *ids, int *renumbered);
  * the logits, weights and weight gradients are never scaled); dinv [local_rows] receives that factor (may be NULL) */
 int gcnhost_model_row_scale(gcnhost_model *m, float *dinv, int *factored);
 int gcnhost_model_schedule(gcnhost_model *m, int *mode, int *n_groups);
+/* the layer that moves this model's rows between ranks ("rccl", "host callbacks", "none") and the number of ranks THAT layer
+ * counts (RCCL: ncclCommCount of the model's communicator) */
+int gcnhost_model_transport(gcnhost_model *m, int *ranks, char name[32]);
+/* column-slice width (floats) the hidden-width aggregation was tuned to at load: 64 (two slices of a 128-wide row) or 32 */
+int gcnhost_model_slice_floats(gcnhost_model *m, int *floats);
 /* variable k of gcn.cpp:21-54 (1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z): this rank's rows, row-major rows x cols.
  * out == NULL: only report the shape. */
 /* Variable k of the reference's list (gcn.cpp:21-54: 1 H0, 2 W1, 3 H1, 4 Z0, 5 W2, 6 Z), this rank's rows, row-major rows x cols

@@ -164,6 +164,51 @@ def test_logical_ranks_as_threads_match_single_gpu(name, world, dropout, run_asy
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,hidden,flags,want_mode", [
+    ("reddit-syn", 128, 0, "allgather"),                    # BASELINE configs[3] at its own size: 8 row blocks of the 233 K-node graph
+    ("reddit-syn", 128, OVERLAP, "allgather"),              # ... with every exchange on its own stream beside the own-column edges
+    ("rmat-20-32", 128, 0, "halo"),                         # BASELINE configs[4]'s family at 1 M nodes: per-peer halo lists
+])
+def test_full_size_eight_logical_ranks_match_single_gpu(name, hidden, flags, want_mode):
+    """The N > 1 path at the BASELINE sizes, on the one GPU this pool has: 8 logical ranks (threads of this process, host-staged
+    transport — everything of the row-partitioned epoch except RCCL itself) against the single-GPU trace of the same model,
+    2 epochs with the device dropout RNG (decisions keyed by global element index: partition-invariant).  Exercises what the
+    reddit-mini / rmat-12 tests cannot: 32-bit offsets and padded-table sizes at N = 233 K / 1 M rows, the split-row
+    segments of 12 K- and 64 K-degree hubs inside a rank's block, the halo lists of a million-node graph.  The exchange a rank
+    reports (kind, table rows, rows sent and received) must be what the host-only plan (tools/exchange_volume.py's source,
+    model.exchange_plan) says for that rank."""
+    from cuda_gcn_amd import datagen, model
+    from cuda_gcn_amd.model import HipGCNModel
+    from tests.mr_threads import run_ranks
+    world, epochs = 8, 2
+    ds = datagen.make_dataset(name)
+    got = run_ranks(ds, world, flags, epochs, hidden, 0.5, run_async=True)
+    for tr in got["traces"][1:]:
+        assert np.array_equal(tr, got["traces"][0])          # every rank reads the same all-reduced scalars
+    x = got["exchange"]
+    plan = model.exchange_plan(ds["g_indptr"], ds["g_indices"], world, 0, 0)
+    assert x["mode"] == want_mode == ("halo" if plan["halo"] else "allgather"), (x, plan["halo"])
+    assert x["table_rows"] == plan["table_rows"]
+    if plan["halo"]:
+        assert x["recv_rows"] == plan["recv_rows"].size and x["send_rows"] == plan["send_rows"].size, (x, plan["recv_rows"].size, plan["send_rows"].size)
+        assert 0 < x["recv_rows"] < (world - 1) * plan["rows_max"]                  # fewer rows than the padded all-gather would move
+    else:
+        assert x["table_rows"] == world * plan["rows_max"]
+    m = HipGCNModel(ds, seed=4, hidden_dim=hidden, dropout=0.5, epochs=epochs)
+    want = m.run_epochs(epochs)
+    wtest = m.eval(3)
+    h1 = m.var(3)
+    m.close()
+    assert np.isfinite(got["trace"]).all() and np.isfinite(want).all()
+    assert np.abs(got["trace"][:, [0, 2]] - want[:, [0, 2]]).max() <= 2e-4, np.abs(got["trace"] - want).max(axis=0)
+    n_scored = max(1, int((ds["split"] == 2).sum()))
+    assert np.abs(got["trace"][:, [1, 3]] - want[:, [1, 3]]).max() <= max(0.005, 2.0 / n_scored)
+    assert np.abs(got["test"] - np.array(wtest, np.float32)).max() <= 2e-4
+    dh = np.abs(got["h1"] - h1)
+    assert np.median(dh) <= 1e-5 and np.quantile(dh, 0.999) <= 1e-3 * max(1.0, float(np.abs(h1).max())), (np.median(dh), dh.max())
+
+
+@pytest.mark.gpu
 def test_overlap_exchange_vs_oracle_cora():
     """the overlapped schedule against the CPU oracle itself (reference RNG stream replayed on every rank)"""
     from cuda_gcn_amd import datagen

@@ -8,6 +8,7 @@ Pure element-wise ops and integer results are exact (==).
 """
 import os
 
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -658,6 +659,9 @@ def test_dense_forward_persistent_and_tile_kernels_give_the_same_bits(dev, N, F)
     w = rng.standard_normal((F, 128)).astype(np.float32)
     f = dev.feat(fp, fi, vals, F)
     assert f.dense
+    bx = C.c_int()
+    _ck(dev.lib, dev.lib.gcnhip_ctx_get_option(dev.ctx, b"gemm_bf16x3", C.byref(bx)), "get_option")
+    _ck(dev.lib, dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", 0), "set_option")      # the two exact-f32 MFMA forms
     try:
         got = {}
         for corun in (0, 1):
@@ -675,6 +679,51 @@ def test_dense_forward_persistent_and_tile_kernels_give_the_same_bits(dev, N, F)
         assert np.all(np.abs(odd[0].astype(np.float64) - odd[1]) <= 4 * EPS * mag + 1e-30)
     finally:
         dev.lib.gcnhip_ctx_set_corun(dev.ctx, 0)
+        dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", bx.value)
+    f.free()
+
+
+@pytest.mark.parametrize("N,F", [(5000, 602), (257, 602), (70000, 96), (31, 40), (8192 * 3 + 17, 130)])
+def test_dense_products_from_three_bf16_planes(dev, oracle, N, F):
+    """p = 128, dense X, context option gemm_bf16x3 (dense_bf16x3.h): the forward X~.W and the weight gradient X~^T.dH0 on the
+    bf16 matrix pipe from three exact bf16 planes per f32 operand.  Checked like every other sum of the path — against the
+    float64 product within 8 eps_f32 * sum|terms| — beside the exact-f32 MFMA kernels on the same inputs, with and without
+    dropout (same decisions: same keep bits) and with the ReLU epilogue; and the same kernel runs whether or not the context
+    is marked co-running, so the two-stream epoch reproduces the one-stream epoch's validation losses bit for bit."""
+    from cuda_gcn_amd.ops import _ck
+    rng = np.random.default_rng(N + F)
+    vals = (rng.standard_normal(N * F) * np.exp(rng.uniform(-6, 6, N * F))).astype(np.float32)     # twelve octaves of magnitudes
+    fp = (np.arange(N + 1) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    w = rng.standard_normal((F, 128)).astype(np.float32)
+    dh = (rng.standard_normal((N, 128)) * 1e-3).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    bx = C.c_int()
+    _ck(dev.lib, dev.lib.gcnhip_ctx_get_option(dev.ctx, b"gemm_bf16x3", C.byref(bx)), "get_option")
+    X = vals.reshape(N, F).astype(np.float64)
+    try:
+        res = {}
+        for mode in (0, 2):
+            _ck(dev.lib, dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", mode), "set_option")
+            res[mode] = (dev.spmm_fwd(f, w), dev.spmm_fwd(f, w, p_drop=0.5, seed=7, epoch=3), dev.spmm_fwd_relu(f, w),
+                         dev.spmm_bwd(f, dh), dev.spmm_bwd(f, dh, p_drop=0.5, seed=7, epoch=3))
+        _ck(dev.lib, dev.lib.gcnhip_ctx_set_corun(dev.ctx, 1), "gcnhip_ctx_set_corun")
+        lane = (dev.spmm_fwd(f, w), dev.spmm_fwd_relu(f, w))
+        _ck(dev.lib, dev.lib.gcnhip_ctx_set_corun(dev.ctx, 0), "gcnhip_ctx_set_corun")
+        assert np.array_equal(lane[0].view(np.uint32), res[2][0].view(np.uint32)) and np.array_equal(lane[1].view(np.uint32), res[2][2].view(np.uint32))
+        keep = philox_keep(7, 3, np.arange(N * F, dtype=np.uint64), thr_of(0.5)).reshape(N, F)
+        Xd = X * np.where(keep, 2.0, 0.0)
+        for Xv, i_f, i_b in ((X, 0, 3), (Xd, 1, 4)):
+            want_f, mag_f = Xv @ w.astype(np.float64), np.abs(Xv) @ np.abs(w.astype(np.float64))
+            want_b, mag_b = Xv.T @ dh.astype(np.float64), np.abs(Xv).T @ np.abs(dh.astype(np.float64))
+            for mode in (0, 2):
+                uf = float((np.abs(res[mode][i_f] - want_f) / (EPS * mag_f + 1e-30)).max())
+                ub = float((np.abs(res[mode][i_b] - want_b) / (EPS * mag_b + 1e-30)).max())
+                assert uf <= 8 and ub <= 8, (mode, "dropout" if i_f else "no dropout", "forward", uf, "weight gradient", ub)
+        assert np.array_equal(res[2][2], np.maximum(res[2][0], 0))
+    finally:
+        dev.lib.gcnhip_ctx_set_corun(dev.ctx, 0)
+        dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", bx.value)
     f.free()
 
 
@@ -848,7 +897,7 @@ def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, 
     ep, sq = dev.buf(np.array([6], np.uint32)), dev.buf(np.array([2.5], np.float32))
     gb = dev.buf(np.zeros((n, ld), np.float32))
     try:
-        for it in range(4):
+        for it in range(24 if n > 100000 else 4):             # the large case: 600 blocks hand their partials over, launch after launch
             lb = dev.padded((rng.standard_normal((n, c)) * 3).astype(np.float32), ld)
             got = []
             for two in (False, True, False):

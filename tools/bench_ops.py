@@ -104,7 +104,19 @@ def main():
         print(f"graphsum bf16 table d={dim} ld={ld}: {ms:.3f} ms (+ f32->bf16 convert {ms_c:.3f} ms)", flush=True)
     only_gs = len(sys.argv) > 3 and sys.argv[3] == 'graphsum'
     if len(sys.argv) > 4 and sys.argv[4] == 'split41':      # would two narrower tables (32 + 9 columns) beat one 48-wide row?
-        gs(Cc, 48); gs(32, 32); gs(9, 12); gs(9, 16); gs(16, 16)
+        # round 5 (verdict r04 next 7): 48-float rows (192 B: always two 128-byte lines for 164 useful bytes) against 64-float
+        # line-aligned rows and a 32 + 16-float split (one whole line + one half line that never straddles; two launches)
+        gs(Cc, 48); gs(Cc, 64); gs(32, 32); gs(9, 12); gs(9, 16); gs(16, 16)
+        r48, r64 = res[f"graphsum_d{Cc}_ld48"]["ms"], res[f"graphsum_d{Cc}_ld64"]["ms"]
+        split = res["graphsum_d32_ld32"]["ms"] + res["graphsum_d9_ld16"]["ms"]
+        print(json.dumps({"class_width_layouts_ms": {"rows_of_48_floats": r48, "rows_of_64_floats": r64, "split_32_plus_16": split,
+                                                     "split_parts": [res["graphsum_d32_ld32"]["ms"], res["graphsum_d9_ld16"]["ms"]]}}))
+        return
+    if len(sys.argv) > 4 and sys.argv[4] == 'only_c64':     # PMC passes: 41 columns in 64-float rows
+        gs(Cc, 64)
+        return
+    if len(sys.argv) > 4 and sys.argv[4] == 'only_split':   # PMC passes: the two launches of the 32 + 16 split (different kernel instantiations)
+        gs(32, 32); gs(9, 16)
         return
     if len(sys.argv) > 4 and sys.argv[4] == 'bf16':
         gs(h, h); gs(Cc, 48)

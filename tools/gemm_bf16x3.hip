@@ -9,8 +9,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
+#include <string.h>
 #include <random>
 #include <vector>
+#include "dense_kernels.h"
 #include "dense_bf16x3.h"
 
 int gcnhip_fail(const char *d) { fprintf(stderr, "%s\n", d ? d : ""); return -1; }
@@ -47,6 +49,17 @@ __global__ void glds12_probe(const uint32_t *src, uint32_t *dst) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int i = lane; i < 512; i += 64) dst[i] = buf[i];
+}
+
+// a bandwidth hog for the co-running check: streams a big buffer; `use_lds` workgroups also hold 32 KB of LDS each, so that
+// they share CUs (and the LDS allocator) with the kernel under test
+__global__ __launch_bounds__(256) void hog_kernel(float4 *buf, size_t n, int use_lds) {
+    __shared__ float pad[8192];
+    if (use_lds) { pad[threadIdx.x] = (float)blockIdx.x; __syncthreads(); }
+    float s = use_lds ? pad[(threadIdx.x * 7) & 255] : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 v = buf[i]; v.x += s; buf[i] = v;
+    }
 }
 
 int main(int argc, char **argv) {
@@ -159,6 +172,114 @@ int main(int argc, char **argv) {
                 snprintf(what, sizeof what, "bf16x3, %d plane products", np);
                 check(dout, what, drop, scale);
             }
+    }
+    // ================================================================= the forward beside a co-running kernel (the validation lane's situation)
+    {
+        hipStream_t s1, s2;
+        CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        float4 *hog; const size_t hog_n = (size_t)64 << 20;        // 1 GiB
+        CK(hipMalloc(&hog, hog_n * 16)); CK(hipMemset(hog, 0, hog_n * 16));
+        Bx3FwdArgs a{dx, ldx, dwp, dout, p, m, K, n_chunks, n_rb, nullptr, 1};
+        bx_pack_w_kernel<<<2 * n_chunks, 256>>>(dw, p, K, 2 * n_chunks, dwp, 1.f);
+        dense_fwd_bf16x3_kernel<false, 6><<<n_cu, 512>>>(a);
+        CK(hipDeviceSynchronize());
+        std::vector<float> ref((size_t)m * p), got((size_t)m * p);
+        CK(hipMemcpy(ref.data(), dout, ref.size() * 4, hipMemcpyDeviceToHost));
+        for (int use_lds = 0; use_lds < 4; use_lds++) {
+            int bad_runs = 0; long bad_vals = 0; int first_bad_row = -1;
+            for (int it = 0; it < 20; it++) {
+                CK(hipMemsetAsync(dout, 0xFF, (size_t)m * p * 4, s1));
+                hog_kernel<<<2048, 256, 0, s2>>>(hog, hog_n, use_lds & 1);
+                if (use_lds & 2) dense_fwd_bf16x3_kernel<false, 6, 16><<<n_cu, 512, 0, s1>>>(a);
+                else dense_fwd_bf16x3_kernel<false, 6><<<n_cu, 512, 0, s1>>>(a);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(got.data(), dout, got.size() * 4, hipMemcpyDeviceToHost));
+                long nb = 0;
+                for (size_t i = 0; i < got.size(); i++) if (memcmp(&got[i], &ref[i], 4)) { nb++; if (first_bad_row < 0) first_bad_row = (int)(i / p); }
+                bad_runs += nb > 0; bad_vals += nb;
+            }
+            printf("forward beside a co-running kernel (%s%s): %d of 20 runs differ from the run alone (%ld values, first in row %d)\n",
+                   (use_lds & 1) ? "holding LDS" : "no LDS", (use_lds & 2) ? ", every wait vmcnt(0)" : "", bad_runs, bad_vals, first_bad_row);
+        }
+        CK(hipFree(hog));
+    }
+    // ================================================================= weight gradient dW = X~^T . dH0
+    {
+        const int ldp = (K + 127) / 128 * 128, n_fr = ldp / 128;
+        std::vector<float> hxp((size_t)m * ldp, 0.f), hd((size_t)m * p);
+        for (int i = 0; i < m; i++) for (int k = 0; k < K; k++) hxp[(size_t)i * ldp + k] = hx[(size_t)i * ldx + k];
+        for (auto &v : hd) v = nd(rng) * 1e-3f;
+        float *dxp, *dd, *dslab, *ddw, *ddw2;
+        CK(hipMalloc(&dxp, hxp.size() * 4)); CK(hipMalloc(&dd, hd.size() * 4));
+        CK(hipMemcpy(dxp, hxp.data(), hxp.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dd, hd.data(), hd.size() * 4, hipMemcpyHostToDevice));
+        int S = (2 * n_cu) / n_fr; if (S < 1) S = 1;
+        int rps = ((m + S - 1) / S + 31) / 32 * 32; if (rps < 32) rps = 32;
+        S = (m + rps - 1) / rps;
+        CK(hipMalloc(&dslab, (size_t)S * K * p * 4)); CK(hipMalloc(&ddw, (size_t)K * p * 4)); CK(hipMalloc(&ddw2, (size_t)K * p * 4));
+        printf("weight gradient: %d feature ranges x %d row splits of %d rows\n", n_fr, S, rps);
+        // CPU reference on sampled outputs (every feature of a few columns)
+        auto check_dw = [&](const float *d_dw, const char *what, bool drop, float scale) {
+            std::vector<float> ho((size_t)K * p);
+            hipMemcpy(ho.data(), d_dw, ho.size() * 4, hipMemcpyDeviceToHost);
+            double worst = 0, sumsq = 0; long cnt = 0, nonfinite = 0;
+            for (auto v : ho) nonfinite += !std::isfinite(v);
+            if (nonfinite) printf("  !! %ld non-finite outputs\n", nonfinite);
+            const int cols[3] = {0, 77, 127};
+            for (int f = 0; f < K; f += (f < 40 || f > K - 40) ? 1 : 37) for (int c : cols) {
+                double ref = 0, mag = 0;
+                for (int i = 0; i < m; i++) {
+                    const size_t e = (size_t)i * K + f;
+                    const bool keep = !drop || ((hbits[e >> 5] >> (e & 31)) & 1);
+                    const double t = keep ? (double)hx[(size_t)i * ldx + f] * scale * (double)hd[(size_t)i * p + c] : 0.0;
+                    ref += t; mag += fabs(t);
+                }
+                const double u = fabs((double)ho[(size_t)f * p + c] - ref) / (1.1920929e-7 * (mag > 0 ? mag : 1));
+                worst = std::max(worst, u); sumsq += u * u; cnt++;
+            }
+            printf("  %-44s error vs float64: max %.4f, rms %.4f  (units of eps_f32 * sum|x dh|; parity bound 8)\n", what, worst, sqrt(sumsq / cnt));
+            if (m <= 20000) {                                      // small problems: every output, and a map of the bad 32 x 32 blocks
+                int bad[32][4] = {};
+                for (int f = 0; f < K; f++) for (int c = 0; c < p; c++) {
+                    double ref = 0, mag = 0;
+                    for (int i = 0; i < m; i++) {
+                        const size_t e = (size_t)i * K + f;
+                        const bool keep = !drop || ((hbits[e >> 5] >> (e & 31)) & 1);
+                        const double t = keep ? (double)hx[(size_t)i * ldx + f] * scale * (double)hd[(size_t)i * p + c] : 0.0;
+                        ref += t; mag += fabs(t);
+                    }
+                    if (fabs((double)ho[(size_t)f * p + c] - ref) > 8 * 1.1920929e-7 * mag) bad[f / 32][c / 32]++;
+                }
+                printf("    bad entries per (feature block, column block):");
+                for (int fb = 0; fb * 32 < K; fb++) printf(" [%d %d %d %d]", bad[fb][0], bad[fb][1], bad[fb][2], bad[fb][3]);
+                printf("\n");
+            }
+        };
+        // exact-f32 MFMA split tiles (the product's kernel since round 1)
+        for (int drop = 0; drop < 2; drop++) {
+            Tile128Args t;
+            t.x = dxp; t.ldx = ldp; t.w = dd; t.ldw = p; t.out = dslab; t.ldo = p; t.m = m; t.K = K; t.p = p;
+            t.bits = drop ? dbits : nullptr; t.scale = drop ? 2.f : 1.f; t.rows_per_split = rps; t.split0 = 0; t.relu = 0;
+            dim3 grid(S, (K + 127) / 128, 1);
+            const float ms = time_ms(iters, [&]() {
+                dense_bwd_t128_kernel<4, true><<<grid, 256>>>(t);
+                launch_slab_reduce(dslab, S, K, p, p, ddw2, p, 0);
+            });
+            CK(hipGetLastError());
+            printf("f32 MFMA split-tile weight gradient, dropout %d: %.4f ms  %.1f TF/s\n", drop, ms, 2.0 * m * K * p / ms / 1e9);
+            check_dw(ddw2, "f32 MFMA", drop, t.scale);
+        }
+        for (int drop = 0; drop < 2; drop++) {
+            Bx3BwdArgs b{dxp, ldp, dd, p, dslab, p, m, K, rps, 0, drop ? dbits : nullptr, drop ? 2.f : 1.f};
+            dim3 grid(n_fr, S);
+            const float ms = time_ms(iters, [&]() {
+                if (drop) dense_bwd_bf16x3_kernel<true, 6><<<grid, 256>>>(b); else dense_bwd_bf16x3_kernel<false, 6><<<grid, 256>>>(b);
+                launch_slab_reduce(dslab, S, K, p, p, ddw, p, 0);
+            });
+            CK(hipGetLastError());
+            printf("bf16x3 weight gradient, 6 plane products, dropout %d: %.4f ms  %.1f TF/s algorithmic\n", drop, ms, 2.0 * m * K * p / ms / 1e9);
+            check_dw(ddw, "bf16x3, 6 plane products", drop, b.scale);
+        }
     }
     return 0;
 }
