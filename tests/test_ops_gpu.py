@@ -925,7 +925,9 @@ def test_loss_final_reduction_in_the_launch_equals_the_second_launch(dev, n, c, 
                 want = ring.download()
                 assert np.array_equal(armed, want)
                 r = want[6 % 4, 2]
-                assert r[0] == got[0][0][0] and r[2] == got[0][1][0] and r[3] == rows.size and r[4] == 2.5 and r[5] == 6.0
+                # (the row is what THIS entry point reduced: on odd iterations got[] came from the row-list form, whose lanes
+                #  own other rows — the same terms in another order, a last bit apart now and then)
+                assert r[0] == res.download()[0] and abs(r[0] - got[0][0][0]) <= 4 * EPS * abs(r[0]) and r[2] == got[0][1][0] and r[3] == rows.size and r[4] == 2.5 and r[5] == 6.0
     finally:
         dev.set_option("xent_finalize", 0)
 
