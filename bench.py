@@ -461,6 +461,19 @@ def dense_leg(ds, hidden, device, iters=10):
             "mfma_busy_pmc": pmc}
 
 
+def first_layer_method(ds, hidden):
+    """how X.W1 and its weight gradient are summed in this run (DESIGN.md 4.1); the switches are HipGCNOptions::gemm
+    (HIPGCN_GEMM=f32|bf16x3) and the context option gemm_bf16x3 (GCNHIP_GEMM_BF16X3=0|1|2)"""
+    dense = ds["f_indptr"].size - 1 == ds["num_nodes"] and ds["f_val"].size == ds["num_nodes"] * ds["input_dim"]
+    if not dense:
+        return "sparse X: CSR / CSC row kernels, f32 FMA"
+    off = os.environ.get("HIPGCN_GEMM", "") == "f32" or os.environ.get("GCNHIP_GEMM_BF16X3", "") == "0"
+    if hidden == 128 and not off:
+        return ("bf16x3: f32 operands split exactly into three bf16 planes, six plane products on the bf16 MFMA pipe, f32 accumulate "
+                "(error within the f32 summation bound; GCNHIP_GEMM_BF16X3=0 selects the f32-MFMA kernels)")
+    return "f32 MFMA"
+
+
 # ----------------------------------------------------------------------------------------------- one rank
 def main():
     args = parse_args()
@@ -738,6 +751,7 @@ def main():
                        "graph_structure": graph_structure(ds),
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": schedule, "aggregation_slice_floats": slice_floats,
+                       "first_layer_products": first_layer_method(ds, args.hidden),
                        "eval_lane": "on" if lane_on else "off",
                        "overlap_exchange": "on" if overlap_on else "off",
                        "schedule": ("plain one-stream" if not (lane_on or overlap_on) else

@@ -106,6 +106,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_graph_scales": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]),
     "gcnhip_feat_scale_rows": (I, [P, P, P]),
     "gcnhip_xent_fwd_rows_scaled": (I, [P, P, I, P, I, P, P, I, I, I, I, I, P, P, P]),
+    "gcnhip_xent_from_row_terms": (I, [P, P, P, P, I, P, P]),
     "gcnhip_matmul_bwd_ex": (I, [P, P, I, P, I, P, I, P, I, P, I, I, I, I, F, P, I, P]),
     "gcnhip_graphsum_part": (I, [P, P, P, P, I, P, I, I, P, I, I, I, F, U64, P, U64, P]),
     "gcnhip_feat_create": (I, [P, C.POINTER(P), P, P, P, I, I]),

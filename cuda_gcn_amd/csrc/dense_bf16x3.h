@@ -17,15 +17,7 @@
 // The f32-MFMA kernels stay selectable (option gemm_bf16x3 = 0).
 #pragma once
 #include "dense_persist.h"
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-#define MFMA_BF16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a_), (b_), (c_), 0, 0, 0)
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#include "bf16x3_split.h"
 
 constexpr int BX_BK = 32;                                    // K per chunk of X (two MFMA k-steps of 16 = two half-items)
 constexpr int BX_BH_BYTES = 3 * 4 * 1024;                    // 12288: one k-step of W: [plane][column block][lane] x 16 bytes
@@ -45,30 +37,6 @@ constexpr int BX_SMEM = BX_NB * BX_BH_BYTES;                 // 122880
 // on the chip every load had landed long before its wait and all tests passed — beside a second kernel (the validation lane)
 // the X loads were slow, the wait fell through on the early DMA completions, and rows of garbage came out.  So a wait for an
 // operation of one kind allows only the number of YOUNGER OPERATIONS OF THE SAME KIND: operations of a kind do complete in order.
-
-// two f32 -> their bf16 roundings (one v_cvt_pk_bf16_f32) as a packed word
-__device__ __forceinline__ uint32_t bx_cvt2(float a, float b) {
-    const bf16x2_t h = __builtin_convertvector((float2_t){a, b}, bf16x2_t);
-    return __builtin_bit_cast(uint32_t, h);
-}
-// (a, b) -> word i of the three planes: a = hi + mid + lo exactly (see the header)
-__device__ __forceinline__ void bx_split2(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l) {
-    // (v_pk_add_f32 beside MFMAs is slower than two scalar subtractions: cdna guide, "anti-lever")
-    h = bx_cvt2(a, b);
-    float ra = a - __uint_as_float(h << 16);
-    asm("" : "+v"(ra));                                      // opaque: keeps hipcc from packing the two subtractions into v_pk_add_f32
-    const float rb = b - __uint_as_float(h & 0xFFFF0000u);
-    m = bx_cvt2(ra, rb);
-    float sa = ra - __uint_as_float(m << 16);
-    asm("" : "+v"(sa));
-    const float sb = rb - __uint_as_float(m & 0xFFFF0000u);
-    l = bx_cvt2(sa, sb);
-}
-struct BxPlanes { uint32_t w[3][4]; };                       // [plane][word]: 8 bf16 per plane
-__device__ __forceinline__ bf16x8 bx_plane(const BxPlanes &P, int p) {
-    const uint4 q = make_uint4(P.w[p][0], P.w[p][1], P.w[p][2], P.w[p][3]);
-    return __builtin_bit_cast(bf16x8, q);
-}
 
 // W[K x 128] (* scale) -> the forward's B image, one 12 KB block per k-step hs: 16-byte piece ((hs*3 + p)*4 + n)*64 + lane
 // holds plane p of W[k(hs, lane >> 5, j)][32 n + (lane & 31)], j = 0..7, where the MFMA's k slots are PERMUTED inside a

@@ -62,6 +62,12 @@ struct GsArgs {
     // factored coefficients (gcnhip_graphsum_ex): coef == NULL -> every edge counts 1 and the row's total is multiplied by
     // post[row] (NULL: by nothing) before the epilogue.  The input rows then hold dinv(col) * x.
     const float *post;
+    // loss epilogue (gcnhip_gs_loss, gcnhip.h): xe_truth == NULL -> off.  dim <= 64: one lane group holds the row.
+    const int32_t *xe_truth;
+    float *xe_grad; int xe_ld_grad; int xe_training;
+    float xe_count;
+    const float *xe_grad_scale;
+    float *xe_terms;
 };
 
 __device__ inline bool row_wanted(const GsArgs &a, int row) {
@@ -104,6 +110,90 @@ __device__ inline float4 relu_dropout4(float4 v, const GsArgs &a, int64_t r, int
         for (int i = 0; i < 4; i++) x[i] *= (bits >> i & 1u) ? a.scale : 0.f;   // module.cpp:216
     }
     return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+// ---- loss epilogue (gcnhip_gs_loss) ------------------------------------------------------------------------------------
+// The arithmetic of xent_lane_kernel (xent.hip; CrossEntropyLoss::forward, module.cpp:124-161), statement for statement,
+// on a row that sits in a wave's registers instead of in memory: max (order-free), exp of the shifted logits, their sum
+// LEFT TO RIGHT (v_readlane of column after column into a wave-uniform chain of adds: the reference's order and
+// xent_lane_kernel's), the loss term, the accuracy test, the gradient quad of each lane.  Same bits as the loss kernel run
+// on the stored row.
+// Layout A (vector kernel): lane l of group 0 holds columns 4l..4l+3 in z; every lane of the wave calls.
+template <int L>
+__device__ __forceinline__ void xent_row_epilogue4(const GsArgs &a, int row, float4 z, int lane, int l, int g, int col0) {
+#pragma clang fp contract(off)
+    const int t = a.xe_truth[row];                          // wave-uniform
+    const int nv4 = (a.dim + 3) >> 2;
+    float *gr = a.xe_grad ? a.xe_grad + (size_t)row * a.xe_ld_grad : nullptr;
+    if (t < 0) {                                            // not scored: zero gradient row, zero terms (module.cpp:129,132)
+        if (a.xe_training && gr && g == 0 && l < nv4) *reinterpret_cast<float4 *>(gr + col0) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) *reinterpret_cast<float2 *>(a.xe_terms + 2 * (size_t)row) = make_float2(0.f, 0.f);
+        return;
+    }
+    float x[4] = {z.x, z.y, z.z, z.w};
+    float mx = -1e30f;                                      // module.cpp:135
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (col0 + i < a.dim) mx = fmaxf(mx, x[i]);
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, WAVE));
+    mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));       // lane 0 is in group 0
+    const int ti = t & 3;
+    const float sel = ti == 0 ? x[0] : (ti == 1 ? x[1] : (ti == 2 ? x[2] : x[3]));
+    const float tv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sel), t >> 2));
+    const bool correct = !(mx > tv);                        // gcn.cpp:88-93
+    float ex[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        x[i] -= mx;                                         // module.cpp:140
+        ex[i] = col0 + i < a.dim ? expf(x[i]) : 0.f;
+    }
+    float se = 0.f;
+    for (int q = 0; q < nv4; q++) {                         // columns 4q .. 4q+3 live in lane q (group 0): left to right
+#pragma unroll
+        for (int i = 0; i < 4; i++) se += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex[i]), q));
+    }
+    const float term = logf(se) - (tv - mx);                // module.cpp:143
+    if (lane == 0) *reinterpret_cast<float2 *>(a.xe_terms + 2 * (size_t)row) = make_float2(term, correct ? 1.f : 0.f);
+    if (a.xe_training && gr && g == 0 && l < nv4) {
+        const float gs = a.xe_grad_scale ? a.xe_grad_scale[row] : 1.f;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float p = ex[i] / se;                           // module.cpp:147
+            if (col0 + i == t) p = (float)((double)p - 1.0);
+            o[i] = col0 + i < a.dim ? (a.xe_grad_scale ? (p / a.xe_count) * gs : p / a.xe_count) : 0.f;   // module.cpp:157
+        }
+        *reinterpret_cast<float4 *>(gr + col0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+// Layout B (finalize kernel, split rows): lane c of the block's first wave holds column c in v; that whole wave calls.
+__device__ __forceinline__ void xent_row_epilogue1(const GsArgs &a, int row, float v, int lane) {
+#pragma clang fp contract(off)
+    const int t = a.xe_truth[row];
+    const int nv4 = (a.dim + 3) >> 2;
+    float *gr = a.xe_grad ? a.xe_grad + (size_t)row * a.xe_ld_grad : nullptr;
+    if (t < 0) {
+        if (a.xe_training && gr && lane < 4 * nv4) gr[lane] = 0.f;
+        if (lane == 0) *reinterpret_cast<float2 *>(a.xe_terms + 2 * (size_t)row) = make_float2(0.f, 0.f);
+        return;
+    }
+    float mx = lane < a.dim ? fmaxf(-1e30f, v) : -1e30f;
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, WAVE));
+    const float tv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
+    const bool correct = !(mx > tv);
+    const float x = v - mx;
+    const float ex = lane < a.dim ? expf(x) : 0.f;
+    float se = 0.f;
+    for (int j = 0; j < 4 * nv4; j++) se += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), j));
+    const float term = logf(se) - (tv - mx);
+    if (lane == 0) *reinterpret_cast<float2 *>(a.xe_terms + 2 * (size_t)row) = make_float2(term, correct ? 1.f : 0.f);
+    if (a.xe_training && gr && lane < 4 * nv4) {
+        float p = ex / se;
+        if (lane == t) p = (float)((double)p - 1.0);
+        const float gs = a.xe_grad_scale ? a.xe_grad_scale[row] : 1.f;
+        gr[lane] = lane < a.dim ? (a.xe_grad_scale ? (p / a.xe_count) * gs : p / a.xe_count) : 0.f;
+    }
 }
 
 constexpr int GS_U = 4;        // row loads in flight per lane group when the table is cache resident (bf16 kernel: always)
@@ -288,6 +378,8 @@ __global__ __launch_bounds__(256) void graphsum_vec_kernel(GsArgs a) {
         }
         nib = ((acc.x > 0.f ? 1u : 0u) | (acc.y > 0.f ? 2u : 0u) | (acc.z > 0.f ? 4u : 0u) | (acc.w > 0.f ? 8u : 0u)) << (4 * (l & 7));
     }
+    if constexpr (!SLICED && L <= 16)
+        if (a.xe_truth) xent_row_epilogue4<L>(a, row, acc, lane, l, g, col0);     // wave-uniform; one column chunk (launch site)
     if (L >= 8 && a.pos_bits) {                             // wave-uniform; dim % 32 == 0 (launch site): 8 lanes hold one word
         nib |= __shfl_xor(nib, 1, WAVE);
         nib |= __shfl_xor(nib, 2, WAVE);
@@ -747,6 +839,7 @@ __global__ __launch_bounds__(256) void graphsum_finalize_kernel(GsArgs a, const 
             }
             a.out[(size_t)row * a.ld_out + col] = v;
         }
+        if (a.xe_truth && threadIdx.x < WAVE) xent_row_epilogue1(a, row, v, threadIdx.x);   // dim <= 64 (launch site): the first wave holds the row
         if (a.pos_bits) {                                   // 64 consecutive columns per wave: two words of the row
             const uint64_t b = __ballot(col < a.dim && v > 0.f);
             const int w0 = (c0 + (int)(threadIdx.x & ~63u)) >> 5;
@@ -809,7 +902,8 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
                          int dim, int fuse, int training, float p, uint64_t seed, const uint32_t *d_epoch,
                          uint64_t elem_offset, const uint8_t *keep_mask, const uint32_t *row_bits = nullptr,
                          const uint16_t *in_bf = nullptr, const uint32_t *out_bits = nullptr,
-                         const gcnhip_rowset *rs = nullptr, int accumulate = 0, uint32_t *pos_bits = nullptr, int wpr = 0, int scaling = 0) {
+                         const gcnhip_rowset *rs = nullptr, int accumulate = 0, uint32_t *pos_bits = nullptr, int wpr = 0, int scaling = 0,
+                         const gcnhip_gs_loss *loss = nullptr) {
     if (!c || !g || (!in && !in_bf) || !out || dim <= 0 || ld_in < dim || ld_out < dim) return -1;
     if (scaling < 0 || scaling > 3) return -1;
     if (accumulate && in_bf) return -1;                     // the bf16 kernel has no accumulating store
@@ -843,6 +937,16 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     a.post = nullptr;
     const int nt = a.n_tasks ? a.n_tasks : g->n_rows;
     const bool vec = (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in) && aligned16(out);
+    a.xe_truth = nullptr; a.xe_grad = nullptr; a.xe_ld_grad = 0; a.xe_training = 0; a.xe_count = 1.f; a.xe_grad_scale = nullptr; a.xe_terms = nullptr;
+    if (loss) {
+        const int w4 = (dim + 3) / 4 * 4;
+        if (in_bf || !vec || dim > 64 || fuse || pos_bits || !loss->truth || !loss->row_terms || loss->count <= 0 || ((uintptr_t)loss->row_terms & 7))
+            return gcnhip_fail("gcnhip_graphsum_ex: the loss epilogue needs f32 rows that are 16-byte aligned, dim <= 64, no relu_dropout, truth, row_terms and count > 0");
+        if (loss->training && (!loss->grad || loss->ld_grad < w4 || loss->ld_grad % 4 != 0 || !aligned16(loss->grad)))
+            return gcnhip_fail("gcnhip_graphsum_ex: the loss epilogue writes whole 16-byte quads of the gradient row: ld_grad % 4 == 0, ld_grad >= round_up(dim, 4)");
+        a.xe_truth = loss->truth; a.xe_grad = loss->training ? loss->grad : nullptr; a.xe_ld_grad = loss->ld_grad; a.xe_training = loss->training ? 1 : 0;
+        a.xe_count = (float)loss->count; a.xe_grad_scale = loss->grad_row_scale; a.xe_terms = loss->row_terms;
+    }
     if (scaling) {
         // the factored operator runs in the 16-byte-row f32 kernel only (what the model's layouts always are)
         if (in_bf || !vec) return gcnhip_fail("gcnhip_graphsum_ex: scaling != 0 needs f32 rows that are 16-byte aligned (ld % 4 == 0)");
@@ -876,7 +980,7 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     }
     const int gl = c->opt.gs_l;                             // narrower column slices than 64 floats (8: 32 floats, 4: 16 floats), round 5
     if (in_bf) {
-    } else if (vec && (gl == 8 || gl == 4) && dim % (gl * 4) == 0 && dim / (gl * 4) > 1 && 8 % (dim / (gl * 4)) == 0) {
+    } else if (vec && !loss && (gl == 8 || gl == 4) && dim % (gl * 4) == 0 && dim / (gl * 4) > 1 && 8 % (dim / (gl * 4)) == 0) {
         // More slices = a smaller share of the table per XCD's L2 (what a structure-free graph's hub rows need) against more
         // re-reads of the index stream and shorter requests.  Measured per graph (tools/exp_structure.py); never the default.
         if (gl == 8) launch_vec<8>(a, xb, c); else launch_vec<4>(a, xb, c);
@@ -967,7 +1071,7 @@ int gcnhip_graphsum_ex(gcnhip_ctx *c, const gcnhip_graph *g, const gcnhip_gs_opt
     if (o->pos_bits && !o->relu_dropout) return -1;
     return graphsum_impl(c, g, in, ld_in, out, ld_out, dim, o->relu_dropout ? 1 : 0, o->relu_dropout ? o->training : 0, o->relu_dropout ? o->p : 0.f,
                          o->seed, o->d_epoch, o->elem_offset, o->keep_mask, o->in_row_bits, nullptr, nullptr, o->rows, o->accumulate ? 1 : 0,
-                         o->pos_bits, o->words_per_row, o->scaling);
+                         o->pos_bits, o->words_per_row, o->scaling, o->loss);
 }
 
 #ifndef GCNHIP_EXPERIMENTS

@@ -5,6 +5,7 @@
 // weights): the small operand sits in LDS, the long one streams once through
 // exact-f32 MFMA tiles (dense_kernels.h).
 #include "dense_kernels.h"
+#include "class_bf16x3.h"
 
 extern "C" {
 
@@ -12,7 +13,32 @@ int gcnhip_matmul_fwd(gcnhip_ctx *c, const float *a, int lda, const float *b, in
                       float *cc, int ldc, int m, int n, int p) {
     if (!c || !a || !b || !cc || m < 0 || n <= 0 || p <= 0 || lda < n || ldb < p || ldc < p) return -1;
     if (m == 0) return 0;
+    // option gemm_bf16x3 (round 5): hidden width 128, at most 64 classes — the product from three bf16 planes per operand
+    if (c->opt.gemm_bf16x3 >= 1 && cls_fwd_fits(a, lda, cc, ldc, m, n, p)) return launch_class_fwd(c, a, lda, b, ldb, cc, ldc, m, p);
     return launch_rowstream(c, a, lda, b, ldb, 0, cc, ldc, m, n, p, nullptr, 0, 1.f);
+}
+
+// dA and dB of the class layer in one launch (class_bf16x3.h)
+static int launch_class_bwd(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb, const float *dc, int lddc, float *da, int ldda,
+                            float *db, int lddb, int m, int p, float scale, const uint32_t *bits, const float *rowscale) {
+    ClsBwdArgs k;
+    k.dz = dc; k.lddz = lddc; k.h1 = a; k.ldh = lda; k.w2 = b; k.ldw = ldb; k.da = da; k.ldda = ldda; k.bits = bits;
+    k.rowscale = rowscale; k.scale = scale; k.p_ld = (p + 3) / 4 * 4; k.m = m; k.p = p; k.n_rb = ceil_div(m, 32); k.n_ks = (p + 15) / 16;
+    int grid = ceil_div(k.n_rb, CLS_BWD_WAVES);
+    if (grid > c->n_cu) grid = c->n_cu;                      // one workgroup of 8 waves per CU, every wave keeps its share of dW2 in registers
+    const int rc = ensure_slab(c, (size_t)grid * 128 * k.p_ld * sizeof(float));
+    if (rc) return rc;
+    k.slab = c->slab;
+    static bool attr_set = false;                            // (per process; the attribute belongs to the function, not to a context)
+    if (!attr_set) {
+        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
+        attr_set = true;
+    }
+    class_bwd_bf16x3_kernel<<<grid, 512, CLS_BWD_LDS, c->stream>>>(k);
+    GCNHIP_LAUNCH_CHECK();
+    launch_slab_reduce(k.slab, grid, 128, p, k.p_ld, db, lddb, c->stream);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
 }
 
 static int matmul_bwd_impl(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb,
@@ -101,6 +127,8 @@ int gcnhip_matmul_bwd_ex(gcnhip_ctx *c, const float *a, int lda, const float *b,
         if (db) for (int j = 0; j < n; j++) GCNHIP_TRY(hipMemsetAsync(db + (size_t)j * lddb, 0, p * sizeof(float), c->stream));
         return 0;
     }
+    if (db && c->opt.gemm_bf16x3 >= 1 && cls_bwd_fits(a, lda, dc, lddc, da, ldda, pos_bits, words_per_row, m, n, p))
+        return launch_class_bwd(c, a, lda, b, ldb, dc, lddc, da, ldda, db, lddb, m, p, relu_dropout_scale, pos_bits, d_da_row_scale);
     if (db) {
         const int rc = launch_atb(c, a, lda, dc, lddc, db, lddb, m, n, p, 0, 0.f, 0, nullptr, 0, nullptr);
         if (rc) return rc;

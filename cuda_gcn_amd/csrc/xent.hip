@@ -18,6 +18,7 @@ struct XentArgs {
     const int32_t *d_count;    // else read here
     const int32_t *rows;       // optional: only these rows (all labelled) are visited, n_rows = their number
     const float *grad_row_scale; // optional: row r of grad is multiplied by grad_row_scale[r] (the factored aggregation wants dinv . dZ)
+    const float *terms;        // xent_terms_kernel: [2 * rows] {loss term, 1.f if correct} left by a loss epilogue (gcnhip_gs_loss)
     float *part_f;             // [blocks] loss partials
     int32_t *part_i;           // [blocks*2] {correct, total}
     // in-launch final reduction (xent_block_tail): the block that arrives last at `ticket` adds the partials in block order
@@ -269,6 +270,36 @@ __global__ __launch_bounds__(256) void xent_lane_kernel(XentArgs a) {
     xent_block_tail(a, bl, bc, bt);
 }
 
+// The end of xent_lane_kernel for rows whose loss term and accuracy flag already exist (the loss epilogue of the aggregation
+// that produced the logits, graphsum.hip): the same lane -> row assignment, the same per-lane order of additions, the same
+// block tail — the totals have the bits xent_lane_kernel would have produced from the stored logits.
+__global__ __launch_bounds__(256) void xent_terms_kernel(XentArgs a) {
+    __shared__ float sh_f[4];
+    __shared__ int sh_i[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float loss = 0.f;
+    int correct = 0, total = 0;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < a.n_rows; q += gridDim.x * 256) {
+        const int r = a.rows ? a.rows[q] : q;
+        if (a.truth[r] < 0) continue;
+        const float2 tm = *reinterpret_cast<const float2 *>(a.terms + 2 * (size_t)r);
+        total++;
+        if (tm.y != 0.f) correct++;
+        loss += tm.x;
+    }
+    loss = wave_sum(loss); correct = wave_sum_i(correct); total = wave_sum_i(total);
+    if (lane == 0) { sh_f[wave] = loss; sh_i[wave * 2] = correct; sh_i[wave * 2 + 1] = total; }
+    __syncthreads();
+    float bl = 0.f;
+    int bc = 0, bt = 0;
+    if (threadIdx.x == 0) {
+        bl = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
+        bc = sh_i[0] + sh_i[2] + sh_i[4] + sh_i[6];
+        bt = sh_i[1] + sh_i[3] + sh_i[5] + sh_i[7];
+    }
+    xent_block_tail(a, bl, bc, bt);
+}
+
 __global__ __launch_bounds__(256) void count_labelled_kernel(const int32_t *truth, int n, int32_t *part) {
     int c = 0;
     const int chunk = (n + gridDim.x - 1) / gridDim.x;
@@ -342,6 +373,19 @@ static int xent_launch(gcnhip_ctx *c, XentArgs a, float *d_result, int32_t *d_re
         GCNHIP_LAUNCH_CHECK();
         a.d_count = c->red_i + 8192;
     }
+    if (a.terms) {                                     // same grid as the lane-per-row kernel below
+        blocks = ceil_div(a.n_rows, 256);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        xent_terms_kernel<<<blocks, 256, 0, c->stream>>>(a);
+        GCNHIP_LAUNCH_CHECK();
+        if (!a.ticket) {
+            xent_finalize_kernel<<<1, 256, 0, c->stream>>>(a.part_f, a.part_i, blocks, d_result, d_result_i, a.acc_only);
+            GCNHIP_LAUNCH_CHECK();
+            if (record) return gcnhip_metrics_record(c, a.ring, a.ring_capacity, a.ring_slot, a.ring_epoch, d_result, nullptr, a.ring_sumsq);
+        }
+        return 0;
+    }
     // a lane per row when the rows are whole, aligned float4 pieces of at most 64 classes
     const int nv4 = (a.C + 3) / 4;
     const bool force_wave = c->opt.xent_wave != 0;                            // A/B aid
@@ -379,7 +423,7 @@ int gcnhip_xent_fwd(gcnhip_ctx *c, float *logits, int ld, float *grad, int ld_gr
     a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_rows; a.C = num_classes;
     a.training = training; a.shift = shift_in_place; a.acc_only = 0;
-    a.count = count; a.d_count = nullptr; a.rows = nullptr; a.grad_row_scale = nullptr;
+    a.count = count; a.d_count = nullptr; a.rows = nullptr; a.grad_row_scale = nullptr; a.terms = nullptr;
     return xent_launch(c, a, d_result, d_result_i);
 }
 
@@ -400,7 +444,19 @@ int gcnhip_xent_fwd_rows_scaled(gcnhip_ctx *c, float *logits, int ld, float *gra
     a.logits = logits; a.grad = training ? grad : nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = ld_grad; a.n_rows = n_listed; a.C = num_classes;
     a.training = training; a.shift = shift_in_place; a.acc_only = 0;
-    a.count = count; a.d_count = nullptr; a.rows = d_rows; a.grad_row_scale = d_grad_row_scale;
+    a.count = count; a.d_count = nullptr; a.rows = d_rows; a.grad_row_scale = d_grad_row_scale; a.terms = nullptr;
+    return xent_launch(c, a, d_result, d_result_i);
+}
+
+int gcnhip_xent_from_row_terms(gcnhip_ctx *c, const float *d_row_terms, const int32_t *truth, const int32_t *d_rows, int n_listed,
+                               float *d_result, int32_t *d_result_i) {
+    if (!c || !d_row_terms || !truth || !d_result || n_listed < 0 || ((uintptr_t)d_row_terms & 7)) return -1;
+    if (n_listed > 0 && !d_rows) return -1;
+    XentArgs a;
+    a.logits = nullptr; a.grad = nullptr; a.truth = truth;
+    a.ld = 0; a.ld_grad = 0; a.n_rows = n_listed; a.C = 1;
+    a.training = 0; a.shift = 0; a.acc_only = 0;
+    a.count = 1; a.d_count = nullptr; a.rows = d_rows; a.grad_row_scale = nullptr; a.terms = d_row_terms;
     return xent_launch(c, a, d_result, d_result_i);
 }
 
@@ -410,7 +466,7 @@ int gcnhip_accuracy(gcnhip_ctx *c, const float *logits, int ld, const int32_t *t
     XentArgs a;
     a.logits = const_cast<float *>(logits); a.grad = nullptr; a.truth = truth;
     a.ld = ld; a.ld_grad = 0; a.n_rows = n_rows; a.C = num_classes;
-    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr; a.rows = nullptr; a.grad_row_scale = nullptr;
+    a.training = 0; a.shift = 0; a.acc_only = 1; a.count = 1; a.d_count = nullptr; a.rows = nullptr; a.grad_row_scale = nullptr; a.terms = nullptr;
     return xent_launch(c, a, nullptr, d_result_i);
 }
 

@@ -74,6 +74,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
         (int)data->label.size() != params.num_nodes || (int)data->feature_index.indptr.size() != params.num_nodes + 1)
         throw GcnHipFailure(-1, "HipGCN: GCNData arrays do not match num_nodes");
     GCNHIP_CHECK(gcnhip_ctx_create(&env.ctx, opt.device, nullptr));
+    if (opt.gemm >= 0) GCNHIP_CHECK(gcnhip_ctx_set_option(env.ctx, "gemm_bf16x3", opt.gemm ? 2 : 0));   // HIPGCN_GEMM; else the library's default
     timers.reset(new DeviceTimers(env.ctx));
     timers->enabled = (flags & HIPGCN_TIMERS) != 0;
     env.timers = timers.get();
@@ -631,16 +632,24 @@ void HipGCN::build_modules() {
         modules.push_back(sm);
         modules.push_back(gs);
         modules.push_back(mm);
+        HipGraphSum *gs_logits = nullptr;
         {
             auto *gs = new HipGraphSum(&env, Z0, Z, graph, C);
             gs->bwd_row_bits = &bwd_bits; gs->bwd_graph = graph_bwd_out; gs->fwd_out_rows = &cur_out_rows;
             if (factored_) { gs->fwd_scaling = 1; gs->bwd_scaling = 3; }     // Z = dinv . sum(Z0') (the true logits); T = raw sum of dZ'
             wire_overlap(gs, true);
             modules.push_back(gs);
+            gs_logits = gs;
         }
         auto *ce = new HipCrossEntropyLoss(&env, Z, &cur_truth, &cur_count, d_result, d_result_i, C, false);
         ce->rows_list = &cur_rows; ce->rows_n = &cur_rows_n;
         if (factored_) GCNHIP_CHECK(gcnhip_graph_scales(graph, &ce->grad_row_scale, nullptr, nullptr, nullptr));   // dZ' = dinv . dZ
+        // the loss rides in the epilogue of the launch that produces the logits (f32 tables, at most 64 classes; the paths that
+        // cut that launch in two — exchange overlap — or gather bf16 tables keep the loss kernel: HipGraphSum::forward decides)
+        if (opt_.loss_epilogue && C <= 64 && !env.bf16_tables) {
+            ce->row_terms = dev_upload(env.ctx, std::vector<float>((size_t)2 * std::max(N, 1), 0.f).data(), (size_t)2 * std::max(N, 1));
+            gs_logits->loss = ce;
+        }
         modules.push_back(ce);
     }
 }
@@ -730,6 +739,7 @@ void HipGCN::build_eval_lane() {
     GCNHIP_CHECK(gcnhip_ctx_create(&L.env.ctx, /*device of the main context*/ device_, nullptr));
     GCNHIP_CHECK(gcnhip_ctx_set_corun(L.env.ctx, 1));           // the lane's kernels share the chip with the training pass
     if (slice_floats == 32) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gs_l", 8));   // as tuned on the training context
+    if (opt_.gemm >= 0) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gemm_bf16x3", opt_.gemm ? 2 : 0));
     L.timers.reset(new DeviceTimers(L.env.ctx));
     L.timers->enabled = timers->enabled;
     L.env.timers = L.timers.get();
@@ -785,10 +795,17 @@ void HipGCN::build_eval_lane() {
         L.modules.push_back(gs);
     }
     L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
-    { auto *gs = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C); gs->fwd_out_rows = &L.out_rows; if (factored_) gs->fwd_scaling = 1; L.modules.push_back(gs); }
+    auto *gs_logits = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C);
+    gs_logits->fwd_out_rows = &L.out_rows;
+    if (factored_) gs_logits->fwd_scaling = 1;
+    L.modules.push_back(gs_logits);
     {
         auto *ce = new HipCrossEntropyLoss(&L.env, L.Z.get(), &L.truth, &L.count, L.d_result, L.d_result_i, C, false);
         ce->rows_list = &L.rows; ce->rows_n = &L.rows_n;
+        if (opt_.loss_epilogue && C <= 64 && !L.env.bf16_tables) {     // as on the training context
+            ce->row_terms = dev_upload(L.env.ctx, std::vector<float>((size_t)2 * std::max(N, 1), 0.f).data(), (size_t)2 * std::max(N, 1));
+            gs_logits->loss = ce;
+        }
         L.modules.push_back(ce);
     }
     GCNHIP_CHECK(gcnhip_event_create_sync(&L.ev_weights));

@@ -88,6 +88,7 @@ struct HipGCNOptions {
     bool verbose = false;                 // HIPGCN_VERBOSE: where the model build's wall time goes, run-loop statistics (stderr)
     int exchange = -1;                    // HIPGCN_EXCHANGE: -1 unset, 0 auto (per graph), 1 allgather, 2 halo
     bool structure_groups = true;         // HIPGCN_NO_STRUCTURE_GROUPS clears: never search the graph for row groups
+    bool loss_epilogue = true;            // HIPGCN_NO_LOSS_EPILOGUE clears: the loss kernel reads the stored logits (round 4) instead of riding in the class-width aggregation's epilogue
     bool mask_bits = true;                // HIPGCN_NO_MASK_BITS clears: the Matmul backward re-reads H1 instead of one bit per element
     bool loss_records_metrics = true;     // HIPGCN_RECORD_LAUNCH clears: the metrics row gets a launch of its own (A/B)
     int bwd_chunks = 4;                   // HIPGCN_BWD_CHUNKS: row blocks of the opt-in backward pipeline

@@ -223,6 +223,8 @@ void HipGraphSum::forward(bool training) {
             } else {
                 o.rows = out_rows;
             }
+            gcnhip_gs_loss lo = {};
+            if (loss && fused_relu_dropout < 0.f && loss->epilogue_opts(training, &lo)) { o.loss = &lo; loss->terms_fresh = true; }
             GCNHIP_CHECK(gcnhip_graphsum_ex(env->ctx, graph, &o, src, in->ld, out->data, out->ld, dim));
         }
         if (dim > 64) env->timers->stop(TMR_GRAPHSUM_WIDE);
@@ -323,9 +325,21 @@ HipCrossEntropyLoss::HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32
     : env(env), logits(logits), truth(truth), count(count), d_result(d_result), d_result_i(d_result_i),
       num_classes(num_classes), shift_in_place(shift) {}
 
+HipCrossEntropyLoss::~HipCrossEntropyLoss() { if (row_terms) gcnhip_free(env->ctx, row_terms); }
+
+bool HipCrossEntropyLoss::epilogue_opts(bool training, gcnhip_gs_loss *o) const {
+    if (!row_terms || !rows_list || !*rows_list || *count <= 0 || num_classes > 64 || shift_in_place) return false;
+    o->truth = *truth; o->grad = logits->grad; o->ld_grad = logits->ld; o->training = training ? 1 : 0; o->count = *count;
+    o->grad_row_scale = grad_row_scale; o->row_terms = row_terms;
+    return true;
+}
+
 void HipCrossEntropyLoss::forward(bool training) {
     env->timers->start(TMR_LOSS_FW);
-    if (rows_list && *rows_list && *count > 0)
+    if (terms_fresh) {
+        terms_fresh = false;
+        GCNHIP_CHECK(gcnhip_xent_from_row_terms(env->ctx, row_terms, *truth, *rows_list, *rows_n, d_result, d_result_i));
+    } else if (rows_list && *rows_list && *count > 0)
         GCNHIP_CHECK(gcnhip_xent_fwd_rows_scaled(env->ctx, logits->data, logits->ld, logits->grad, logits->ld, *truth, *rows_list, *rows_n,
                                                  num_classes, training ? 1 : 0, *count, shift_in_place ? 1 : 0, d_result, d_result_i,
                                                  grad_row_scale));

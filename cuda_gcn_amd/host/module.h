@@ -113,6 +113,7 @@ public:
     void backward() override;
 };
 
+class HipCrossEntropyLoss;
 class HipGraphSum : public Module {
     HipEnv *env;
     HipVariable *in, *out;
@@ -121,6 +122,7 @@ class HipGraphSum : public Module {
     float fused_relu_dropout;       // >= 0: ReLU (+ dropout with this p when training) in the store epilogue
     uint64_t elem_offset;           // global element index of this rank's first output element
 public:
+    HipCrossEntropyLoss *loss = nullptr;            // the loss module that reads `out`: its arithmetic rides in this launch's epilogue
     gcnhip_graph *fwd_graph_replicated = nullptr;   // global column ids: forward reads a replicated `in` without a gather
     // multi-GPU, first layer: after a training forward publish bit = (out > 0) of this rank's rows to every rank;
     // in exchange backward() finds out->full_grad already complete (rebuilt locally) and gathers nothing
@@ -181,6 +183,14 @@ public:
     int32_t *const *rows_list = nullptr;
     const int *rows_n = nullptr;
     const float *grad_row_scale = nullptr;      // factored aggregation: the gradient rows leave multiplied by dinv of their row
+    // Loss epilogue (round 5, gcnhip_gs_loss): the aggregation that produces `logits` computes each scored row's loss term,
+    // accuracy flag and gradient row while the row is still in its wave's registers (HipGraphSum::loss points here and
+    // fills epilogue_opts()); forward() then only adds the terms — same bits as the loss kernel on the stored logits.
+    // row_terms: [2 x rows] floats owned by this module (NULL: the loss kernel reads the logits, as before).
+    float *row_terms = nullptr;
+    bool terms_fresh = false;                   // the producing launch of this forward wrote row_terms
+    bool epilogue_opts(bool training, gcnhip_gs_loss *o) const;   // false: not applicable (no row list, empty split)
+    ~HipCrossEntropyLoss() override;
     HipCrossEntropyLoss(HipEnv *env, HipVariable *logits, int32_t *const *truth, const int *count,
                         float *d_result, int32_t *d_result_i, int num_classes, bool shift_in_place);
     void forward(bool) override;

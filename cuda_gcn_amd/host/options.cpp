@@ -26,6 +26,7 @@ HipGCNOptions HipGCNOptions::from_environment(HipGCNOptions o) {
         o.exchange = !strcmp(e, "halo") ? 2 : (!strcmp(e, "allgather") ? 1 : (!strcmp(e, "auto") ? 0 : o.exchange));
     if (getenv("HIPGCN_NO_STRUCTURE_GROUPS")) o.structure_groups = false;
     if (getenv("HIPGCN_NO_MASK_BITS")) o.mask_bits = false;
+    if (getenv("HIPGCN_NO_LOSS_EPILOGUE")) o.loss_epilogue = false;
     if (getenv("HIPGCN_NO_SLICE_TUNING")) o.slice_tuning = false;
     if (getenv("HIPGCN_RECORD_LAUNCH")) o.loss_records_metrics = false;
     if (const char *e = getenv("HIPGCN_BWD_CHUNKS")) o.bwd_chunks = atoi(e);

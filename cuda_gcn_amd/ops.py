@@ -19,7 +19,13 @@ class GsOpts(C.Structure):
     """gcnhip_gs_opts (include/gcnhip.h)"""
     _fields_ = [("rows", C.c_void_p), ("in_row_bits", C.c_void_p), ("accumulate", C.c_int), ("relu_dropout", C.c_int), ("training", C.c_int),
                 ("p", C.c_float), ("seed", C.c_uint64), ("d_epoch", C.c_void_p), ("elem_offset", C.c_uint64), ("keep_mask", C.c_void_p),
-                ("pos_bits", C.c_void_p), ("words_per_row", C.c_int), ("scaling", C.c_int)]
+                ("pos_bits", C.c_void_p), ("words_per_row", C.c_int), ("scaling", C.c_int), ("loss", C.c_void_p)]
+
+
+class GsLoss(C.Structure):
+    """gcnhip_gs_loss (include/gcnhip.h)"""
+    _fields_ = [("truth", C.c_void_p), ("grad", C.c_void_p), ("ld_grad", C.c_int), ("training", C.c_int), ("count", C.c_int),
+                ("grad_row_scale", C.c_void_p), ("row_terms", C.c_void_p)]
 
 
 class GcnHipError(RuntimeError):
@@ -170,6 +176,43 @@ class Device:
         o.scaling = int(scaling)
         _ck(self.lib, self.lib.gcnhip_graphsum_ex(self.ctx, g.h, C.byref(o), xin.ptr, ld, out.ptr, ld, dim), "gcnhip_graphsum_ex")
         return out.download()[:, :dim]
+
+    def graphsum_loss(self, g: "Graph", x, scaling, truth, rows=None, training=True, grad_row_scale=None, ld=None, epilogue=True, grad_fill=0.0):
+        """the logits' aggregation followed by the loss over the labelled rows (truth >= 0), two ways:
+        epilogue=True : gcnhip_graphsum_ex with a gcnhip_gs_loss + gcnhip_xent_from_row_terms;
+        epilogue=False: gcnhip_graphsum_ex, then gcnhip_xent_fwd_rows_scaled on the stored logits.
+        returns dict(logits, grad, loss_sum, count, correct, total)"""
+        x = np.asarray(x, np.float32)
+        truth = np.ascontiguousarray(truth, np.int32)
+        dim = x.shape[1]
+        ld = ld or (dim + 3) // 4 * 4
+        xin = self.padded(x, ld)
+        out = self.buf(np.full((g.n_rows, ld), np.nan, np.float32))
+        gb = self.buf(np.full((g.n_rows, ld), grad_fill, np.float32))
+        listed = np.flatnonzero(truth >= 0).astype(np.int32)
+        tb, rb = self.buf(truth), self.buf(listed if listed.size else np.zeros(1, np.int32))
+        sb = self.buf(np.ascontiguousarray(grad_row_scale, np.float32)) if grad_row_scale is not None else None
+        res, resi = self.buf(np.zeros(4, np.float32)), self.buf(np.zeros(2, np.int32))
+        terms = self.buf(np.full((g.n_rows, 2), np.nan, np.float32))
+        count = max(int(listed.size), 1)
+        o = GsOpts()
+        o.rows = rows
+        o.scaling = int(scaling)
+        lo = GsLoss()
+        if epilogue:
+            lo.truth = tb.ptr; lo.grad = gb.ptr; lo.ld_grad = ld; lo.training = int(training); lo.count = count
+            lo.grad_row_scale = sb.ptr if sb else None
+            lo.row_terms = terms.ptr
+            o.loss = C.addressof(lo)
+        _ck(self.lib, self.lib.gcnhip_graphsum_ex(self.ctx, g.h, C.byref(o), xin.ptr, ld, out.ptr, ld, dim), "gcnhip_graphsum_ex")
+        if epilogue:
+            _ck(self.lib, self.lib.gcnhip_xent_from_row_terms(self.ctx, terms.ptr, tb.ptr, rb.ptr, int(listed.size), res.ptr, resi.ptr), "gcnhip_xent_from_row_terms")
+        else:
+            _ck(self.lib, self.lib.gcnhip_xent_fwd_rows_scaled(self.ctx, out.ptr, ld, gb.ptr, ld, tb.ptr, rb.ptr, int(listed.size), dim, int(training), count, 0,
+                                                               res.ptr, resi.ptr, sb.ptr if sb else None), "gcnhip_xent_fwd_rows_scaled")
+        r, ri = res.download(), resi.download()
+        return dict(logits=out.download()[:, :dim], grad=gb.download(), loss_sum=float(r[0]), count=float(r[1]), correct=int(ri[0]), total=int(ri[1]),
+                    res=r, terms=terms.download() if epilogue else None)
 
     def graphsum(self, g: "Graph", x, ld_in=None, ld_out=None, row_nonzero=None):
         x = np.asarray(x, np.float32)

@@ -249,7 +249,23 @@ typedef struct {
     uint32_t *pos_bits;                 /* NULL, or as gcnhip_graphsum_relu_dropout_bits (needs relu_dropout) */
     int words_per_row;
     int scaling;                        /* see above */
+    const struct gcnhip_gs_loss *loss;  /* NULL, or the loss epilogue below (round 5) */
 } gcnhip_gs_opts;
+/* Loss epilogue of the aggregation that produces the logits (round 5; CrossEntropyLoss::forward, src/seq/module.cpp:124-161,
+ * and GCN::get_accuracy, gcn.cpp:83-96, inside the launch that computes Z = A^.Z0).  After its shuffle reduce a wave holds
+ * the whole logit row (dim <= 64) in one lane group: max, sum of exp (left to right, the reference's order), the row's loss
+ * term, the accuracy test and — training — the gradient row (softmax - onehot) / count [* grad_row_scale[r]] are computed
+ * there; the launch writes `out` (the logits) as always, the gradient row, and row_terms[2r] = loss term, row_terms[2r+1] =
+ * 1.f when no logit is above the true one.  gcnhip_xent_from_row_terms then adds the terms of a row list in the order
+ * gcnhip_xent_fwd_rows adds them: same bits as that entry point on the stored logits, without reading the logits again.
+ * Rows with truth < 0 get a zero gradient row and zero terms.  Needs f32 rows, 16-byte aligned, dim <= 64, no relu_dropout. */
+typedef struct gcnhip_gs_loss {
+    const int32_t *truth;               /* [rows of out] */
+    float *grad; int ld_grad;           /* gradient rows (training != 0) */
+    int training, count;                /* as gcnhip_xent_fwd_rows (count > 0) */
+    const float *grad_row_scale;        /* NULL, or as gcnhip_xent_fwd_rows_scaled */
+    float *row_terms;                   /* [2 * rows of out] */
+} gcnhip_gs_loss;
 int gcnhip_graphsum_ex(gcnhip_ctx *ctx, const gcnhip_graph *g, const gcnhip_gs_opts *opts, const float *in, int ld_in,
                        float *out, int ld_out, int dim);
 /* device pointers of the factor arrays of a prepared adjacency: dinv / dinv^2 per row ([n_rows]) and per column ([n_cols]);
@@ -442,6 +458,11 @@ int gcnhip_xent_fwd_rows(gcnhip_ctx *ctx, float *logits, int ld, float *grad, in
 int gcnhip_xent_fwd_rows_scaled(gcnhip_ctx *ctx, float *logits, int ld, float *grad, int ld_grad,
                                 const int32_t *truth, const int32_t *d_rows, int n_listed, int num_classes, int training,
                                 int count, int shift_in_place, float *d_result, int32_t *d_result_i, const float *d_grad_row_scale);
+/* The end of gcnhip_xent_fwd_rows from the per-row terms a loss epilogue left (gcnhip_gs_loss above): d_result / d_result_i
+ * exactly as gcnhip_xent_fwd_rows(_scaled) would have written them from the stored logits (same per-lane order, same block
+ * partials, same final reduction — bit for bit), an armed metrics record included. */
+int gcnhip_xent_from_row_terms(gcnhip_ctx *ctx, const float *d_row_terms, const int32_t *truth, const int32_t *d_rows, int n_listed,
+                               float *d_result, int32_t *d_result_i);
 /* accuracy alone (cuda_gcn.cu:100-120 without the 38 MB D2H) */
 int gcnhip_accuracy(gcnhip_ctx *ctx, const float *logits, int ld, const int32_t *truth,
                     int n_rows, int num_classes, int32_t *d_result_i);

@@ -472,6 +472,58 @@ def test_structure_groups_schedule_is_bit_identical():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name", ["reddit-mini-h0", "reddit-mini-h03", "reddit-mini-zipf"])
+def test_structure_variants_trace_vs_oracle(oracle, name):
+    """the Reddit shape WITHOUT the planted structure the headline graph has (datagen.REDDIT_VARIANTS: no label homophily,
+    weak homophily, Zipf class sizes): the schedule and the slice width HipGCN picks differ from the headline's, the
+    numbers do not — trace against the oracle with the reference's dropout stream replayed, in the narrow-slice form the
+    rule picks and in the headline's 64-float form (8 instead of 4 partial sums per row: another summation order)"""
+    from cuda_gcn_amd.model import HipGCNModel, HOST_MASKS
+    ds = datagen.make_dataset(name)
+    want, _, om = oracle_trace(oracle, ds, 5, 4, hidden_dim=128, dropout=0.5)
+    om.close()
+    m = HipGCNModel(ds, seed=5, flags=HOST_MASKS, hidden_dim=128, dropout=0.5, epochs=4)
+    assert m.slice_floats() in (32, 64)
+    if name.endswith("-h0"):
+        assert m.slice_floats() == 32 and not m.schedule().startswith("label")
+    got = np.array([m.train_epoch() + m.eval(2) for _ in range(4)], np.float32)
+    check_trace(got, want, ds)
+    w = m.var(2).copy()
+    m.close()
+    os.environ["HIPGCN_NO_SLICE_TUNING"] = "1"
+    try:
+        b = HipGCNModel(ds, seed=5, flags=HOST_MASKS, hidden_dim=128, dropout=0.5, epochs=4)
+    finally:
+        del os.environ["HIPGCN_NO_SLICE_TUNING"]
+    assert b.slice_floats() == 64
+    gb = np.array([b.train_epoch() + b.eval(2) for _ in range(4)], np.float32)
+    check_trace(gb, want, ds)
+    assert np.allclose(b.var(2), w, rtol=0, atol=1e-4)
+    b.close()
+
+
+@pytest.mark.parametrize("name,hidden,lane", [("reddit-mini", 128, False), ("reddit-mini", 128, True), ("cora-syn", 16, False)])
+def test_loss_epilogue_is_bit_identical_to_the_loss_kernel(name, hidden, lane):
+    """the loss riding in the epilogue of the class-width aggregation (default) against the loss kernel reading the stored
+    logits (HIPGCN_NO_LOSS_EPILOGUE): every reported number and every weight, bit for bit"""
+    from cuda_gcn_amd.model import HipGCNModel, EVAL_LANE, NO_EVAL_LANE
+    ds = datagen.make_dataset(name)
+    fl = EVAL_LANE if lane else NO_EVAL_LANE
+    a = HipGCNModel(ds, seed=9, flags=fl, hidden_dim=hidden, dropout=0.5, epochs=8)
+    os.environ["HIPGCN_NO_LOSS_EPILOGUE"] = "1"
+    try:
+        b = HipGCNModel(ds, seed=9, flags=fl, hidden_dim=hidden, dropout=0.5, epochs=8)
+    finally:
+        del os.environ["HIPGCN_NO_LOSS_EPILOGUE"]
+    ta, tb = a.run_epochs(6), b.run_epochs(6)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert a.train_epoch() == b.train_epoch()
+    for s in (2, 3, 1):
+        assert a.eval(s) == b.eval(s)
+    assert np.array_equal(a.var(2), b.var(2)) and np.array_equal(a.var(5), b.var(5))
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""

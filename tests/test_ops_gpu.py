@@ -188,6 +188,51 @@ def test_factored_operator_vs_oracle(dev, oracle, gname, dim):
     ga.free(); gb.free(); g.free()
 
 
+@pytest.mark.parametrize("gname", ["cora-syn", "hub"])
+@pytest.mark.parametrize("dim", [41, 7, 64, 3, 16])
+def test_loss_epilogue_of_the_logit_aggregation(dev, oracle, gname, dim):
+    """gcnhip_gs_loss: the loss term, accuracy flag and gradient row of a scored row computed in the epilogue of the launch that
+    aggregates its logits (+ gcnhip_xent_from_row_terms) — the same BITS as the loss kernel run afterwards on the stored
+    logits (gcnhip_xent_fwd_rows_scaled), which the tests above hold to CrossEntropyLoss::forward (module.cpp:124-161):
+    logits, every gradient row, loss sum, counts; training and evaluation; row subset and all rows; split rows (hub graph);
+    with and without the factored aggregation's gradient row factor; and the loss against the oracle's on the same logits"""
+    gp, gi = hub_graph() if gname == "hub" else (lambda d: (d["g_indptr"], d["g_indices"]))(datagen.make_dataset(gname))
+    n = gp.size - 1
+    g = dev.graph(gp, gi)
+    dr = g.scales()[0]
+    rng = np.random.default_rng(dim + n)
+    x = (rng.standard_normal((n, dim)) * 3).astype(np.float32)
+    xs = (x * dr[:, None]).astype(np.float32)
+    truth = rng.integers(0, dim, n).astype(np.int32)
+    truth[rng.random(n) < 0.4] = -1
+    truth[np.argmax(np.diff(gp))] = 1 % dim                      # the heaviest row (a split row on the hub graph) is scored
+    scored = truth >= 0
+    rs = g.add_rowset(scored)
+    for training in (True, False):
+        for rows, scale in ((rs, dr), (rs, None), (None, dr)):
+            a = dev.graphsum_loss(g, xs, 1, truth, rows=rows, training=training, grad_row_scale=scale, epilogue=True, grad_fill=7.0)
+            b = dev.graphsum_loss(g, xs, 1, truth, rows=rows, training=training, grad_row_scale=scale, epilogue=False, grad_fill=7.0)
+            assert np.array_equal(a["logits"][scored].view(np.uint32), b["logits"][scored].view(np.uint32))
+            assert np.array_equal(a["res"].view(np.uint32), b["res"].view(np.uint32)), (a["res"], b["res"])
+            assert (a["correct"], a["total"]) == (b["correct"], b["total"]) and a["total"] == int(scored.sum())
+            w4 = (dim + 3) // 4 * 4
+            ga, gb_ = a["grad"], b["grad"]
+            if training:
+                assert np.array_equal(ga[scored][:, :w4].view(np.uint32), gb_[scored][:, :w4].view(np.uint32))
+            else:
+                assert np.all(ga == 7.0)
+            if rows is not None:
+                assert np.all(ga[~scored] == 7.0)                 # rows outside the subset: untouched
+            elif training:
+                assert np.all(ga[~scored][:, :w4] == 0.0)         # computed but not scored: zero gradient row
+    # the loss itself against the reference's arithmetic on the same logits
+    z = a["logits"].astype(np.float64)
+    zs = z[scored] - z[scored].max(1, keepdims=True)
+    want = float((np.log(np.exp(zs).sum(1)) - zs[np.arange(zs.shape[0]), truth[scored]]).sum())
+    assert abs(a["loss_sum"] - want) <= 1e-5 * max(1.0, abs(want)) * 4
+    g.free()
+
+
 @pytest.mark.parametrize("n,F,p", [(1000, 602, 128), (700, 64, 16), (513, 100, 41)])
 def test_aggregate_first_evaluation_form(dev, oracle, n, F, p):
     """gcnhip_feat_create_aggregated + gcnhip_spmm_fwd_relu: ReLU((A^.X).W) against the reference's order
