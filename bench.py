@@ -474,6 +474,15 @@ def first_layer_method(ds, hidden):
     return "f32 MFMA"
 
 
+def class_layer_method(ds, hidden):
+    """how H1.W2, dH1 and dW2 are summed in this run (csrc/class_bf16x3.h)"""
+    off = os.environ.get("HIPGCN_GEMM", "") == "f32" or os.environ.get("GCNHIP_GEMM_BF16X3", "") == "0"
+    if hidden == 128 and ds["output_dim"] <= 64 and ds["num_nodes"] >= 2048 and not off:
+        return ("bf16x3 (as the first layer): H1.W2 in one launch, dH1 + dW2 fused in one launch + a slab sum; "
+                "loss, accuracy and gradient rows in the epilogue of the class-width aggregation")
+    return "f32 MFMA row-stream kernels; loss in the epilogue of the class-width aggregation"
+
+
 # ----------------------------------------------------------------------------------------------- one rank
 def main():
     args = parse_args()
@@ -752,6 +761,7 @@ def main():
                        "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                        "train_nodes": n_lab, "aggregation_schedule": schedule, "aggregation_slice_floats": slice_floats,
                        "first_layer_products": first_layer_method(ds, args.hidden),
+                       "class_layer_products": class_layer_method(ds, args.hidden),
                        "eval_lane": "on" if lane_on else "off",
                        "overlap_exchange": "on" if overlap_on else "off",
                        "schedule": ("plain one-stream" if not (lane_on or overlap_on) else

@@ -39,3 +39,23 @@ __device__ __forceinline__ bf16x8 bx_plane(const BxPlanes &P, int p) {
     return __builtin_bit_cast(bf16x8, q);
 }
 
+
+// ---- vector-memory loads as inline asm (one hand-kept count covers them; hipcc neither sees nor moves nor waits for them) -----
+// Rules measured in round 5 (dense_bf16x3.h, "COUNTED WAITS"): `s_waitcnt vmcnt(N)` before the use of a load is safe when N is
+// the number of YOUNGER LOADS of this wave (stores and LDS-DMA pieces, older or younger, may be ignored: they are in the count
+// on both sides); the destination registers of a load must be tied ("+v") to the wait that precedes their first use — and, for
+// loads whose data is never used, to a final vmcnt(0) — or hipcc reuses them while the load is in flight.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 bx_make_rsrc(const void *p, uint32_t bytes) {
+    const uint64_t q = (uint64_t)(uintptr_t)p;
+    return (u32x4){(uint32_t)q, (uint32_t)(q >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+// dst = 4 bytes at rsrc.base + voff + soff; past the descriptor's byte count: 0
+__device__ __forceinline__ void bx_bload4(float &dst, uint32_t voff, u32x4 rsrc, uint32_t soff) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// dst = 16 bytes at rsrc.base + voff + OFF (OFF < 4096)
+template <int OFF>
+__device__ __forceinline__ void bx_bload16(f32x4 &dst, uint32_t voff, u32x4 rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+}

@@ -53,13 +53,24 @@ __device__ __forceinline__ void cls_lds_put(uint4 *img, int piece, int lane, con
 
 // ------------------------------------------------------------------------------------------------------------ forward
 struct ClsFwdArgs {
-    const float *h1; int ldh;        // [m x 128], 16-byte aligned rows
+    const float *h1; int ldh;        // [m x 128], 16-byte aligned rows; m * ldh * 4 < 2^32 (buffer loads)
     const float *w2; int ldw;        // [128 x p]
     float *z0; int ldz;              // [m x p], 16-byte aligned rows; padding columns are not written
     int m, p, n_rb;                  // n_rb = ceil(m / 32)
 };
 constexpr int CLS_FWD_LDS = 8 * 2 * 3 * 1024;               // pieces (k-step s, class block cb): W2^T as the A operand
 
+#define CLS_WAIT2(N, x, y) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x), "+v"(y) :: "memory")
+template <int S>
+__device__ __forceinline__ void cls_fwd_issue(f32x4 (&R)[16], uint32_t vo, u32x4 rs) {
+    bx_bload16<64 * S>(R[2 * S], vo, rs);
+    bx_bload16<64 * S + 16>(R[2 * S + 1], vo, rs);
+}
+
+// A wave keeps the 16 row loads of ONE row block in flight at all times: the two loads of k-step s of the next block are issued
+// the moment this block's k-step s has been taken out of its registers, so every wait sees exactly 14 younger loads.  (As plain
+// C++ loads hipcc issued each k-step's pair right before its use and waited: eight dependent round trips per block, 49 us.)
+template <int ABL>
 __global__ __launch_bounds__(256) void class_fwd_bf16x3_kernel(ClsFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 cls_img[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
@@ -77,66 +88,85 @@ __global__ __launch_bounds__(256) void class_fwd_bf16x3_kernel(ClsFwdArgs a) {
         cls_lds_put(cls_img, s * 2 + cb, ln, v);
     }
     __syncthreads();
-    for (int rb = blockIdx.x * 4 + wave; rb < a.n_rb; rb += gridDim.x * 4) {
-        const int row = rb * 32 + li;
-        const float *hp = a.h1 + (size_t)min(row, a.m - 1) * a.ldh + 8 * hh;     // rows past m compute on a copy of the last row and store nothing
-        float4 raw[16];
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            raw[2 * s] = *reinterpret_cast<const float4 *>(hp + 16 * s);
-            raw[2 * s + 1] = *reinterpret_cast<const float4 *>(hp + 16 * s + 4);
-        }
+    const u32x4 rs_h = bx_make_rsrc(a.h1, (uint32_t)a.m * (uint32_t)a.ldh * 4u);      // rows past m read as zero and store nothing
+    const int stride = gridDim.x * 4;
+    int rb = blockIdx.x * 4 + wave;
+    auto voff = [&](int b) { return ((uint32_t)(b * 32 + li) * (uint32_t)a.ldh + 8u * hh) * 4u; };
+    f32x4 R[16];
+    {
+        const uint32_t vo = voff(rb);
+        cls_fwd_issue<0>(R, vo, rs_h); cls_fwd_issue<1>(R, vo, rs_h); cls_fwd_issue<2>(R, vo, rs_h); cls_fwd_issue<3>(R, vo, rs_h);
+        cls_fwd_issue<4>(R, vo, rs_h); cls_fwd_issue<5>(R, vo, rs_h); cls_fwd_issue<6>(R, vo, rs_h); cls_fwd_issue<7>(R, vo, rs_h);
+    }
+    for (; rb < a.n_rb; rb += stride) {
+        const uint32_t vn = voff(rb + stride);               // past the last block: past the descriptor, zeros, never used
         f32x16 acc[2];
 #pragma unroll
         for (int cb = 0; cb < 2; cb++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const float v[8] = {raw[2 * s].x, raw[2 * s].y, raw[2 * s].z, raw[2 * s].w, raw[2 * s + 1].x, raw[2 * s + 1].y, raw[2 * s + 1].z, raw[2 * s + 1].w};
-            const ClsB3 B = cls_planes(v);
-#pragma unroll
-            for (int cb = 0; cb < 2; cb++) cls_mac(acc[cb], cls_lds(cls_img, s * 2 + cb, lane), B);
+#define CLS_FWD_STEP(S)                                                                                                      \
+        {                                                                                                                    \
+            CLS_WAIT2(14, R[2 * S], R[2 * S + 1]);                                                                           \
+            const float v[8] = {R[2 * S][0], R[2 * S][1], R[2 * S][2], R[2 * S][3], R[2 * S + 1][0], R[2 * S + 1][1], R[2 * S + 1][2], R[2 * S + 1][3]}; \
+            cls_fwd_issue<S>(R, vn, rs_h);                                                                                   \
+            if constexpr (ABL & 1) { acc[0][S] += v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; }                      \
+            else {                                                                                                           \
+                const ClsB3 B = cls_planes(v);                                                                               \
+                cls_mac(acc[0], B, cls_lds(cls_img, S * 2, lane));                                                           \
+                if (a.p > 32) cls_mac(acc[1], B, cls_lds(cls_img, S * 2 + 1, lane));                                         \
+            }                                                                                                                \
         }
-        if (row < a.m) {
-            float *zp = a.z0 + (size_t)row * a.ldz;
+        CLS_FWD_STEP(0) CLS_FWD_STEP(1) CLS_FWD_STEP(2) CLS_FWD_STEP(3) CLS_FWD_STEP(4) CLS_FWD_STEP(5) CLS_FWD_STEP(6) CLS_FWD_STEP(7)
+#undef CLS_FWD_STEP
+        // D[row = (r & 3) + 8 (r >> 2) + 4 hh][class = 32 cb + li]: a store instruction writes 32 consecutive classes of two rows
+        if (!(ABL & 2) || acc[0][0] == 123.456f) {
 #pragma unroll
             for (int cb = 0; cb < 2; cb++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int c0 = 32 * cb + 8 * q + 4 * hh;
-                    if (c0 + 4 <= a.p) {
-                        *reinterpret_cast<float4 *>(zp + c0) = make_float4(acc[cb][4 * q], acc[cb][4 * q + 1], acc[cb][4 * q + 2], acc[cb][4 * q + 3]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) if (c0 + i < a.p) zp[c0 + i] = acc[cb][4 * q + i];
-                    }
+                for (int r = 0; r < 16; r++) {
+                    const int orow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, c = 32 * cb + li;
+                    if (orow < a.m && c < a.p) a.z0[(size_t)orow * a.ldz + c] = acc[cb][r];
                 }
         }
     }
+    // the loads issued for the block after the last: their registers stay allocated until they have landed
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) CLS_WAIT2(0, R[i], R[i + 1]);
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
 struct ClsBwdArgs {
-    const float *dz; int lddz;       // dZ0 [m x p], 16-byte aligned rows, lddz >= 16 ceil(p / 16) (whole k-steps are read)
-    const float *h1; int ldh;        // H1 [m x 128]
+    const float *dz; int lddz;       // dZ0 [m x p], 16-byte aligned rows, lddz >= 16 ceil(p / 16) (whole k-steps are read); m * lddz * 4 < 2^32
+    const float *h1; int ldh;        // H1 [m x 128]; m * ldh * 4 < 2^32
     const float *w2; int ldw;        // W2 [128 x p]
     float *da; int ldda;             // dH1 [m x 128], 16-byte aligned rows
     const uint32_t *bits;            // bit (f & 31) of bits[r * 4 + (f >> 5)] = (H1[r, f] > 0); 16-byte aligned
     const float *rowscale; float scale;   // dH1[r, :] = mask . (scale * rowscale[r]) . (...)   (rowscale may be NULL)
     float *slab; int p_ld;           // dW2 partials [gridDim.x][128][p_ld]
-    int m, p, n_rb, n_ks;            // n_ks = ceil(p / 16) <= 4
+    int m, p, n_rb;
 };
-constexpr int CLS_BWD_WAVES = 8;
+constexpr int CLS_BWD_PAIRS = 4;                            // wave pairs per workgroup: a pair shares a row block, each wave takes two of the four feature blocks
 constexpr int CLS_BWD_IMG = 4 * 4 * 3 * 1024;               // pieces (k-step s < 4, feature block fb): W2 as the A operand of dH1^T
 constexpr int CLS_BWD_LDS = CLS_BWD_IMG + 128 * 64 * 4;     // + the workgroup's sum of dW2
 
+struct ClsCol { float z[2][8], h[2][8]; };                  // one k-step of 16 rows, column-wise: dZ0 (class blocks 0, 1) and H1 (this wave's two feature blocks)
+#define CLS_TIE8(x) "+v"((x)[0]), "+v"((x)[1]), "+v"((x)[2]), "+v"((x)[3]), "+v"((x)[4]), "+v"((x)[5]), "+v"((x)[6]), "+v"((x)[7])
+// N (a compile-time constant) = the number of loads this wave has issued AFTER the ones waited for — never more
+#define CLS_WAIT_COL(N, c) asm volatile("s_waitcnt vmcnt(%32)" : CLS_TIE8((c).z[0]), CLS_TIE8((c).z[1]), CLS_TIE8((c).h[0]), CLS_TIE8((c).h[1]) : "n"(N) : "memory")
+
+// NKS = ceil(p / 16) k-steps of classes.  Vector-memory loads of a row block, in issue order (all inline asm):
+//   L1(b): 2 NKS row pieces of dZ0, the row's 4 mask words, its factor   (2 NKS + 2 loads)   — issued during block b-1
+//   C0(b): k-step 0 column-wise: 16 + 16 dwords                          (32)                — issued at the top of block b
+//   C1(b): k-step 1, into C0's registers once those are planes            (32)
+template <int NKS, int ABL = 0>
 __global__ __launch_bounds__(512) void class_bwd_bf16x3_kernel(ClsBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 cls_img[];
     float *red = reinterpret_cast<float *>(cls_img) + CLS_BWD_IMG / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int pair = wave >> 1, half = wave & 1;
     // A[i = feature][k = class]: piece (s, fb) of lane ln holds W2[32 fb + (ln & 31)][16 s + 8 (ln >> 5) + j], j = 0..7 (classes past p: zero)
-    for (int idx = threadIdx.x; idx < a.n_ks * 4 * 64; idx += 512) {
+    for (int idx = threadIdx.x; idx < NKS * 4 * 64; idx += 512) {
         const int ln = idx & 63, fb = (idx >> 6) & 3, s = idx >> 8;
         const int f = 32 * fb + (ln & 31), c0 = 16 * s + 8 * (ln >> 5);
         float v[8];
@@ -149,95 +179,143 @@ __global__ __launch_bounds__(512) void class_bwd_bf16x3_kernel(ClsBwdArgs a) {
     for (int i = threadIdx.x; i < 128 * 64; i += 512) red[i] = 0.f;
     __syncthreads();
 
-    f32x16 dw[4][2];                                         // dW2[32 fb + ..][32 cb + li]: this wave's rows
+    const u32x4 rs_z = bx_make_rsrc(a.dz, (uint32_t)a.m * (uint32_t)a.lddz * 4u);    // rows past m read as zero: they add nothing to dW2
+    const u32x4 rs_h = bx_make_rsrc(a.h1, (uint32_t)a.m * (uint32_t)a.ldh * 4u);
+    const u32x4 rs_b = bx_make_rsrc(a.bits, (uint32_t)a.m * 16u);
+    const u32x4 rs_s = bx_make_rsrc(a.rowscale ? a.rowscale : a.dz, a.rowscale ? (uint32_t)a.m * 4u : 0u);   // no factors: every load is out of range = 0
+    uint32_t so_z[8], so_h[8];                               // row j of a lane's eight: scalar byte offsets
 #pragma unroll
-    for (int fb = 0; fb < 4; fb++)
+    for (int j = 0; j < 8; j++) { so_z[j] = (uint32_t)j * (uint32_t)a.lddz * 4u; so_h[j] = (uint32_t)j * (uint32_t)a.ldh * 4u; }
+
+    f32x4 Z[2 * NKS];                                        // L1: this lane's row of dZ0, 8 floats per k-step
+    f32x4 KB;                                                // the row's four mask words
+    float RSC;                                               // its factor
+    auto issue_l1 = [&](int b) __attribute__((always_inline)) {
+        const uint32_t row = (uint32_t)(b * 32 + li);
+        const uint32_t vz = (row * (uint32_t)a.lddz + 8u * hh) * 4u;
+        bx_bload16<0>(Z[0], vz, rs_z); bx_bload16<16>(Z[1], vz, rs_z);
+        if constexpr (NKS > 1) { bx_bload16<64>(Z[2], vz, rs_z); bx_bload16<80>(Z[3], vz, rs_z); }
+        if constexpr (NKS > 2) { bx_bload16<128>(Z[4], vz, rs_z); bx_bload16<144>(Z[5], vz, rs_z); }
+        if constexpr (NKS > 3) { bx_bload16<192>(Z[6], vz, rs_z); bx_bload16<208>(Z[7], vz, rs_z); }
+        bx_bload16<0>(KB, row * 16u, rs_b);
+        bx_bload4(RSC, row * 4u, rs_s, 0u);
+    };
+    constexpr int NL1 = 2 * NKS + 2;
+    ClsCol Cc;
+    auto issue_col = [&](int b, int s2) __attribute__((always_inline)) {
+        const uint32_t r0 = (uint32_t)(b * 32 + 16 * s2 + 8 * hh);
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+            const uint32_t c = 32u * cb + li;
+            // classes past the row's allocation must not be read as the next row's: they are sent past the descriptor (zero)
+            const uint32_t vo = c < (uint32_t)a.lddz ? (r0 * (uint32_t)a.lddz + c) * 4u : 0xFFFFF000u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) bx_bload4(Cc.z[cb][j], vo, rs_z, so_z[j]);
+        }
+#pragma unroll
+        for (int f2 = 0; f2 < 2; f2++) {
+            const uint32_t vo = (r0 * (uint32_t)a.ldh + 32u * (2 * half + f2) + li) * 4u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) bx_bload4(Cc.h[f2][j], vo, rs_h, so_h[j]);
+        }
+    };
+
+    f32x16 dw[2][2];                                         // dW2[32 (2 half + f2) + ..][32 cb + li]: this wave's share over its row blocks
+#pragma unroll
+    for (int f2 = 0; f2 < 2; f2++)
 #pragma unroll
         for (int cb = 0; cb < 2; cb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) dw[fb][cb][r] = 0.f;
+            for (int r = 0; r < 16; r++) dw[f2][cb][r] = 0.f;
 
-    for (int rb = blockIdx.x * CLS_BWD_WAVES + wave; rb < a.n_rb; rb += gridDim.x * CLS_BWD_WAVES) {
-        const int row0 = rb * 32, row = row0 + li;
-        const bool live = row < a.m;
-        const size_t rc = (size_t)min(row, a.m - 1);
+    const int stride = gridDim.x * CLS_BWD_PAIRS;
+    int rb = blockIdx.x * CLS_BWD_PAIRS + pair;
+    issue_l1(rb);
+    for (; rb < a.n_rb; rb += stride) {
+        issue_col(rb, 0);
         // ---- dH1^T[feature][row] = sum_c W2[feature][c] . dZ0[row][c]: dZ0 in its memory layout as the B operand
-        const float *zp = a.dz + rc * a.lddz + 8 * hh;
-        float4 zr[8];
+        asm volatile("s_waitcnt vmcnt(32)" : "+v"(KB), "+v"(RSC) :: "memory");           // L1 has 32 younger loads (C0)
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-            if (s < a.n_ks) { zr[2 * s] = *reinterpret_cast<const float4 *>(zp + 16 * s); zr[2 * s + 1] = *reinterpret_cast<const float4 *>(zp + 16 * s + 4); }
-        const uint4 kb = *reinterpret_cast<const uint4 *>(a.bits + rc * 4);
-        const float sc = a.rowscale ? a.scale * a.rowscale[rc] : a.scale;
-        f32x16 acc[4];
+        for (int i = 0; i < 2 * NKS; i++) asm volatile("" : "+v"(Z[i]));
+        const uint32_t kw[2] = {__float_as_uint(KB[2 * half]), __float_as_uint(KB[2 * half + 1])};
+        const float sc = a.rowscale ? a.scale * RSC : a.scale;
+        f32x16 acc[2];
 #pragma unroll
-        for (int fb = 0; fb < 4; fb++)
+        for (int f2 = 0; f2 < 2; f2++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[fb][r] = 0.f;
+            for (int r = 0; r < 16; r++) acc[f2][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            if (s < a.n_ks) {
-                float v[8] = {zr[2 * s].x, zr[2 * s].y, zr[2 * s].z, zr[2 * s].w, zr[2 * s + 1].x, zr[2 * s + 1].y, zr[2 * s + 1].z, zr[2 * s + 1].w};
-                const int c0 = 16 * s + 8 * hh;
+        for (int s = 0; s < NKS; s++) {
+            float v[8] = {Z[2 * s][0], Z[2 * s][1], Z[2 * s][2], Z[2 * s][3], Z[2 * s + 1][0], Z[2 * s + 1][1], Z[2 * s + 1][2], Z[2 * s + 1][3]};
+            const int c0 = 16 * s + 8 * hh;
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = c0 + j < a.p ? v[j] : 0.f;      // padding columns may hold anything
-                const ClsB3 B = cls_planes(v);
+            for (int j = 0; j < 8; j++) v[j] = c0 + j < a.p ? v[j] : 0.f;              // padding columns may hold anything
+            if constexpr (ABL & 1) { acc[0][s] += v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; continue; }
+            const ClsB3 B = cls_planes(v);
 #pragma unroll
-                for (int fb = 0; fb < 4; fb++) cls_mac(acc[fb], cls_lds(cls_img, s * 4 + fb, lane), B);
+            for (int f2 = 0; f2 < 2; f2++) cls_mac(acc[f2], B, cls_lds(cls_img, s * 4 + 2 * half + f2, lane));
+        }
+        if ((ABL & 2) ? (acc[0][0] == 123.456f) : true) {
+            // D[row = (r & 3) + 8 (r >> 2) + 4 hh][feature = 32 fb + li]: lane li holds the mask words and the factor of row li
+            // (both halves of the wave); a store instruction writes 32 consecutive features — one full line — of two rows.
+            // (As 16-byte lane stores of a transposed tile the 119 MB of dH1 left in 7.4 M separate requests: 40 us of a 95 us launch.)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, orow = rb * 32 + rl;
+                const float scr = __shfl(sc, rl, WAVE);
+                const uint32_t w0 = __shfl(kw[0], rl, WAVE), w1 = __shfl(kw[1], rl, WAVE);
+                if (orow < a.m) {
+                    float *dp = a.da + (size_t)orow * a.ldda + 64 * half + li;
+                    dp[0] = ((w0 >> li) & 1u) ? acc[0][r] * scr : 0.f;
+                    dp[32] = ((w1 >> li) & 1u) ? acc[1][r] * scr : 0.f;
+                }
             }
         }
-        if (live) {
-            float *dp = a.da + (size_t)row * a.ldda;
-            const uint32_t kw[4] = {kb.x, kb.y, kb.z, kb.w};
-#pragma unroll
-            for (int fb = 0; fb < 4; fb++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t nib = kw[fb] >> (8 * q + 4 * hh);
-                    float x[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) x[i] = ((nib >> i) & 1u) ? acc[fb][4 * q + i] * sc : 0.f;
-                    *reinterpret_cast<float4 *>(dp + 32 * fb + 8 * q + 4 * hh) = make_float4(x[0], x[1], x[2], x[3]);
-                }
-        }
+        issue_l1(rb + stride);                               // the next block's row pieces travel under the second phase
         // ---- dW2[feature][c] += sum_rows H1[row][feature] . dZ0[row][c]: both operands column-wise (k = row)
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
-            const int r0 = row0 + 16 * s2 + 8 * hh;         // this lane's 8 rows of the k-step
-            ClsB3 Bz[2];
+            if (s2 == 0) CLS_WAIT_COL(NL1, Cc);              // younger than C0: the next block's L1
+            else CLS_WAIT_COL(0, Cc);
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) dw[0][0][j] += Cc.z[0][j] + Cc.z[1][j] + Cc.h[0][j] + Cc.h[1][j];
+                if (s2 == 0) issue_col(rb, 1);
+                continue;
+            }
+            ClsB3 Bz[2], Ah[2];
 #pragma unroll
             for (int cb = 0; cb < 2; cb++) {
-                const int c = 32 * cb + li;
-                const bool okc = c < a.p;
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = a.dz[(size_t)min(r0 + j, a.m - 1) * a.lddz + (okc ? c : 0)];
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = (okc && r0 + j < a.m) ? v[j] : 0.f;   // rows past m and classes past p contribute nothing
+                for (int j = 0; j < 8; j++) v[j] = (32 * cb + li < a.p) ? Cc.z[cb][j] : 0.f;   // classes past p: padding
                 Bz[cb] = cls_planes(v);
             }
 #pragma unroll
-            for (int fb = 0; fb < 4; fb++) {
-                float v[8];
+            for (int f2 = 0; f2 < 2; f2++) Ah[f2] = cls_planes(Cc.h[f2]);
+            if (s2 == 0) issue_col(rb, 1);                   // into the registers just turned into planes
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = a.h1[(size_t)min(r0 + j, a.m - 1) * a.ldh + 32 * fb + li];
-                const ClsB3 A = cls_planes(v);
-                cls_mac(dw[fb][0], A, Bz[0]);
-                if (a.p > 32) cls_mac(dw[fb][1], A, Bz[1]);
+            for (int f2 = 0; f2 < 2; f2++) {
+                cls_mac(dw[f2][0], Ah[f2], Bz[0]);
+                if (a.p > 32) cls_mac(dw[f2][1], Ah[f2], Bz[1]);
             }
         }
     }
-    // ---- the workgroup's sum, wave after wave (fixed order), then one slab per workgroup
-    for (int w = 0; w < CLS_BWD_WAVES; w++) {
-        if (wave == w) {
+    // the L1 loads issued for the block after the last: their registers stay allocated until they have landed
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(KB), "+v"(RSC) :: "memory");
 #pragma unroll
-            for (int fb = 0; fb < 4; fb++)
+    for (int i = 0; i < 2 * NKS; i++) asm volatile("" : "+v"(Z[i]));
+    // ---- the workgroup's sum, pair after pair (fixed order; the two waves of a pair own different features), one slab per workgroup
+    for (int w = 0; w < CLS_BWD_PAIRS; w++) {
+        if (pair == w) {
+#pragma unroll
+            for (int f2 = 0; f2 < 2; f2++)
 #pragma unroll
                 for (int cb = 0; cb < 2; cb++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const int f = 32 * fb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        red[f * 64 + 32 * cb + li] += dw[fb][cb][r];
+                        const int f = 32 * (2 * half + f2) + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        red[f * 64 + 32 * cb + li] += dw[f2][cb][r];
                     }
         }
         __syncthreads();
@@ -251,20 +329,28 @@ __global__ __launch_bounds__(512) void class_bwd_bf16x3_kernel(ClsBwdArgs a) {
 
 // the shapes these kernels take (anything else: the f32-MFMA kernels of dense_kernels.h)
 static inline bool cls_fwd_fits(const float *a, int lda, const float *c, int ldc, int m, int n, int p) {
-    return n == 128 && p >= 1 && p <= 64 && m >= 2048 && lda % 4 == 0 && lda >= 128 && ldc % 4 == 0 && aligned16(a) && aligned16(c);
+    return n == 128 && p >= 1 && p <= 64 && m >= 2048 && lda % 4 == 0 && lda >= 128 && ldc % 4 == 0 && aligned16(a) && aligned16(c) &&
+           (uint64_t)m * lda * 4 < (1ull << 32);
 }
 static inline bool cls_bwd_fits(const float *a, int lda, const float *dc, int lddc, const float *da, int ldda, const uint32_t *bits, int wpr,
                                 int m, int n, int p) {
     return n == 128 && p >= 1 && p <= 64 && m >= 2048 && wpr == 4 && bits && aligned16(bits) && a && lda >= 128 && lddc % 4 == 0 &&
-           lddc >= (p + 15) / 16 * 16 && ldda % 4 == 0 && ldda >= 128 && aligned16(dc) && aligned16(da);
+           lddc >= (p + 15) / 16 * 16 && ldda % 4 == 0 && ldda >= 128 && aligned16(dc) && aligned16(da) &&
+           (uint64_t)m * lda * 4 < (1ull << 32) && (uint64_t)m * lddc * 4 < (1ull << 32);
 }
 
 static int launch_class_fwd(gcnhip_ctx *c, const float *a, int lda, const float *b, int ldb, float *z, int ldz, int m, int p) {
     ClsFwdArgs k;
     k.h1 = a; k.ldh = lda; k.w2 = b; k.ldw = ldb; k.z0 = z; k.ldz = ldz; k.m = m; k.p = p; k.n_rb = ceil_div(m, 32);
     int grid = ceil_div(k.n_rb, 4);
-    if (grid > c->n_cu * 3) grid = c->n_cu * 3;              // 48 KB of LDS per workgroup: three per CU
-    class_fwd_bf16x3_kernel<<<grid, 256, CLS_FWD_LDS, c->stream>>>(k);
+    const int per_cu = c->opt.cls_wgs > 0 ? c->opt.cls_wgs : 3;     // 48 KB of LDS per workgroup: three per CU
+    if (grid > c->n_cu * per_cu) grid = c->n_cu * per_cu;
+    switch (c->opt.cls_abl & 3) {
+        case 1: class_fwd_bf16x3_kernel<1><<<grid, 256, CLS_FWD_LDS, c->stream>>>(k); break;
+        case 2: class_fwd_bf16x3_kernel<2><<<grid, 256, CLS_FWD_LDS, c->stream>>>(k); break;
+        case 3: class_fwd_bf16x3_kernel<3><<<grid, 256, CLS_FWD_LDS, c->stream>>>(k); break;
+        default: class_fwd_bf16x3_kernel<0><<<grid, 256, CLS_FWD_LDS, c->stream>>>(k); break;
+    }
     GCNHIP_LAUNCH_CHECK();
     return 0;
 }

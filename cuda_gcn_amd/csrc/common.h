@@ -34,6 +34,9 @@ struct GcnOptions {
     int gemm_bf16x3;        // dense first-layer products (p = 128) from three bf16 planes on the bf16 MFMA pipe: 2 (default) on, also on a
                             // co-running stream; 1 on, the co-running stream keeps the f32 tiles; 0 off: the exact-f32 MFMA kernels
     int gemm_w4;            // 1: four-wave forward tiles
+    int cls_abl;            // measurement aid (tools/bench_class.py): class_bf16x3.h kernels without 1: matrix work, 2: stores, 4: the column-wise operand loads
+    int cls_wgs;            // measurement aid: workgroups per CU of the class-layer forward (0: default)
+    int cls_fwd;            // 1 (default): H1.W2 through class_bf16x3.h when gemm_bf16x3 >= 1; 0: through the f32-MFMA row stream
     int gemm_persist_bwd;   // 1: persistent first-layer weight gradient (measured slower)
     int dbg_linear;         // timing experiment only: the persistent forward reads X as if tile-major (wrong results)
     int xent_finalize;      // 1: the loss's final reduction as its own launch

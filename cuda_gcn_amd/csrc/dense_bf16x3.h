@@ -371,7 +371,6 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
 //   Both operands' values of step s+1 are split (8 pairs) while step s's 24 MFMAs run; loads run two steps ahead.
 // Rows past the split's end contribute zero (lane masks); rows past m are outside the buffer descriptors and read as zero.
 // One f32 slab [K x 128] per row split, summed in split order by slab_reduce_kernel (no atomics: the same bits every run).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Bx3BwdArgs {
     const float *x; int ldx;          // X [m x ldx], ldx >= 128 * gridDim.x, zero padded past K
@@ -383,13 +382,6 @@ struct Bx3BwdArgs {
     float scale;                      // 1 / (1 - p) with dropout, applied to the stored partial
 };
 
-__device__ __forceinline__ u32x4 bx_make_rsrc(const void *p, uint32_t bytes) {
-    const uint64_t q = (uint64_t)(uintptr_t)p;
-    return (u32x4){(uint32_t)q, (uint32_t)(q >> 32) & 0xFFFFu, bytes, 0x00020000u};
-}
-__device__ __forceinline__ void bx_bload4(float &dst, uint32_t voff, u32x4 rsrc, uint32_t soff) {
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
 template <int OFF>
 __device__ __forceinline__ void bx_ldswrite16(uint32_t addr, u32x4 v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");

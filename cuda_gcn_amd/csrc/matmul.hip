@@ -14,7 +14,7 @@ int gcnhip_matmul_fwd(gcnhip_ctx *c, const float *a, int lda, const float *b, in
     if (!c || !a || !b || !cc || m < 0 || n <= 0 || p <= 0 || lda < n || ldb < p || ldc < p) return -1;
     if (m == 0) return 0;
     // option gemm_bf16x3 (round 5): hidden width 128, at most 64 classes — the product from three bf16 planes per operand
-    if (c->opt.gemm_bf16x3 >= 1 && cls_fwd_fits(a, lda, cc, ldc, m, n, p)) return launch_class_fwd(c, a, lda, b, ldb, cc, ldc, m, p);
+    if (c->opt.gemm_bf16x3 >= 1 && c->opt.cls_fwd && cls_fwd_fits(a, lda, cc, ldc, m, n, p)) return launch_class_fwd(c, a, lda, b, ldb, cc, ldc, m, p);
     return launch_rowstream(c, a, lda, b, ldb, 0, cc, ldc, m, n, p, nullptr, 0, 1.f);
 }
 
@@ -23,18 +23,33 @@ static int launch_class_bwd(gcnhip_ctx *c, const float *a, int lda, const float 
                             float *db, int lddb, int m, int p, float scale, const uint32_t *bits, const float *rowscale) {
     ClsBwdArgs k;
     k.dz = dc; k.lddz = lddc; k.h1 = a; k.ldh = lda; k.w2 = b; k.ldw = ldb; k.da = da; k.ldda = ldda; k.bits = bits;
-    k.rowscale = rowscale; k.scale = scale; k.p_ld = (p + 3) / 4 * 4; k.m = m; k.p = p; k.n_rb = ceil_div(m, 32); k.n_ks = (p + 15) / 16;
-    int grid = ceil_div(k.n_rb, CLS_BWD_WAVES);
+    k.rowscale = rowscale; k.scale = scale; k.p_ld = (p + 3) / 4 * 4; k.m = m; k.p = p; k.n_rb = ceil_div(m, 32);
+    const int nks = (p + 15) / 16;
+    int grid = ceil_div(k.n_rb, CLS_BWD_PAIRS);
     if (grid > c->n_cu) grid = c->n_cu;                      // one workgroup of 8 waves per CU, every wave keeps its share of dW2 in registers
     const int rc = ensure_slab(c, (size_t)grid * 128 * k.p_ld * sizeof(float));
     if (rc) return rc;
     k.slab = c->slab;
     static bool attr_set = false;                            // (per process; the attribute belongs to the function, not to a context)
     if (!attr_set) {
-        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
+        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
+        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
+        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
+        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
         attr_set = true;
     }
-    class_bwd_bf16x3_kernel<<<grid, 512, CLS_BWD_LDS, c->stream>>>(k);
+    const int abl = c->opt.cls_abl & 3;                       // measurement aid (tools/bench_class.py), p = 33..48 only
+    if (abl && nks == 3) {
+        if (abl == 1) { GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); class_bwd_bf16x3_kernel<3, 1><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); }
+        else if (abl == 2) { GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); class_bwd_bf16x3_kernel<3, 2><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); }
+        else { GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); class_bwd_bf16x3_kernel<3, 3><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); }
+    } else
+    switch (nks) {
+        case 1: class_bwd_bf16x3_kernel<1><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
+        case 2: class_bwd_bf16x3_kernel<2><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
+        case 3: class_bwd_bf16x3_kernel<3><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
+        default: class_bwd_bf16x3_kernel<4><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
+    }
     GCNHIP_LAUNCH_CHECK();
     launch_slab_reduce(k.slab, grid, 128, p, k.p_ld, db, lddb, c->stream);
     GCNHIP_LAUNCH_CHECK();

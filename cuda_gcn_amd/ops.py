@@ -316,6 +316,22 @@ class Device:
                                                              bt.ptr, bits.shape[1]), "gcnhip_matmul_bwd_fused_bits")
         return da.download(), db.download()[:, :p]
 
+    def matmul_bwd_ex(self, a, b, dc, scale, bits, rowscale=None, ldp=None, p=None):
+        """gcnhip_matmul_bwd_ex: da = mask(bits) . (scale * rowscale[r]) . (dc . b^T), db = a^T . dc; dc may come with its
+        padding columns (p = the real width)"""
+        a, b, dc = (np.asarray(t, np.float32) for t in (a, b, dc))
+        m, n = a.shape
+        p = p or b.shape[1]
+        ldp = ldp or (p + 3) // 4 * 4
+        ab, bb, dcb = self.buf(a), self.padded(b, ldp), self.padded(dc, ldp)
+        bt = self.buf(np.ascontiguousarray(bits, np.uint32))
+        rs = self.buf(np.ascontiguousarray(rowscale, np.float32)) if rowscale is not None else None
+        da = self.buf(np.full((m, n), np.nan, np.float32))
+        db = self.buf(np.full((n, ldp), np.nan, np.float32))
+        _ck(self.lib, self.lib.gcnhip_matmul_bwd_ex(self.ctx, ab.ptr, n, bb.ptr, ldp, dcb.ptr, ldp, da.ptr, n, db.ptr, ldp, m, n, p, scale,
+                                                     bt.ptr, bits.shape[1], rs.ptr if rs else None), "gcnhip_matmul_bwd_ex")
+        return da.download(), db.download()[:, :p]
+
     def spmm_fwd(self, f: "Feat", w, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, keep_mask=None, vals=None, ld_w=None, ld_out=None):
         w = np.asarray(w, np.float32)
         p = w.shape[1]

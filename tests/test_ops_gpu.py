@@ -804,6 +804,50 @@ def test_matmul_vs_oracle(dev, oracle, m, n, p, pad):
     close_mag(db2, ob, mb)
 
 
+@pytest.mark.parametrize("m,p", [(2048 + 17, 41), (70001, 41), (4096, 64), (3000, 7), (2500, 33), (2049, 32)])
+def test_class_layer_products_from_three_bf16_planes(dev, m, p):
+    """class_bf16x3.h (option gemm_bf16x3 >= 1, hidden width 128, <= 64 classes, >= 2048 rows): H1.W2, and the fused backward
+    dH1 = mask . s_r . (dZ0.W2^T) with dW2 = H1^T.dZ0 in one launch — against float64 products within the f32 summation bound
+    the f32-MFMA kernels are held to (Matmul, module.cpp:11-42), and beside those kernels (option 0) on the same inputs;
+    ragged last row block, padding columns of dZ0 holding NaN, rows past m"""
+    n = 128
+    rng = np.random.default_rng(m + p)
+    a = (rng.standard_normal((m, n)) * rng.choice([0.0, 1.0, 30.0], (m, n), p=[0.5, 0.4, 0.1])).astype(np.float32)   # H1: half zeros
+    b = (rng.standard_normal((n, p)) * 0.3).astype(np.float32)
+    dc = (rng.standard_normal((m, p)) * 1e-3).astype(np.float32)
+    rs = (1.0 / rng.integers(1, 500, m)).astype(np.float32)
+    bits = np.zeros((m, 4), np.uint32)
+    for c in range(n):
+        bits[:, c // 32] |= (a[:, c] > 0).astype(np.uint32) << np.uint32(c % 32)
+    ldp = (p + 15) // 16 * 16
+    a64, b64, dc64 = a.astype(np.float64), b.astype(np.float64), dc.astype(np.float64)
+    want_f, mag_f = a64 @ b64, np.abs(a64) @ np.abs(b64)
+    sc = np.float32(2.0) * rs
+    want_da = np.where(a > 0, (dc64 @ b64.T) * sc[:, None].astype(np.float64), 0.0)
+    mag_da = (np.abs(dc64) @ np.abs(b64.T)) * sc[:, None].astype(np.float64)
+    want_db, mag_db = a64.T @ dc64, np.abs(a64).T @ np.abs(dc64)
+    res = {}
+    old = C.c_int(0)
+    dev.lib.gcnhip_ctx_get_option(dev.ctx, b"gemm_bf16x3", C.byref(old))
+    try:
+        for mode in (2, 0):
+            dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", mode)
+            z = dev.matmul_fwd(a, b, lda=n, ldb=ldp, ldc=ldp)
+            da, db = dev.matmul_bwd_ex(a, b, dc, 2.0, bits, rowscale=rs, ldp=ldp)      # (Device.padded: padding columns hold NaN)
+            close_mag(z, want_f, mag_f)
+            close_mag(da, want_da, mag_da + 1e-30)
+            close_mag(db, want_db, mag_db)
+            assert np.all(da[~(a > 0)] == 0.0)
+            res[mode] = (z, da, db)
+    finally:
+        dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", old.value)
+    # error against float64, new kernels beside the f32-MFMA kernels: no worse than 2 x (both far inside the bound)
+    for i, (want, mag) in enumerate(((want_f, mag_f), (want_da, mag_da), (want_db, mag_db))):
+        e_new = (np.abs(res[2][i] - want) / (mag + 1e-30)).max()
+        e_old = (np.abs(res[0][i] - want) / (mag + 1e-30)).max()
+        assert e_new <= 2 * e_old + EPS, (i, e_new, e_old)
+
+
 @pytest.mark.parametrize("m,n,p", [(1000, 128, 41), (333, 16, 7), (70000, 128, 41), (65, 70, 3), (1, 1, 1), (4097, 200, 47)])
 def test_pack_positive_and_da_from_bits(dev, m, n, p):
     """multi-GPU backward: the ReLU/dropout mask travels as one bit per element and
