@@ -67,14 +67,26 @@ __device__ __forceinline__ void cls_fwd_issue(f32x4 (&R)[16], uint32_t vo, u32x4
     bx_bload16<64 * S + 16>(R[2 * S + 1], vo, rs);
 }
 
-// A wave keeps the 16 row loads of ONE row block in flight at all times: the two loads of k-step s of the next block are issued
-// the moment this block's k-step s has been taken out of its registers, so every wait sees exactly 14 younger loads.  (As plain
-// C++ loads hipcc issued each k-step's pair right before its use and waited: eight dependent round trips per block, 49 us.)
+#define CLS_TIE4(R, i) "+v"((R)[i]), "+v"((R)[(i) + 1]), "+v"((R)[(i) + 2]), "+v"((R)[(i) + 3])
+#define CLS_WAIT_ALL16(R) asm volatile("s_waitcnt vmcnt(0)" : CLS_TIE4(R, 0), CLS_TIE4(R, 4), CLS_TIE4(R, 8), CLS_TIE4(R, 12) :: "memory")
+
+// A wave keeps the 16 row loads of ONE row block in flight at all times: the two loads of k-step s of the NEXT block are issued
+// the moment this block's k-step s has been turned into planes (pinned by an empty asm, so that the old values are dead before
+// their registers are named as the new loads' destinations), and every wait sees exactly 14 younger loads.
+// Round 5, fourth fact about hand-counted loads: these registers are live across the loop's back edge WHILE IN FLIGHT.  A first
+// version issued the refill before the split had consumed the old values; hipcc gave the refills registers of their own and
+// copied them into the loop's registers at the back edge — 32 v_mov_b64 BEFORE their waits: garbage whenever a load had not
+// landed by then.  Every parity test passed (cache-resident inputs land within a block's compute); two rmat-22 runs differed.
+// Nothing in the language forbids such copies, so the build is checked instead: tools/check_asm_loads.py walks the compiled
+// kernel's control-flow graph and fails (tests/test_isa_cpu.py) if any instruction touches a register of a load in flight.
+// (A version with two whole register sets and no load in flight at the back edge is immune by construction and was measured:
+// 158 registers, two waves per SIMD, 48.5 us against 36.7.  As plain C++ loads, before all that, hipcc issued each k-step's pair
+// right before its use and waited: eight dependent round trips per block, 49 us.)
 template <int ABL>
 __global__ __launch_bounds__(256) void class_fwd_bf16x3_kernel(ClsFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 cls_img[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
-    // A[i = class][k = feature]: piece (s, cb) of lane ln holds W2[16 s + 8 (ln >> 5) + j][32 cb + (ln & 31)], j = 0..7
+    // B[k = feature][n = class]: piece (s, cb) of lane ln holds W2[16 s + 8 (ln >> 5) + j][32 cb + (ln & 31)], j = 0..7
     for (int idx = threadIdx.x; idx < 8 * 2 * 64; idx += 256) {
         const int ln = idx & 63, cb = (idx >> 6) & 1, s = idx >> 7;
         const int c = 32 * cb + (ln & 31), k0 = 16 * s + 8 * (ln >> 5);
@@ -92,12 +104,12 @@ __global__ __launch_bounds__(256) void class_fwd_bf16x3_kernel(ClsFwdArgs a) {
     const int stride = gridDim.x * 4;
     int rb = blockIdx.x * 4 + wave;
     auto voff = [&](int b) { return ((uint32_t)(b * 32 + li) * (uint32_t)a.ldh + 8u * hh) * 4u; };
+    auto issue = [&](f32x4 (&Q)[16], uint32_t vo) __attribute__((always_inline)) {
+        cls_fwd_issue<0>(Q, vo, rs_h); cls_fwd_issue<1>(Q, vo, rs_h); cls_fwd_issue<2>(Q, vo, rs_h); cls_fwd_issue<3>(Q, vo, rs_h);
+        cls_fwd_issue<4>(Q, vo, rs_h); cls_fwd_issue<5>(Q, vo, rs_h); cls_fwd_issue<6>(Q, vo, rs_h); cls_fwd_issue<7>(Q, vo, rs_h);
+    };
     f32x4 R[16];
-    {
-        const uint32_t vo = voff(rb);
-        cls_fwd_issue<0>(R, vo, rs_h); cls_fwd_issue<1>(R, vo, rs_h); cls_fwd_issue<2>(R, vo, rs_h); cls_fwd_issue<3>(R, vo, rs_h);
-        cls_fwd_issue<4>(R, vo, rs_h); cls_fwd_issue<5>(R, vo, rs_h); cls_fwd_issue<6>(R, vo, rs_h); cls_fwd_issue<7>(R, vo, rs_h);
-    }
+    issue(R, voff(rb));
     for (; rb < a.n_rb; rb += stride) {
         const uint32_t vn = voff(rb + stride);               // past the last block: past the descriptor, zeros, never used
         f32x16 acc[2];
@@ -109,12 +121,17 @@ __global__ __launch_bounds__(256) void class_fwd_bf16x3_kernel(ClsFwdArgs a) {
         {                                                                                                                    \
             CLS_WAIT2(14, R[2 * S], R[2 * S + 1]);                                                                           \
             const float v[8] = {R[2 * S][0], R[2 * S][1], R[2 * S][2], R[2 * S][3], R[2 * S + 1][0], R[2 * S + 1][1], R[2 * S + 1][2], R[2 * S + 1][3]}; \
-            cls_fwd_issue<S>(R, vn, rs_h);                                                                                   \
-            if constexpr (ABL & 1) { acc[0][S] += v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; }                      \
-            else {                                                                                                           \
-                const ClsB3 B = cls_planes(v);                                                                               \
-                cls_mac(acc[0], B, cls_lds(cls_img, S * 2, lane));                                                           \
-                if (a.p > 32) cls_mac(acc[1], B, cls_lds(cls_img, S * 2 + 1, lane));                                         \
+            if constexpr (ABL & 1) {                                                                                         \
+                float sum = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7];                                             \
+                asm volatile("" : "+v"(sum));                                                                                \
+                acc[0][S] += sum;                                                                                            \
+                cls_fwd_issue<S>(R, vn, rs_h);                                                                               \
+            } else {                                                                                                         \
+                ClsB3 A = cls_planes(v);                                                                                     \
+                asm volatile("" : "+v"(A.h), "+v"(A.m), "+v"(A.l));        /* the k-step's floats are dead from here on */    \
+                cls_fwd_issue<S>(R, vn, rs_h);                                                                               \
+                cls_mac(acc[0], A, cls_lds(cls_img, S * 2, lane));                                                           \
+                if (a.p > 32) cls_mac(acc[1], A, cls_lds(cls_img, S * 2 + 1, lane));                                         \
             }                                                                                                                \
         }
         CLS_FWD_STEP(0) CLS_FWD_STEP(1) CLS_FWD_STEP(2) CLS_FWD_STEP(3) CLS_FWD_STEP(4) CLS_FWD_STEP(5) CLS_FWD_STEP(6) CLS_FWD_STEP(7)
@@ -131,8 +148,7 @@ __global__ __launch_bounds__(256) void class_fwd_bf16x3_kernel(ClsFwdArgs a) {
         }
     }
     // the loads issued for the block after the last: their registers stay allocated until they have landed
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) CLS_WAIT2(0, R[i], R[i + 1]);
+    CLS_WAIT_ALL16(R);
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
@@ -156,7 +172,7 @@ struct ClsCol { float z[2][8], h[2][8]; };                  // one k-step of 16 
 #define CLS_WAIT_COL(N, c) asm volatile("s_waitcnt vmcnt(%32)" : CLS_TIE8((c).z[0]), CLS_TIE8((c).z[1]), CLS_TIE8((c).h[0]), CLS_TIE8((c).h[1]) : "n"(N) : "memory")
 
 // NKS = ceil(p / 16) k-steps of classes.  Vector-memory loads of a row block, in issue order (all inline asm):
-//   L1(b): 2 NKS row pieces of dZ0, the row's 4 mask words, its factor   (2 NKS + 2 loads)   — issued during block b-1
+//   L1(b): 2 NKS row pieces of dZ0, the row's 4 mask words, its factor   (2 NKS + 2 loads)   — issued during block b-1, landed by its end
 //   C0(b): k-step 0 column-wise: 16 + 16 dwords                          (32)                — issued at the top of block b
 //   C1(b): k-step 1, into C0's registers once those are planes            (32)
 template <int NKS, int ABL = 0>
@@ -300,8 +316,13 @@ __global__ __launch_bounds__(512) void class_bwd_bf16x3_kernel(ClsBwdArgs a) {
                 if (a.p > 32) cls_mac(dw[f2][1], Ah[f2], Bz[1]);
             }
         }
+        // NO load is in flight across the back edge (see the forward kernel): the next block's L1 has landed with C1's vmcnt(0);
+        // its registers are tied to a wait here so that hipcc's back-edge copies come after it
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(KB), "+v"(RSC) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 2 * NKS; i++) asm volatile("" : "+v"(Z[i]));
     }
-    // the L1 loads issued for the block after the last: their registers stay allocated until they have landed
+    // (waves that never entered the loop: the prologue's L1)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(KB), "+v"(RSC) :: "memory");
 #pragma unroll
     for (int i = 0; i < 2 * NKS; i++) asm volatile("" : "+v"(Z[i]));

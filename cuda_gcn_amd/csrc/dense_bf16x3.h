@@ -348,8 +348,10 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         chunk(R1, R2, R0, g + 1);
         chunk(R2, R0, R1, g + 2);
     }
-    if (g < n_items) { chunk(R0, R1, R2, g); g++; }
-    if (g < n_items) { chunk(R1, R2, R0, g); g++; }
+    if (g < n_items) {                                       // (nested, not two tests in a row: the second chunk is reachable only through the
+        chunk(R0, R1, R2, g); g++;                           //  first, whose wait covers R1 — tools/check_asm_loads.py walks every CFG path)
+        if (g < n_items) { chunk(R1, R2, R0, g); g++; }
+    }
     // Nothing of this wave may still be landing when it ends — and the raw buffers stay allocated until here: the loads issued
     // past the end of the share are never used, so hipcc would otherwise hand their destination registers to the epilogue
     // while the loads are still in flight (an asm output counts as written when the statement is issued).
