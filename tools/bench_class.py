@@ -3,7 +3,8 @@
 gcnhip_matmul_fwd and gcnhip_matmul_bwd_ex (mask bits + row factors, as HipGCN calls them), with the bf16x3 kernels of
 csrc/class_bf16x3.h (option gemm_bf16x3 = 2) and with the f32-MFMA kernels of csrc/dense_kernels.h (0).
 
-    python tools/bench_class.py [N] [iters]          (run on the GPU box; for a PMC pass: PMC_PROG="tools/bench_class.py" tools/pmc_gemm.sh ...)
+    python tools/bench_class.py [N] [iters] [noabl]   (run on the GPU box; counter passes: PMC_PROG="tools/bench_class.py 232965 10 noabl"
+                                                       PMC_MATCH="class_,slab_reduce,rowstream,atb" tools/pmc_gemm.sh <out>)
 """
 import ctypes as C
 import json
@@ -19,6 +20,7 @@ from cuda_gcn_amd.ops import Device, _ck  # noqa: E402
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 232965
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    noabl = "noabl" in sys.argv[3:]                      # counter passes: only the product's kernels
     h, Cc, ldc = 128, 41, 48
     dev = Device(0)
     lib = dev.lib
@@ -55,6 +57,8 @@ def main():
         print(f"[bench_class] {name}: H1.W2 {f * 1e3:.1f} us ({by_f / f / 1e6:.0f} GB/s of {by_f / 1e6:.0f} MB), "
               f"dH1 + dW2 {b * 1e3:.1f} us ({by_b / b / 1e6:.0f} GB/s of {by_b / 1e6:.0f} MB)", flush=True)
     lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", 2)
+    if noabl:
+        print(json.dumps(res)); return
     for abl, what in ((1, "no matrix work (loads, stores)"), (2, "no stores"), (3, "loads only")):
         lib.gcnhip_ctx_set_option(dev.ctx, b"cls_abl", abl)
         f = timeit(lambda: _ck(lib, lib.gcnhip_matmul_fwd(dev.ctx, h1.ptr, h, w2.ptr, ldc, z0.ptr, ldc, N, h, Cc), "fwd"))
