@@ -847,7 +847,21 @@ def main():
         out["structure_legs"] = legs
     if extras and args.hidden > 64 and ds["f_indices"] is not None and ds["f_indptr"][1] == ds["input_dim"]:
         try:
-            out["roofline_dense"] = dense_leg(ds, args.hidden, device)
+            rd = dense_leg(ds, args.hidden, device)
+            # The same products inside the epoch, from the per-op HIP-event timers of this run (forward: the training and the
+            # validation product together, with their plane-packing / keep-bit launches; backward: the product and its slab sum).
+            # The stand-alone leg above repeats one MFMA-bound launch back to back and runs into the socket power cap (lower
+            # shader clock); in the epoch the products alternate with memory-bound kernels and run at the higher clock.
+            bd = out.get("breakdown_ms_per_epoch") or {}
+            if bd.get("spmatmul_fw") and bd.get("spmatmul_bw"):
+                mult = 6 if rd["method"] == "bf16x3" else 1
+                fw_tf, bw_tf = 2 * rd["flop_per_launch"] / bd["spmatmul_fw"] / 1e9, rd["flop_per_launch"] / bd["spmatmul_bw"] / 1e9
+                rd["in_epoch"] = {"forward_pair_ms": bd["spmatmul_fw"], "forward_algorithmic_TFLOPs": fw_tf, "forward_frac_of_pipe_peak": mult * fw_tf / rd["peak"],
+                                  "weight_gradient_ms": bd["spmatmul_bw"], "weight_gradient_algorithmic_TFLOPs": bw_tf,
+                                  "weight_gradient_frac_of_pipe_peak": mult * bw_tf / rd["peak"],
+                                  "source": "breakdown_ms_per_epoch of this run (one-stream timers pass; every launch of the op included)"}
+                rd["frac_in_epoch"] = min(rd["in_epoch"]["forward_frac_of_pipe_peak"], rd["in_epoch"]["weight_gradient_frac_of_pipe_peak"])
+            out["roofline_dense"] = rd
         except Exception as e:
             out["roofline_dense"] = {"error": repr(e)}
     if extras:
