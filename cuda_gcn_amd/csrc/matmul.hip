@@ -30,26 +30,25 @@ static int launch_class_bwd(gcnhip_ctx *c, const float *a, int lda, const float 
     const int rc = ensure_slab(c, (size_t)grid * 128 * k.p_ld * sizeof(float));
     if (rc) return rc;
     k.slab = c->slab;
-    static bool attr_set = false;                            // (per process; the attribute belongs to the function, not to a context)
-    if (!attr_set) {
-        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
-        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
-        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
-        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS));
-        attr_set = true;
-    }
+    // (the attribute is set per launch, as the other kernels with more than 64 KB of LDS do: it belongs to the function on the
+    //  CURRENT device, and a process may drive several — gcn-hip with GCN_GPUS=N runs one host thread per GPU)
+#define CLS_BWD(...)                                                                                                              \
+    do {                                                                                                                          \
+        GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); \
+        class_bwd_bf16x3_kernel<__VA_ARGS__><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k);                                          \
+    } while (0)
     const int abl = c->opt.cls_abl & 3;                       // measurement aid (tools/bench_class.py), p = 33..48 only
     if (abl && nks == 3) {
-        if (abl == 1) { GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); class_bwd_bf16x3_kernel<3, 1><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); }
-        else if (abl == 2) { GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); class_bwd_bf16x3_kernel<3, 2><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); }
-        else { GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); class_bwd_bf16x3_kernel<3, 3><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); }
-    } else
-    switch (nks) {
-        case 1: class_bwd_bf16x3_kernel<1><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
-        case 2: class_bwd_bf16x3_kernel<2><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
-        case 3: class_bwd_bf16x3_kernel<3><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
-        default: class_bwd_bf16x3_kernel<4><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k); break;
+        if (abl == 1) CLS_BWD(3, 1); else if (abl == 2) CLS_BWD(3, 2); else CLS_BWD(3, 3);
+    } else {
+        switch (nks) {
+            case 1: CLS_BWD(1); break;
+            case 2: CLS_BWD(2); break;
+            case 3: CLS_BWD(3); break;
+            default: CLS_BWD(4); break;
+        }
     }
+#undef CLS_BWD
     GCNHIP_LAUNCH_CHECK();
     launch_slab_reduce(k.slab, grid, 128, p, k.p_ld, db, lddb, c->stream);
     GCNHIP_LAUNCH_CHECK();
