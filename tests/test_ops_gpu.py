@@ -848,6 +848,97 @@ def test_class_layer_products_from_three_bf16_planes(dev, m, p):
         assert e_new <= 2 * e_old + EPS, (i, e_new, e_old)
 
 
+def test_first_layer_products_beside_a_bandwidth_hog(dev):
+    """the same stress for dense_bf16x3.h (X by asm loads three chunks deep, W planes by LDS-DMA, counted waits): X of 400 001 rows x
+    602 columns (963 MB, four times the Infinity Cache) multiplied beside a second context's aggregation; forward without and with
+    dropout and the weight gradient must reproduce the quiet run's bits, five times over"""
+    from cuda_gcn_amd.ops import Device, _ck
+    N, F, p = 400001, 602, 128
+    rng = np.random.default_rng(21)
+    vals = rng.standard_normal(N * F, dtype=np.float32)
+    fp = (np.arange(N + 1, dtype=np.int64) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    f = dev.feat(fp, fi, vals, F)
+    del fi, vals
+    assert f.dense
+    lib = dev.lib
+    w = dev.buf((rng.standard_normal((F, p)) * 0.05).astype(np.float32))
+    dh = dev.buf((rng.standard_normal((N, p)) * 1e-3).astype(np.float32))
+    out, dw = dev.buf(np.zeros((N, p), np.float32)), dev.buf(np.zeros((F, p), np.float32))
+    ep = dev.buf(np.array([3], np.uint32))
+
+    def run():
+        res = []
+        for pd in (0.0, 0.5):
+            _ck(lib, lib.gcnhip_spmm_fwd(dev.ctx, f.h, f.values_ptr, w.ptr, p, out.ptr, p, p, pd, 7, ep.ptr, 0, None), "fwd")
+            res.append(out.download().copy())
+        _ck(lib, lib.gcnhip_spmm_bwd(dev.ctx, f.h, f.values_ptr, dh.ptr, p, dw.ptr, p, p, 0.5, 7, ep.ptr, 0, None), "bwd")
+        res.append(dw.download().copy())
+        return res
+    quiet = run()
+    hog = Device(0)
+    nh = 1 << 19
+    lo, hi = datagen._sample_edges(rng, nh, 8 * nh)
+    gp, gi = datagen.csr_with_self_loops(lo, hi, nh)
+    g = hog.graph(gp, gi)
+    x = hog.buf(rng.standard_normal((nh, 256), dtype=np.float32))
+    y = hog.buf(np.zeros((nh, 256), np.float32))
+    try:
+        for it in range(5):
+            for _ in range(8):
+                _ck(hog.lib, hog.lib.gcnhip_graphsum(hog.ctx, g.h, x.ptr, 256, y.ptr, 256, 256), "hog")
+            got = run()
+            for q, r, what in zip(quiet, got, ("X.W", "X~.W", "X~^T.dH0")):
+                assert np.array_equal(q.view(np.uint32), r.view(np.uint32)), (it, what)
+        hog.sync()
+    finally:
+        g.free(); hog.close(); f.free()
+
+
+def test_class_layer_products_beside_a_bandwidth_hog(dev):
+    """the kernels of class_bf16x3.h keep their loads in flight under hand-counted waits; a wrong count shows only when loads
+    are slow.  Here a second context on the same GPU keeps a large aggregation running (gather traffic on every channel) while
+    H1.W2 and the fused backward run on inputs far larger than the 256 MiB Infinity Cache (a million rows: every load comes from
+    HBM, as at R-MAT scale 22): every result must have the bits of the quiet run, ten times over.  (Validated against the first
+    version of the forward kernel, whose loop copied registers of loads in flight: it fails here; cache-resident sizes pass.)"""
+    from cuda_gcn_amd.ops import Device, _ck
+    m, n, p, ldp = 1000001, 128, 41, 48
+    rng = np.random.default_rng(12)
+    a = (rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.3)).astype(np.float32)
+    b = (rng.standard_normal((n, p)) * 0.3).astype(np.float32)
+    dc = (rng.standard_normal((m, p)) * 1e-3).astype(np.float32)
+    rs = (1.0 / rng.integers(1, 500, m)).astype(np.float32)
+    bits = np.packbits(a > 0, axis=1, bitorder="little").view(np.uint32)        # bit (c & 31) of word c >> 5
+    lib = dev.lib
+    ab, bb, dcb = dev.buf(a), dev.padded(b, ldp), dev.padded(dc, ldp)
+    bt, rsb = dev.buf(bits), dev.buf(rs)
+    z, da, db = dev.buf(np.zeros((m, ldp), np.float32)), dev.buf(np.zeros((m, n), np.float32)), dev.buf(np.zeros((n, ldp), np.float32))
+
+    def run():
+        _ck(lib, lib.gcnhip_matmul_fwd(dev.ctx, ab.ptr, n, bb.ptr, ldp, z.ptr, ldp, m, n, p), "fwd")
+        _ck(lib, lib.gcnhip_matmul_bwd_ex(dev.ctx, ab.ptr, n, bb.ptr, ldp, dcb.ptr, ldp, da.ptr, n, db.ptr, ldp, m, n, p, 2.0, bt.ptr, 4, rsb.ptr), "bwd")
+        return z.download()[:, :p].copy(), da.download().copy(), db.download()[:, :p].copy()
+    quiet = run()
+    # the hog: a 2^19-node random graph aggregated at width 256 (a 512 MB table: HBM regime), launched asynchronously on its own stream
+    hog = Device(0)
+    nh = 1 << 19
+    lo, hi = datagen._sample_edges(rng, nh, 8 * nh)
+    gp, gi = datagen.csr_with_self_loops(lo, hi, nh)
+    g = hog.graph(gp, gi)
+    x = hog.buf(rng.standard_normal((nh, 256), dtype=np.float32))
+    y = hog.buf(np.zeros((nh, 256), np.float32))
+    try:
+        for it in range(10):
+            for _ in range(6):
+                _ck(hog.lib, hog.lib.gcnhip_graphsum(hog.ctx, g.h, x.ptr, 256, y.ptr, 256, 256), "hog")
+            got = run()
+            for q, w, what in zip(quiet, got, ("H1.W2", "dH1", "dW2")):
+                assert np.array_equal(q.view(np.uint32), w.view(np.uint32)), (it, what)
+        hog.sync()
+    finally:
+        g.free(); hog.close()
+
+
 @pytest.mark.parametrize("m,n,p", [(1000, 128, 41), (333, 16, 7), (70000, 128, 41), (65, 70, 3), (1, 1, 1), (4097, 200, 47)])
 def test_pack_positive_and_da_from_bits(dev, m, n, p):
     """multi-GPU backward: the ReLU/dropout mask travels as one bit per element and
