@@ -36,6 +36,8 @@ struct GcnOptions {
     int gemm_w4;            // 1: four-wave forward tiles
     int cls_abl;            // measurement aid (tools/bench_class.py): class_bf16x3.h kernels without 1: matrix work, 2: stores, 4: the column-wise operand loads
     int cls_wgs;            // measurement aid: workgroups per CU of the class-layer forward (0: default)
+    int gemm_lane_waves;    // waves per workgroup of the bf16x3 first-layer forward on a co-running context: 8 (default) or 4 (measured: no gain)
+    int gemm_lane_wgs;      // workgroups (= CUs) of that launch; 0: one per CU
     int cls_fwd;            // 1 (default): H1.W2 through class_bf16x3.h when gemm_bf16x3 >= 1; 0: through the f32-MFMA row stream
     int gemm_persist_bwd;   // 1: persistent first-layer weight gradient (measured slower)
     int dbg_linear;         // timing experiment only: the persistent forward reads X as if tile-major (wrong results)

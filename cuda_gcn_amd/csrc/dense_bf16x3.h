@@ -118,8 +118,15 @@ __device__ __forceinline__ void bx_ldsread16(bf16x8 &dst, uint32_t addr) {
 // The last round of a workgroup may have fewer than 8 row blocks: waves without one run the same instruction stream on the
 // share's last row and store nothing (the counted waits need every wave to issue the same operations).
 // ABL (timing experiments only, wrong results): 1 no X loads, 2 no W DMA, 4 no split, 8 no W LDS reads
-template <bool DROP, int NP, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) {
+// NW = waves per workgroup.  8: the whole-chip form (two waves per SIMD fill the CU's register file).  4 (round 5, for a context
+// that runs BESIDE another stream's kernels — the validation lane): one wave per SIMD and half the register file, so that a
+// gather-bound kernel's waves can be resident on the same CU at the same time.  The eight-wave workgroup needs an EMPTY CU to
+// start: beside the training pass's hidden-width aggregation it is handed CUs only as they drain and runs 895 us instead of
+// 198 (kernel timeline, docs/NOTEBOOK_r5.md §7).  Measured: co-residency costs the aggregation half its waves on those CUs and
+// the epoch gains nothing (option gemm_lane_waves, default 8).
+template <bool DROP, int NP, int ABL = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) {
+    static_assert(NW == 8 || NW == 4, "12 W pieces per k-step: two per wave of eight (four of them duplicates) or three per wave of four");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BX_SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,14 +138,14 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
     const int nb = (int)((int64_t)(blockIdx.x + 1) * a.n_rb / gridDim.x) - rb_lo;
     if (nb <= 0) return;
     const int row_last = min(a.m, (rb_lo + nb) * 32) - 1;       // rows past this workgroup's share are read as its last row (cache hits, no HBM traffic)
-    const int n_rounds = (nb + 7) >> 3;
+    const int n_rounds = (nb + NW - 1) / NW;
     const int n_items = n_rounds * a.n_chunks;                   // chunks of this wave, all rounds
     const int n_hs = 2 * a.n_chunks;
-    const int piece2 = wave < 4 ? wave + 8 : wave - 4;           // second DMA piece of this wave (waves 4-7: a duplicate of one of pieces 0-3)
+    const int piece2 = NW == 4 ? wave + 4 : (wave < 4 ? wave + 8 : wave - 4);   // second DMA piece of this wave (eight waves: waves 4-7 repeat one of pieces 0-3)
 
     // the X values (and keep words) of chunk (round t, chunk c) of this lane's row
     auto load_raw = [&](BxRaw &r, int t, int c) __attribute__((always_inline)) {
-        const int row = min((rb_lo + 8 * t + wave) * 32 + li, row_last);
+        const int row = min((rb_lo + NW * t + wave) * 32 + li, row_last);
         const float *p = a.x + (size_t)row * a.ldx + c * BX_BK + 16 * hh;
         if (ABL & 1) p = a.x + lane * 16;
         bx_gload16<0>(r.v[0], p); bx_gload16<16>(r.v[1], p); bx_gload16<32>(r.v[2], p); bx_gload16<48>(r.v[3], p);
@@ -158,7 +165,10 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         const uint4 *src = a.wp + (size_t)hs * (BX_BH_BYTES / 16);
         pg_glds16(src + wave * 64 + lane, dst + wave * 1024);
         pg_glds16(src + piece2 * 64 + lane, dst + piece2 * 1024);
+        if (NW == 4) pg_glds16(src + (wave + 8) * 64 + lane, dst + (wave + 8) * 1024);
     };
+    // what the W wait allows: the younger W pieces of this wave, BX_PD - 2 k-steps of 2 (eight waves) or 3 (four waves) pieces
+#define BX_WAIT_W() do { if (ABL & 16) PG_WAIT_BARRIER(0); else if (NW == 4) PG_WAIT_BARRIER(12); else PG_WAIT_BARRIER(8); } while (0)
 
     f32x16 acc[4];
 #pragma unroll
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
     };
     auto window = [&](const BxRaw &r, int t, int c) __attribute__((always_inline)) -> uint32_t {
         if (!DROP) return 0u;
-        const int row = min((rb_lo + 8 * t + wave) * 32 + li, row_last);
+        const int row = min((rb_lo + NW * t + wave) * 32 + li, row_last);
         const uint32_t sh = (uint32_t)(((uint64_t)row * a.K + c * BX_BK + 16 * hh) & 31);
         return (uint32_t)(((((uint64_t)r.kw[1]) << 32) | r.kw[0]) >> sh);
     };
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         BX_WAIT_LDS(Bc);
         // W k-step h0+1 has landed: issued BX_PD-1 half-items ago, BX_PD-2 younger k-steps of two pieces each.  Every wave is past
         // half-item h0-1: its ring slot takes k-step h0+BX_PD
-        if (ABL & 16) PG_WAIT_BARRIER(0); else PG_WAIT_BARRIER(8);
-        static_assert(2 * (BX_PD - 2) == 8, "the W wait above allows the younger W pieces: 2 per k-step");
+        BX_WAIT_W();
+        static_assert(2 * (BX_PD - 2) == 8 && 3 * (BX_PD - 2) == 12, "the W wait above allows the younger W pieces: 2 (3) per k-step");
         issue_b(h0 + BX_PD);
         load_raw(Rc, t2, c2);
         read_b(Bn, h0, BxN<3>());
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         BX_PIN(P0, 1);
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
-        if (ABL & 16) PG_WAIT_BARRIER(0); else PG_WAIT_BARRIER(8);
+        BX_WAIT_W();
         issue_b(h0 + 1 + BX_PD);
         read_b(Bn, h0 + 1, BxN<3>());
         __builtin_amdgcn_sched_barrier(0);
@@ -337,9 +347,9 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
         if (c == a.n_chunks - 1) {
-            const bool live = 8 * t + wave < nb;
+            const bool live = NW * t + wave < nb;
 #pragma unroll
-            for (int n = 0; n < 4; n++) store_block(acc[n], (rb_lo + 8 * t + wave) * 32, 32 * n + li, live);
+            for (int n = 0; n < 4; n++) store_block(acc[n], (rb_lo + NW * t + wave) * 32, 32 * n + li, live);
         }
     };
     int g = 0;
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) 
     BX_WAIT_RAW(0, R1);
     BX_WAIT_RAW(0, R2);
 }
+#undef BX_WAIT_W
 
 // ------------------------------------------------------------------------------------------------ backward
 // dW[K x 128] = X~^T[K x m] . dH0[m x 128]: the rows are the reduction.  Grid (feature range of 128, row split); a workgroup is

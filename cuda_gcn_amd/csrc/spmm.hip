@@ -225,9 +225,15 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
             ba.x = t.x; ba.ldx = t.ldx; ba.wp = wp3; ba.out = out; ba.ldo = ld_out;
             ba.m = t.m; ba.K = t.K; ba.n_chunks = n_chunks; ba.n_rb = ceil_div(t.m, 32);
             ba.bits = t.bits; ba.relu = relu;
-            const int wgs = std::max(1, std::min(c->n_cu, ba.n_rb));
-            if (ba.bits) dense_fwd_bf16x3_kernel<true, 6><<<wgs, 512, 0, c->stream>>>(ba);
-            else dense_fwd_bf16x3_kernel<false, 6><<<wgs, 512, 0, c->stream>>>(ba);
+            int wgs = std::max(1, std::min(c->n_cu, ba.n_rb));
+            if (c->corun && c->opt.gemm_lane_wgs > 0) wgs = std::max(1, std::min(wgs, c->opt.gemm_lane_wgs));   // fewer CUs host the lane's product
+            // option gemm_lane_waves = 4: a context that runs beside another stream's kernels takes the four-wave form (half a CU's
+            // registers: co-resident with a gather-bound kernel's waves).  Measured (docs/NOTEBOOK_r5.md §7): the lane's product is
+            // then truly concurrent with the training pass's aggregation, which loses half its resident waves on those CUs —
+            // 347.5 (256 CUs), 351.5 (128), 340 (64) epochs/s against 351.0 for the eight-wave form: not the default
+            const bool four = c->corun && c->opt.gemm_lane_waves == 4;
+            if (ba.bits) { if (four) dense_fwd_bf16x3_kernel<true, 6, 0, 4><<<wgs, 256, 0, c->stream>>>(ba); else dense_fwd_bf16x3_kernel<true, 6><<<wgs, 512, 0, c->stream>>>(ba); }
+            else { if (four) dense_fwd_bf16x3_kernel<false, 6, 0, 4><<<wgs, 256, 0, c->stream>>>(ba); else dense_fwd_bf16x3_kernel<false, 6><<<wgs, 512, 0, c->stream>>>(ba); }
             GCNHIP_LAUNCH_CHECK();
             return 0;
         }
