@@ -6,12 +6,12 @@ guide asks for on one's own access pattern: TCC_MISS_sum x 128 B (every L2 miss 
 2 x FETCH_SIZE.  `_meta` ties the file to the tree it was taken on (bench.py refuses a profile whose kernel name or
 duration does not match the launch it has just timed).
 
-    python3 tools/pmc_summary.py <dir> [commit] [what was run] [kernel-name substring, default graphsum]
+    python3 tools/pmc_summary.py <dir> [commit] [what was run] [kernel-name substrings, comma separated; default graphsum]
 """
 import collections, csv, glob, json, os, statistics, sys
 
 root = sys.argv[1]
-match = sys.argv[4] if len(sys.argv) > 4 else "graphsum"
+match = (sys.argv[4] if len(sys.argv) > 4 else "graphsum").split(",")      # kernel-name substrings, comma separated
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 
@@ -29,7 +29,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*_kernel_trace.csv"), recursiv
 out = {"_meta": {"commit": sys.argv[2] if len(sys.argv) > 2 else None, "what": sys.argv[3] if len(sys.argv) > 3 else None,
                  "counters": "median per launch; one rocprofv3 --pmc pass per counter group, --kernel-trace only"}}
 for k, cs in agg.items():
-    if match not in k:
+    if not any(m in k for m in match):
         continue
     d = {c: statistics.median(v) for c, v in cs.items()}
     d["launches"] = max(len(v) for v in cs.values())
