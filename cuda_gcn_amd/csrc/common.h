@@ -38,6 +38,7 @@ struct GcnOptions {
     int cls_wgs;            // measurement aid: workgroups per CU of the class-layer forward (0: default)
     int gemm_lane_waves;    // waves per workgroup of the bf16x3 first-layer forward on a co-running context: 8 (default) or 4 (measured: no gain)
     int gemm_lane_wgs;      // workgroups (= CUs) of that launch; 0: one per CU
+    int spmm_slices;        // 1 (default): sparse X, W past an XCD's L2, h % 32 == 0: XCD-bound 32-float column slices of W; 0: the unsliced row kernel
     int cls_fwd;            // 1 (default): H1.W2 through class_bf16x3.h when gemm_bf16x3 >= 1; 0: through the f32-MFMA row stream
     int gemm_persist_bwd;   // 1: persistent first-layer weight gradient (measured slower)
     int dbg_linear;         // timing experiment only: the persistent forward reads X as if tile-major (wrong results)

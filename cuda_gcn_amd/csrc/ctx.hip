@@ -20,7 +20,7 @@ int gcnhip_fail(const char *detail) {
 
 const GcnOptionEntry GCN_OPTION_TABLE[] = {
     {"gs_pipe", &GcnOptions::gs_pipe, 0}, {"gs_u", &GcnOptions::gs_u, 0}, {"gs_nt", &GcnOptions::gs_nt, 0}, {"gs_fold", &GcnOptions::gs_fold, 0}, {"gs_l", &GcnOptions::gs_l, 0},
-    {"gemm_tiles", &GcnOptions::gemm_tiles, 0}, {"gemm_bf16x3", &GcnOptions::gemm_bf16x3, 2}, {"gemm_w4", &GcnOptions::gemm_w4, 0}, {"cls_abl", &GcnOptions::cls_abl, 0}, {"cls_wgs", &GcnOptions::cls_wgs, 0}, {"cls_fwd", &GcnOptions::cls_fwd, 1}, {"gemm_lane_waves", &GcnOptions::gemm_lane_waves, 8}, {"gemm_lane_wgs", &GcnOptions::gemm_lane_wgs, 0}, {"gemm_persist_bwd", &GcnOptions::gemm_persist_bwd, 0},
+    {"gemm_tiles", &GcnOptions::gemm_tiles, 0}, {"gemm_bf16x3", &GcnOptions::gemm_bf16x3, 2}, {"gemm_w4", &GcnOptions::gemm_w4, 0}, {"cls_abl", &GcnOptions::cls_abl, 0}, {"cls_wgs", &GcnOptions::cls_wgs, 0}, {"cls_fwd", &GcnOptions::cls_fwd, 1}, {"spmm_slices", &GcnOptions::spmm_slices, 1}, {"gemm_lane_waves", &GcnOptions::gemm_lane_waves, 8}, {"gemm_lane_wgs", &GcnOptions::gemm_lane_wgs, 0}, {"gemm_persist_bwd", &GcnOptions::gemm_persist_bwd, 0},
     {"dbg_linear", &GcnOptions::dbg_linear, 0}, {"xent_finalize", &GcnOptions::xent_finalize, 0}, {"xent_wave", &GcnOptions::xent_wave, 0},
     {"adam_sum_launch", &GcnOptions::adam_sum_launch, 0}, {"atb_cap_mb", &GcnOptions::atb_cap_mb, 12}, {"rs_wgs", &GcnOptions::rs_wgs, 0},
     {"spmm_lds", &GcnOptions::spmm_lds, 0}, {"spmm_rows", &GcnOptions::spmm_rows, 0}, {"spmm_general", &GcnOptions::spmm_general, 0}, {"spmm_nw", &GcnOptions::spmm_nw, 0}, {"split_edges", &GcnOptions::split_edges, 0},

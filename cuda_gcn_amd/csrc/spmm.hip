@@ -347,6 +347,21 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
     // rows per wave: enough waves to fill every slot about twice, at most 8 rows each (one wave per row on small inputs)
     a.rows_per_wave = std::max(1, std::min(8, (int)(f->n_rows / ((int64_t)c->n_cu * 64))));
     if (c->opt.spmm_rows > 0) a.rows_per_wave = std::min(32, c->opt.spmm_rows);
+    a.n_slices = 1;
+    // a W past an XCD's L2 (4 MiB), rows of whole 32-float slices: the XCD-sliced form (spmm_sparse.h; option spmm_slices = 0: off)
+    if (vec && c->opt.spmm_slices != 0 && p % 32 == 0 && (p / 32 == 2 || p / 32 == 4 || p / 32 == 8) &&
+        (size_t)f->n_cols * ld_w * sizeof(float) > ((size_t)4 << 20) && f->n_rows >= 8 * 64) {
+        a.n_slices = p / 32;
+        if (c->opt.spmm_rows <= 0) a.rows_per_wave = 2;            // measured, 2 M rows of 50 values, h = 128: 4.58 / 4.00 / 4.32 / 4.41 / 4.52 ms at 1 / 2 / 4 / 8 / 16
+        const int Gs = 8 / a.n_slices;
+        const int units_total = ceil_div(f->n_rows, a.rows_per_wave);
+        const int per_group = ceil_div(units_total, Gs) + 1;       // (+1: the shares differ by at most one unit)
+        dim3 sgrid(8 * ceil_div(per_group, 4), 1);
+        a.nnz_bytes = (int)std::min<int64_t>(f->nnz * 4, 0x7FFFFFFF);
+        spmm_csr_fwd_kernel<8, true, true><<<sgrid, 256, 0, c->stream>>>(a);
+        GCNHIP_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(ceil_div(ceil_div(f->n_rows, a.rows_per_wave), 4), 1);
     a.nnz_bytes = (int)std::min<int64_t>(f->nnz * 4, 0x7FFFFFFF);
     // narrow 16-byte aligned rows (hidden <= 64; the reference's default is 16): the shuffle-free kernel (spmm_sparse.h)

@@ -100,6 +100,7 @@ struct SpFwdArgs {
     int w_floats;                   // LDS form: floats of W to stage (n_cols * ld_w)
     int rows_per_wave;              // consecutive rows a wave of spmm_csr_fwd_kernel walks (1 .. 32)
     int nnz_bytes;                  // size of indices[] and vals[] in bytes (bounds of the narrow-row kernel's buffer loads)
+    int n_slices;                   // SLICED kernel: p = n_slices * L * 4 columns, one slice of L * 4 per XCD group (1, 2, 4 or 8)
 };
 
 template <int L, bool VEC>
@@ -142,22 +143,42 @@ __device__ __forceinline__ void sp_fwd_row(const SpFwdArgs &a, const float *w, i
 // wave's next row — are already on their way: per row one exposed round trip (the gather) instead of three dependent ones
 // (row pointers -> pairs -> W rows), which is what a 50-value row costs when a wave lives for one row (measured: 2 M rows of
 // 50 values, h = 16: 0.97 ms with a wave per row).  Same lane groups, same order: bit-identical to sp_fwd_row.
-template <int L, bool VEC>
+// SLICED (round 5): a W that does not fit an XCD's 4 MiB L2 (F x h x 4 bytes: 25.6 MB at F = 50 000, h = 128) is gathered from
+// the Infinity Cache at the uniformly-random-row rate whatever the kernel does (8.8 TB/s of W rows, 6.0 ms for 2 M rows of 50
+// values: verdict r04's "fabric traffic 25 x B_sp").  As in the aggregation kernel (graphsum.hip) the columns are cut into
+// slices of L * 4 floats and each slice is bound to the workgroups of one XCD group (blockIdx % 8), which also takes a
+// contiguous share of the rows: an XCD's L2 then sees 1 / n_slices of W — 6.4 MB of 25.6 at 32-float slices — at the price of
+// reading the (index, value) stream n_slices times.  Measured with the aggregation kernel standing in (tools/exp_spmm_gather.py):
+// 5.06 / 3.83 / 7.4 ms at 64- / 32- / 16-float slices against 6.04.  Another summation order per row (8 lane groups instead
+// of 2 at h = 128): inside the summation bound, not the bits of the unsliced kernel.
+template <int L, bool VEC, bool SLICED = false>
 __global__ __launch_bounds__(256) void spmm_csr_fwd_kernel(SpFwdArgs a) {
     constexpr int V = VEC ? 4 : 1;
     const int lane = threadIdx.x & 63;
     const int K = a.rows_per_wave;                            // 1 .. 32
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * K;
+    int row0, cslice = 0;
+    if (SLICED) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int G = 8 / a.n_slices, g_id = xcd / a.n_slices;     // XCD groups that share the rows; which share
+        cslice = xcd % a.n_slices;
+        const int units = (a.n_rows + K - 1) / K;
+        const int lo = (int)((int64_t)units * g_id / G), hi = (int)((int64_t)units * (g_id + 1) / G);
+        const int u = lo + q * 4 + (threadIdx.x >> 6);
+        if (u >= hi) return;
+        row0 = u * K;
+    } else {
+        row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * K;
+    }
     if (row0 >= a.n_rows) return;
     const uint32_t epoch = (a.d.on && a.d.d_epoch) ? *a.d.d_epoch : 0u;
-    if (a.p > L * V) {                                        // more than one column pass (p > 256): the plain walk
+    if (!SLICED && a.p > L * V) {                             // more than one column pass (p > 256): the plain walk
         for (int r = row0; r < min(a.n_rows, row0 + K); r++) sp_fwd_row<L, VEC>(a, a.w, r, lane, epoch);
         return;
     }
     const int nr = min(K, a.n_rows - row0);
     const int ip = a.indptr[row0 + min(lane, nr)];
     const int g = lane / L, l = lane % L;
-    const int col0 = l * V;
+    const int col0 = (SLICED ? cslice * L * V : 0) + l * V;
     const bool active = col0 < a.p;
     const float *wp = a.w + (active ? col0 : 0);
     int r = 0;

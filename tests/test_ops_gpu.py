@@ -585,6 +585,45 @@ def test_spmm_sparse_vs_oracle(dev, oracle, name, p):
     f.free()
 
 
+@pytest.mark.parametrize("p", [128, 64, 256])
+def test_spmm_sparse_sliced_forward_vs_oracle(dev, oracle, p):
+    """a W past an XCD's L2 (F x p x 4 bytes > 4 MiB) with rows of whole 32-float pieces takes the XCD-sliced forward (spmm_sparse.h,
+    round 5): against the oracle's SparseMatmul (module.cpp:47-61) within the summation bound, with dropout (injected decisions and
+    device RNG), the ReLU epilogue, ragged and empty rows, a row count that is not a multiple of anything; and beside the unsliced
+    kernel (option spmm_slices = 0) on the same inputs"""
+    rng = np.random.default_rng(p)
+    N, F = 4099, (4 << 20) // (p * 4) + 700
+    lens = rng.integers(0, 40, N); lens[7] = 0; lens[11] = 300
+    fp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    fi = np.concatenate([np.sort(rng.choice(F, int(k), replace=False)) for k in lens]).astype(np.int32)
+    vals = rng.standard_normal(fi.size).astype(np.float32)
+    w = rng.standard_normal((F, p)).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    assert not f.dense
+    old = C.c_int(0)
+    dev.lib.gcnhip_ctx_get_option(dev.ctx, b"spmm_slices", C.byref(old))
+    try:
+        outs = {}
+        for mode in (1, 0):
+            dev.lib.gcnhip_ctx_set_option(dev.ctx, b"spmm_slices", mode)
+            want, mag = oracle.spmm_fwd(fp, fi, vals, w, p), oracle.spmm_fwd(fp, fi, np.abs(vals), np.abs(w), p)
+            got = dev.spmm_fwd(f, w)
+            close_mag(got, want, mag)
+            outs[mode] = got
+            close_mag(dev.spmm_fwd_relu(f, w), np.maximum(want, 0), mag)
+            keep = rng.integers(0, 2, fi.size).astype(np.uint8)
+            vd = (vals * np.where(keep != 0, np.float32(2), np.float32(0))).astype(np.float32)
+            close_mag(dev.spmm_fwd(f, w, p_drop=0.5, keep_mask=keep), oracle.spmm_fwd(fp, fi, vd, w, p), mag * 2)
+            k = philox_keep(5, 2, np.arange(fi.size, dtype=np.uint64), thr_of(0.5))
+            vd = (vals * np.where(k, np.float32(2), np.float32(0))).astype(np.float32)
+            close_mag(dev.spmm_fwd(f, w, p_drop=0.5, seed=5, epoch=2), oracle.spmm_fwd(fp, fi, vd, w, p), mag * 2)
+        assert not np.array_equal(outs[0], outs[1]) or p == 0          # (two summation orders: the sliced kernel really ran)
+        assert np.all(outs[1][7] == 0.0)                                # the empty row
+    finally:
+        dev.lib.gcnhip_ctx_set_option(dev.ctx, b"spmm_slices", old.value)
+    f.free()
+
+
 def _skewed_sparse_x(rng, n, f, nnz_row, hot_cols, hot_share):
     """n rows of nnz_row distinct sorted columns, a share of them drawn from the first hot_cols columns: a few very long
     columns (bag-of-words stop words) beside many short ones, some empty rows and empty columns"""
