@@ -525,6 +525,30 @@ def test_loss_epilogue_is_bit_identical_to_the_loss_kernel(name, hidden, lane):
     a.close(); b.close()
 
 
+def test_f32_mfma_products_stay_selectable():
+    """HIPGCN_GEMM=f32 (HipGCNOptions::gemm -> context option gemm_bf16x3 = 0 on the training and the lane context): the first-layer
+    and class-layer products on the exact-f32 MFMA kernels of rounds 1-4.  Same real numbers as the bf16x3 default, another
+    rounding: traces within 2e-5, weights within Adam's amplification of it — and not the same bits (the switch took effect)"""
+    from cuda_gcn_amd.model import HipGCNModel
+    ds = datagen.make_dataset("reddit-mini")
+    a = HipGCNModel(ds, seed=4, hidden_dim=128, dropout=0.5, epochs=8)
+    os.environ["HIPGCN_GEMM"] = "f32"
+    try:
+        b = HipGCNModel(ds, seed=4, hidden_dim=128, dropout=0.5, epochs=8)
+    finally:
+        del os.environ["HIPGCN_GEMM"]
+    ta, tb = a.run_epochs(6), b.run_epochs(6)
+    assert np.abs(ta[:, [0, 2]] - tb[:, [0, 2]]).max() <= 2e-5
+    assert np.abs(ta[:, [1, 3]] - tb[:, [1, 3]]).max() <= 2.0 / int((ds["split"] == 2).sum())
+    assert not np.array_equal(a.var(2), b.var(2))
+    # (Adam's step is lr * m / (sqrt(v) + eps): where a gradient element is ~1e-7 its rounding decides the sign of a step of ~lr,
+    #  so a handful of the 77 K + 5 K weights may sit a few steps apart after eight epochs; the bulk must agree)
+    for v in (2, 5):
+        dw = np.abs(a.var(v).astype(np.float64) - b.var(v))
+        assert np.median(dw) <= 1e-5 and np.mean(dw > 2e-3) <= 2e-3, (v, float(np.median(dw)), float(np.mean(dw > 2e-3)), float(dw.max()))
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""
