@@ -117,6 +117,7 @@ GCNHIP_SYMBOLS = {
     "gcnhip_feat_nnz": (I64, [P]),
     "gcnhip_spmm_fwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
     "gcnhip_spmm_fwd_relu": (I, [P, P, P, P, I, P, I, I]),
+    "gcnhip_spmm_fwd_relu_matmul": (I, [P, P, P, P, I, I, P, I, I, P, I]),
     "gcnhip_spmm_bwd": (I, [P, P, P, P, I, P, I, I, F, U64, P, U64, P]),
     "gcnhip_spmm_bwd_plan": (I, [P, P, I, C.POINTER(I), C.POINTER(I)]),
     "gcnhip_spmm_bwd_part": (I, [P, P, P, P, I, I, F, U64, P, U64, P, I, I, I]),

@@ -68,6 +68,7 @@ int gcnhip_device_count(int *count) {
 
 const char *gcnhip_error_string(int code) {
     if (code == -1) return "gcnhip: invalid argument";
+    if (code == GCNHIP_NOT_AVAILABLE) return "gcnhip: this fused form is not available for these shapes / options (nothing was launched)";
     return hipGetErrorString((hipError_t)code);
 }
 

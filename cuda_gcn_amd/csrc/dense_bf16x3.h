@@ -57,8 +57,33 @@ __device__ inline void bx_pack_w_body(int idx, const float *__restrict__ w, int 
 #pragma unroll
     for (int p = 0; p < 3; p++) wp[(((size_t)hs * 3 + p) * 4 + n) * 64 + lane] = make_uint4(P.w[p][0], P.w[p][1], P.w[p][2], P.w[p][3]);
 }
-__global__ __launch_bounds__(256) void bx_pack_w_kernel(const float *__restrict__ w, int ldw, int K, int n_hs, uint4 *__restrict__ wp, float scale) {
-    bx_pack_w_body(blockIdx.x * blockDim.x + threadIdx.x, w, ldw, K, n_hs, wp, scale);
+// W2 [128 x p2] -> the ZOUT form's A image: piece (s, cb) of lane ln = (c, h) holds plane p of W2[f(s, h, j)][32 cb + c], j = 0..7,
+// f(s, h, j) = 32 (s >> 1) + (j & 3) + 8 ((j >> 2) + 2 (s & 1)) + 4 h — the feature that accumulator register 8 (s & 1) + j of
+// block s >> 1 holds in lane half h of the transposed tile; classes past p2: zero.  One thread per (s, cb, lane): 1024.
+__device__ inline void bx_pack_w2_body(int idx, const float *__restrict__ w2, int ldw2, int p2, uint4 *__restrict__ img) {
+    if (idx >= 8 * 2 * 64) return;
+    const int ln = idx & 63, cb = (idx >> 6) & 1, s = idx >> 7;
+    const int c = 32 * cb + (ln & 31), h = ln >> 5;
+    BxPlanes P;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = 2 * i + u;
+            const int f = 32 * (s >> 1) + (j & 3) + 8 * ((j >> 2) + 2 * (s & 1)) + 4 * h;
+            v[u] = c < p2 ? w2[(size_t)f * ldw2 + c] : 0.f;
+        }
+        bx_split2(v[0], v[1], P.w[0][i], P.w[1][i], P.w[2][i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) img[((s * 2 + cb) * 3 + p) * 64 + ln] = make_uint4(P.w[p][0], P.w[p][1], P.w[p][2], P.w[p][3]);
+}
+// (w2 == NULL: the W planes alone; else four more workgroups lay the W2 image out)
+__global__ __launch_bounds__(256) void bx_pack_w_kernel(const float *__restrict__ w, int ldw, int K, int n_hs, uint4 *__restrict__ wp, float scale,
+                                                        const float *__restrict__ w2 = nullptr, int ldw2 = 0, int p2 = 0, uint4 *__restrict__ img = nullptr) {
+    if ((int)blockIdx.x < n_hs) bx_pack_w_body(blockIdx.x * blockDim.x + threadIdx.x, w, ldw, K, n_hs, wp, scale);
+    else bx_pack_w2_body(((int)blockIdx.x - n_hs) * 256 + threadIdx.x, w2, ldw2, p2, img);
 }
 // keep bits + packed W in one launch (as dropbits_pack_w_kernel of dense_persist.h)
 __global__ __launch_bounds__(256) void dropbits_bx_pack_w_kernel(uint32_t *__restrict__ bits, int64_t n_elems, int thr, uint64_t seed,
@@ -76,7 +101,11 @@ struct Bx3FwdArgs {
     int m, K, n_chunks, n_rb;         // n_chunks = ceil(K / 32); n_rb = ceil(m / 32)
     const uint32_t *bits;             // keep bits of the stored elements (element row*K + col), NULL: no dropout
     int relu;
+    // ZOUT form (evaluation): the second layer's product rides in the epilogue — Z0 = relu(X.W) . W2 leaves, H never does
+    const uint4 *w2p;                 // planes of W2 as the A operand of Z0^T = W2^T . H^T (bx_pack_w2_body): 16 pieces of 3 KB
+    float *z0; int ldz, p2;           // Z0 [m x p2], p2 <= 64, 16-byte aligned rows
 };
+constexpr int BX_W2_BYTES = 8 * 2 * 3 * 1024;                // 49152
 
 struct BxB3 { bf16x8 h, m, l; };
 template <int N> struct BxN { static constexpr int value = N; };
@@ -124,10 +153,21 @@ __device__ __forceinline__ void bx_ldsread16(bf16x8 &dst, uint32_t addr) {
 // start: beside the training pass's hidden-width aggregation it is handed CUs only as they drain and runs 895 us instead of
 // 198 (kernel timeline, docs/NOTEBOOK_r5.md §7).  Measured: co-residency costs the aggregation half its waves on those CUs and
 // the epoch gains nothing (option gemm_lane_waves, default 8).
-template <bool DROP, int NP, int ABL = 0, int NW = 8>
+// ZOUT (round 5, evaluation forwards; verdict r04 item 4c): the product is computed TRANSPOSED (W planes as the A operand, the X
+// planes as B: the same plane products in the same order), so that a lane ends up with ONE ROW and, in its accumulator
+// registers, that row's features — which is the layout the B operand of a second product Z0^T = W2^T . relu(H)^T wants: register
+// group 8(s & 1) .. +7 of feature block s >> 1 is k-step s, with the k slots permuted (slot (h, j) = feature (j & 3) + 8 (j >> 2) +
+// 4 h of the 16) exactly as bx_pack_w2_body lays W2 out.  At the end of a round the 32 x 128 tile of H is clamped at zero, split
+// into planes in registers and multiplied by the W2 image (48 KB of LDS beside a ring of 8 instead of 10 W k-steps); Z0's 32 x p2
+// tile is stored, H is not: 119 MB less written, 119 MB less read, one launch less per evaluation forward.
+template <bool DROP, int NP, int ABL = 0, int NW = 8, bool ZOUT = false>
 __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) {
     static_assert(NW == 8 || NW == 4, "12 W pieces per k-step: two per wave of eight (four of them duplicates) or three per wave of four");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[BX_SMEM];
+    // ring slots: k-step h + BX_PD is written (after the barrier of half-item h) into the slot of k-step h + BX_PD - NBV, which
+    // every wave has finished reading once it is past half-item h - 1: NBV >= BX_PD + 1
+    constexpr int NBV = ZOUT ? 8 : BX_NB;
+    static_assert(NBV >= BX_PD + 1, "ring too short for the prefetch distance");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NBV * BX_BH_BYTES + (ZOUT ? BX_W2_BYTES : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
@@ -161,7 +201,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     auto issue_b = [&](int hq) __attribute__((always_inline)) {
         if (ABL & 2) return;
         int hs = hq % n_hs;
-        const uint32_t dst = lds0 + (hq % BX_NB) * BX_BH_BYTES;
+        const uint32_t dst = lds0 + (hq % NBV) * BX_BH_BYTES;
         const uint4 *src = a.wp + (size_t)hs * (BX_BH_BYTES / 16);
         pg_glds16(src + wave * 64 + lane, dst + wave * 1024);
         pg_glds16(src + piece2 * 64 + lane, dst + piece2 * 1024);
@@ -210,7 +250,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     // the three planes of column block N of the W k-step in ring slot hq % BX_NB: issued, not waited for
     auto read_b = [&](BxB3 &b, int hq, auto n_tag) __attribute__((always_inline)) {
         constexpr int N = (ABL & 8) ? 0 : decltype(n_tag)::value;
-        const uint32_t addr = lds0 + (hq % BX_NB) * BX_BH_BYTES + lane * 16;
+        const uint32_t addr = lds0 + (hq % NBV) * BX_BH_BYTES + lane * 16;
         bx_ldsread16<(0 * 4 + N) * 1024>(b.h, addr);
         bx_ldsread16<(1 * 4 + N) * 1024>(b.m, addr);
         bx_ldsread16<(2 * 4 + N) * 1024>(b.l, addr);
@@ -218,6 +258,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     // acc += A . B over the NP plane products, smallest weights first
     auto mac = [&](f32x16 &c, const BxPlanes &A, const BxB3 &B) __attribute__((always_inline)) {
         const bf16x8 ah = bx_plane(A, 0), am = bx_plane(A, 1), al = bx_plane(A, 2);
+        if (ZOUT) {                                              // the transposed tile: W planes as the MFMA's A operand
+            c = MFMA_BF16(B.h, al, c);
+            c = MFMA_BF16(B.m, am, c);
+            c = MFMA_BF16(B.l, ah, c);
+            c = MFMA_BF16(B.h, am, c);
+            c = MFMA_BF16(B.m, ah, c);
+            c = MFMA_BF16(B.h, ah, c);
+            return;
+        }
         if (NP >= 8) { c = MFMA_BF16(al, B.m, c); c = MFMA_BF16(am, B.l, c); }
         c = MFMA_BF16(al, B.h, c);
         c = MFMA_BF16(am, B.m, c);
@@ -225,6 +274,61 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         c = MFMA_BF16(am, B.h, c);
         c = MFMA_BF16(ah, B.m, c);
         c = MFMA_BF16(ah, B.h, c);
+    };
+    // ZOUT: the round's tile of H (acc, transposed: this lane's row) -> Z0's tile.  Once per round; plain LDS reads and stores.
+    auto second_product = [&](int row0, bool live) __attribute__((always_inline)) {
+        const uint4 *img = reinterpret_cast<const uint4 *>(smem + NBV * BX_BH_BYTES);
+        f32x16 z[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[cb][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            BxPlanes P;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float x0 = acc[s >> 1][8 * (s & 1) + 2 * i], x1 = acc[s >> 1][8 * (s & 1) + 2 * i + 1];
+                x0 = (a.relu && !(x0 > 0.f)) ? 0.f : x0;
+                x1 = (a.relu && !(x1 > 0.f)) ? 0.f : x1;
+                bx_split2(x0, x1, P.w[0][i], P.w[1][i], P.w[2][i]);
+            }
+            const bf16x8 hh_ = bx_plane(P, 0), hm = bx_plane(P, 1), hl = bx_plane(P, 2);
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                if (cb == 1 && a.p2 <= 32) continue;
+                const int piece = s * 2 + cb;
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, img[(piece * 3 + 0) * 64 + lane]);
+                const bf16x8 wm = __builtin_bit_cast(bf16x8, img[(piece * 3 + 1) * 64 + lane]);
+                const bf16x8 wl = __builtin_bit_cast(bf16x8, img[(piece * 3 + 2) * 64 + lane]);
+                z[cb] = MFMA_BF16(wl, hh_, z[cb]);
+                z[cb] = MFMA_BF16(wm, hm, z[cb]);
+                z[cb] = MFMA_BF16(wh, hl, z[cb]);
+                z[cb] = MFMA_BF16(wm, hh_, z[cb]);
+                z[cb] = MFMA_BF16(wh, hm, z[cb]);
+                z[cb] = MFMA_BF16(wh, hh_, z[cb]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+        const int row = row0 + li;
+        if (live && row < a.m) {
+            float *zp = a.z0 + (size_t)row * a.ldz;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int c0 = 32 * cb + 8 * q + 4 * hh;
+                    if (c0 + 4 <= a.p2) {
+                        *reinterpret_cast<float4 *>(zp + c0) = make_float4(z[cb][4 * q], z[cb][4 * q + 1], z[cb][4 * q + 2], z[cb][4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) if (c0 + i < a.p2) zp[c0 + i] = z[cb][4 * q + i];
+                    }
+                }
+        }
     };
     // one group: NP MFMAs with 3 of the group's other instructions (split VALU, LDS reads) behind each
     auto interleave = [&]() __attribute__((always_inline)) {
@@ -235,6 +339,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         }
     };
 
+    if (ZOUT) {                                                  // the W2 image, before any hand-counted operation is issued
+        uint4 *img = reinterpret_cast<uint4 *>(smem + NBV * BX_BH_BYTES);
+        for (int i = tid; i < BX_W2_BYTES / 16; i += 64 * NW) img[i] = a.w2p[i];
+        __syncthreads();
+    }
     // ---- prologue: W k-steps 0 .. BX_PD-1, X chunks 0 and 1; everything landed
     BxRaw R0, R1, R2;
 #pragma unroll
@@ -348,8 +457,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         BX_WAIT_LDS(Bc);
         if (c == a.n_chunks - 1) {
             const bool live = NW * t + wave < nb;
+            if (ZOUT) {
+                second_product((rb_lo + NW * t + wave) * 32, live);
+            } else {
 #pragma unroll
-            for (int n = 0; n < 4; n++) store_block(acc[n], (rb_lo + NW * t + wave) * 32, 32 * n + li, live);
+                for (int n = 0; n < 4; n++) store_block(acc[n], (rb_lo + NW * t + wave) * 32, 32 * n + li, live);
+            }
         }
     };
     int g = 0;

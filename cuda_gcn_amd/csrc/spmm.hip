@@ -184,11 +184,15 @@ static void launch_dense_fwd(const DenseFwdArgs &a, int vx, dim3 grid, hipStream
 
 extern "C" {
 
+// the second layer's product in the epilogue of the evaluation forward (dense_bf16x3.h, ZOUT): Z0 = relu(X.W) . W2
+struct Z0Fuse { const float *w2; int ld_w2, p2; float *z0; int ld_z0; };
+
 static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
                          float *out, int ld_out, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
-                         uint64_t nnz_offset, const uint8_t *keep_mask, int relu) {
-    if (!c || !f || !vals || !w || !out || p <= 0 || ld_w < p || ld_out < p) return -1;
+                         uint64_t nnz_offset, const uint8_t *keep_mask, int relu, const Z0Fuse *zf = nullptr) {
+    if (!c || !f || !vals || !w || (!out && !zf) || p <= 0 || ld_w < p || (out && ld_out < p)) return -1;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
+    if (zf && !(f->dense && p == 128)) return GCNHIP_NOT_AVAILABLE;   // (the other forms below store `out`, which a fused call does not have)
     if (f->n_rows == 0) return 0;
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
     if (f->dense && p > 64) {                 // 128 x 128 MFMA tiles
@@ -208,24 +212,36 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         // product on the bf16 matrix pipe from three exact bf16 planes per f32 operand (dense_bf16x3.h) — f32 results inside the
         // f32 summation bound, 0.21 ms instead of 0.35 at Reddit scale.  0 keeps the exact-f32 MFMA kernels.
         const int bx = c->opt.gemm_bf16x3;
-        if (fast && p == 128 && !tiles_only && bx && (bx >= 2 || !c->corun) && aligned16(t.x) && aligned16(out) &&
-            (uint64_t)(t.m + 256) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 2 * BX_BH_BYTES <= c->wpack_bytes) {
+        if (zf && !(fast && p == 128 && !tiles_only && bx && !d.on && aligned16(t.x) && zf->p2 >= 1 && zf->p2 <= 64 && zf->ld_z0 % 4 == 0 &&
+                    zf->ld_z0 >= zf->p2 && zf->ld_w2 >= zf->p2 && aligned16(zf->z0) && (size_t)n_chunks * 2 * BX_BH_BYTES + BX_W2_BYTES <= c->wpack_bytes))
+            return GCNHIP_NOT_AVAILABLE;                          // the caller runs the two products one after the other
+        if (fast && p == 128 && !tiles_only && bx && (zf || ((bx >= 2 || !c->corun) && aligned16(out) &&
+            (uint64_t)(t.m + 256) * (uint64_t)ld_out * 4u < (1ull << 32))) && aligned16(t.x) && (size_t)n_chunks * 2 * BX_BH_BYTES <= c->wpack_bytes) {
             const int n_hs = 2 * n_chunks;
             uint4 *wp3 = reinterpret_cast<uint4 *>(c->wpack);
+            uint4 *w2img = wp3 + (size_t)n_hs * (BX_BH_BYTES / 16);
             if (d.on && keep_bits_by_block(d)) {         // keep bits and the packed planes of W from one launch
                 const int n_bits_wgs = (int)ceil_div(((f->nnz + 31) / 32 + 3) / 4, (int64_t)256);
                 dropbits_bx_pack_w_kernel<<<n_bits_wgs + n_hs, 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7, n_bits_wgs,
                                                                                      w, ld_w, t.K, n_hs, wp3, t.scale);
             } else {
                 if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
-                bx_pack_w_kernel<<<n_hs, 256, 0, c->stream>>>(w, ld_w, t.K, n_hs, wp3, t.bits ? t.scale : 1.f);
+                if (zf) bx_pack_w_kernel<<<n_hs + 4, 256, 0, c->stream>>>(w, ld_w, t.K, n_hs, wp3, 1.f, zf->w2, zf->ld_w2, zf->p2, w2img);
+                else bx_pack_w_kernel<<<n_hs, 256, 0, c->stream>>>(w, ld_w, t.K, n_hs, wp3, t.bits ? t.scale : 1.f);
             }
             GCNHIP_LAUNCH_CHECK();
             Bx3FwdArgs ba;
             ba.x = t.x; ba.ldx = t.ldx; ba.wp = wp3; ba.out = out; ba.ldo = ld_out;
             ba.m = t.m; ba.K = t.K; ba.n_chunks = n_chunks; ba.n_rb = ceil_div(t.m, 32);
             ba.bits = t.bits; ba.relu = relu;
+            ba.w2p = nullptr; ba.z0 = nullptr; ba.ldz = 0; ba.p2 = 0;
             int wgs = std::max(1, std::min(c->n_cu, ba.n_rb));
+            if (zf) {
+                ba.w2p = w2img; ba.z0 = zf->z0; ba.ldz = zf->ld_z0; ba.p2 = zf->p2;
+                dense_fwd_bf16x3_kernel<false, 6, 0, 8, true><<<wgs, 512, 0, c->stream>>>(ba);      // (144 KB of static LDS: one workgroup per CU)
+                GCNHIP_LAUNCH_CHECK();
+                return 0;
+            }
             if (c->corun && c->opt.gemm_lane_wgs > 0) wgs = std::max(1, std::min(wgs, c->opt.gemm_lane_wgs));   // fewer CUs host the lane's product
             // option gemm_lane_waves = 4: a context that runs beside another stream's kernels takes the four-wave form (half a CU's
             // registers: co-resident with a gather-bound kernel's waves).  Measured (docs/NOTEBOOK_r5.md §7): the lane's product is
@@ -398,6 +414,13 @@ int gcnhip_spmm_fwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
 int gcnhip_spmm_fwd_relu(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
                          float *out, int ld_out, int p) {
     return spmm_fwd_impl(c, f, vals, w, ld_w, out, ld_out, p, 0.f, 0, nullptr, 0, nullptr, 1);
+}
+
+int gcnhip_spmm_fwd_relu_matmul(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *w, int ld_w, int p,
+                                const float *w2, int ld_w2, int p2, float *z0, int ld_z0) {
+    if (!w2 || !z0 || p2 <= 0) return -1;
+    const Z0Fuse zf = {w2, ld_w2, p2, z0, ld_z0};
+    return spmm_fwd_impl(c, f, vals, w, ld_w, nullptr, 0, p, 0.f, 0, nullptr, 0, nullptr, 1, &zf);
 }
 
 // the split-K plan of the dense weight gradient: S row ranges of rps rows (a multiple of the K chunk) fill the chip twice

@@ -727,6 +727,8 @@ void HipGCN::build_agg_first_eval() {
     // H1 = ReLU((A^.X).W1) written straight into variable 3; from there on the training modules' own forward(false)
     auto *sm = new HipSparseMatmul(&env, &agg_vals, variables[2].get(), variables[3].get(), feat_agg, n_local, F, H, 0.f, 0);
     sm->relu_out = true;
+    // nothing but H1.W2 reads an evaluation's hidden matrix: both products in one launch, H1 not stored (get_var(3) rebuilds it)
+    if (opt_.eval_fusion && !env.bf16_tables) sm->fuse_next = dynamic_cast<HipMatmul *>(modules[2]);
     eval_modules.push_back(sm);
     for (size_t i = 2; i < modules.size(); i++) eval_modules.push_back(modules[i]);
 }
@@ -736,6 +738,7 @@ void HipGCN::build_eval_lane() {
     const int N = n_local, F = params.input_dim, H = params.hidden_dim, C = params.output_dim;
     lane.reset(new EvalLane());
     EvalLane &L = *lane;
+    HipSparseMatmul *lane_sm = nullptr;
     GCNHIP_CHECK(gcnhip_ctx_create(&L.env.ctx, /*device of the main context*/ device_, nullptr));
     GCNHIP_CHECK(gcnhip_ctx_set_corun(L.env.ctx, 1));           // the lane's kernels share the chip with the training pass
     if (slice_floats == 32) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gs_l", 8));   // as tuned on the training context
@@ -785,6 +788,7 @@ void HipGCN::build_eval_lane() {
     if (feat_agg) {
         auto *sm = new HipSparseMatmul(&L.env, &agg_vals, variables[2].get(), L.H1.get(), feat_agg, N, F, H, 0.f, 0);
         sm->relu_out = true;
+        lane_sm = sm;
         L.modules.push_back(sm);
     } else {
         auto *sm = new HipSparseMatmul(&L.env, &eval_vals, variables[2].get(), L.H0.get(), feat, N, F, H, 0.f, nnz_off);
@@ -794,7 +798,11 @@ void HipGCN::build_eval_lane() {
         L.modules.push_back(sm);
         L.modules.push_back(gs);
     }
-    L.modules.push_back(new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C));
+    {
+        auto *mm = new HipMatmul(&L.env, L.H1.get(), variables[5].get(), L.Z0.get(), N, H, C);
+        if (lane_sm && opt_.eval_fusion && !L.env.bf16_tables) lane_sm->fuse_next = mm;      // as on the training context
+        L.modules.push_back(mm);
+    }
     auto *gs_logits = new HipGraphSum(&L.env, L.Z0.get(), L.Z.get(), L.graph, C);
     gs_logits->fwd_out_rows = &L.out_rows;
     if (factored_) gs_logits->fwd_scaling = 1;
@@ -978,6 +986,7 @@ void HipGCN::train_end() {
 }
 
 void HipGCN::train_epoch_async() {              // gcn.cpp:107-118
+    h1_from_fused_eval = false;                 // the training forward stores H1
     train_begin();
     for (auto m : modules) m->forward(true);
     for (int i = (int)modules.size() - 1; i >= 0; i--) modules[i]->backward();
@@ -1061,6 +1070,7 @@ void HipGCN::eval_async(int s) {                // gcn.cpp:120-128
     // (an evaluation on this stream scores the weights of the last update: the row of env.d_epoch_done, not of the epoch to come)
     if (in_loss) GCNHIP_CHECK(gcnhip_metrics_record_with_next_loss(env.ctx, d_ring, RING, s == 2 ? 1 : 2, env.d_epoch_done, optimizer->d_sumsq));
     for (auto m : eval_modules.empty() ? modules : eval_modules) m->forward(false);
+    h1_from_fused_eval = !eval_modules.empty() && static_cast<HipSparseMatmul *>(eval_modules[0])->hidden_not_stored;
     if (env.comm->size() > 1) {
         timers->start(TMR_COMM);
         env.comm->allreduce_sum(d_result, 4);
@@ -1343,6 +1353,12 @@ void HipGCN::report_test() {
 void HipGCN::get_var(int k, bool grad, std::vector<float> &out, int *rows, int *cols) {
     if (k < 1 || k > 6) throw GcnHipFailure(-1, "get_var: k must be 1..6");
     HipVariable *v = variables[k].get();
+    if (k == 3 && !grad && h1_from_fused_eval && !eval_modules.empty()) {
+        // the last forward on this stream was an evaluation whose hidden matrix stayed in registers: run it as its own launch
+        static_cast<HipSparseMatmul *>(eval_modules[0])->forward_stored();
+        h1_from_fused_eval = false;
+        sync();
+    }
     if (k == 3 && grad && dh1_pack) {           // introspection: rebuild the dense image of the packed gradient
         GCNHIP_CHECK(gcnhip_rowpack_expand(env.ctx, dh1_pack, v->grad, v->ld));
         sync();

@@ -88,6 +88,7 @@ struct HipGCNOptions {
     bool verbose = false;                 // HIPGCN_VERBOSE: where the model build's wall time goes, run-loop statistics (stderr)
     int exchange = -1;                    // HIPGCN_EXCHANGE: -1 unset, 0 auto (per graph), 1 allgather, 2 halo
     bool structure_groups = true;         // HIPGCN_NO_STRUCTURE_GROUPS clears: never search the graph for row groups
+    bool eval_fusion = true;              // HIPGCN_NO_EVAL_FUSION clears: evaluation forwards store the hidden matrix and run H1.W2 as its own launch
     bool loss_epilogue = true;            // HIPGCN_NO_LOSS_EPILOGUE clears: the loss kernel reads the stored logits (round 4) instead of riding in the class-width aggregation's epilogue
     bool mask_bits = true;                // HIPGCN_NO_MASK_BITS clears: the Matmul backward re-reads H1 instead of one bit per element
     bool loss_records_metrics = true;     // HIPGCN_RECORD_LAUNCH clears: the metrics row gets a launch of its own (A/B)
@@ -199,6 +200,7 @@ private:
     gcnhip_feat *feat_agg = nullptr;
     const float *agg_vals = nullptr;
     std::vector<Module *> eval_modules;                        // [0] owned (the GEMM on A^.X); the rest are modules[2..]
+    bool h1_from_fused_eval = false;                           // the last forward on the main stream kept its hidden matrix in registers (get_var(3) rebuilds it)
     void build_agg_first_eval();
     const float *full_vals = nullptr;
     bool replicate_l1 = false;

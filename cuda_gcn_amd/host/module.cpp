@@ -6,7 +6,17 @@
 HipMatmul::HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float s)
     : env(env), a(a), b(b), c(c), m(m), n(n), p(p), fused_bwd_scale(s) {}
 
+bool HipMatmul::fused_eval_forward(gcnhip_feat *sp, const float *vals, HipVariable *w1, int p1) {
+    if (p1 != n) return false;
+    const int rc = gcnhip_spmm_fwd_relu_matmul(env->ctx, sp, vals, w1->data, w1->ld, p1, b->data, b->ld, p, c->data, c->ld);
+    if (rc == GCNHIP_NOT_AVAILABLE) return false;
+    GCNHIP_CHECK(rc);
+    skip_forward_once = true;
+    return true;
+}
+
 void HipMatmul::forward(bool) {
+    if (skip_forward_once) { skip_forward_once = false; return; }     // the producer's launch has written c already
     env->timers->start(TMR_MATMUL_FW);
     GCNHIP_CHECK(gcnhip_matmul_fwd(env->ctx, a->data, a->ld, b->data, b->ld, c->data, c->ld, m, n, p));
     env->timers->stop(TMR_MATMUL_FW);
@@ -68,9 +78,11 @@ void HipSparseMatmul::forward(bool training) {
     if (training) fwd_decisions_valid = fused_dropout > 0.f && !sp_full && !relu_out && gcnhip_feat_is_dense(sp);
     env->timers->start(TMR_SPMATMUL_FW);
     const float pd = training ? fused_dropout : 0.f;
+    hidden_not_stored = false;
     if (relu_out) {
         if (training) throw GcnHipFailure(-1, "HipSparseMatmul: the ReLU epilogue is an evaluation-only form");
-        GCNHIP_CHECK(gcnhip_spmm_fwd_relu(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p));
+        if (fuse_next && fuse_next->fused_eval_forward(sp, *vals, b, p)) hidden_not_stored = true;
+        else GCNHIP_CHECK(gcnhip_spmm_fwd_relu(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p));
     } else if (sp_full)        // every row of the product, with global element indices for the dropout stream
         GCNHIP_CHECK(gcnhip_spmm_fwd(env->ctx, sp_full, *vals_full, b->data, b->ld, c->full, c->ld, p, pd,
                                      env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, 0,
@@ -80,6 +92,12 @@ void HipSparseMatmul::forward(bool training) {
                                      env->seed ^ KEY_INPUT_DROPOUT, env->d_epoch, nnz_offset,
                                      pd > 0.f ? env->keep_input : nullptr));
     env->timers->stop(TMR_SPMATMUL_FW);
+}
+
+void HipSparseMatmul::forward_stored() {
+    if (!relu_out) throw GcnHipFailure(-1, "HipSparseMatmul::forward_stored: an evaluation-only form");
+    GCNHIP_CHECK(gcnhip_spmm_fwd_relu(env->ctx, sp, *vals, b->data, b->ld, c->data, c->ld, p));
+    hidden_not_stored = false;
 }
 
 void HipSparseMatmul::backward_part(int k) {

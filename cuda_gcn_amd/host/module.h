@@ -82,7 +82,12 @@ public:
     // rows, da_row_scale_full for the rows of the gathered table (rebuild_da)
     const float *da_row_scale = nullptr, *da_row_scale_full = nullptr;
     HipMatmul(HipEnv *env, HipVariable *a, HipVariable *b, HipVariable *c, int m, int n, int p, float fused_bwd_scale = 0.f);
+    // Evaluation, round 5: c = ReLU(X . w1) . b in ONE launch with the producer of `a` (gcnhip_spmm_fwd_relu_matmul) — `a`, the
+    // hidden matrix, is then never stored.  Returns false when that form is not available for these shapes / options (nothing
+    // launched); on success this module's next forward() is a no-op.
+    bool fused_eval_forward(gcnhip_feat *sp, const float *vals, HipVariable *w1, int p1);
 private:
+    bool skip_forward_once = false;
     void rebuild_da(int first_row, int n_rows);     // da rows [first_row, first_row + n_rows) of the table from dc + mask bits
 public:
     void forward(bool) override;
@@ -104,6 +109,9 @@ public:
     gcnhip_feat *sp_full = nullptr;
     const float *const *vals_full = nullptr;
     bool relu_out = false;          // evaluation on A^.X: ReLU when the product is stored (forward(false) only)
+    HipMatmul *fuse_next = nullptr; // relu_out: the Matmul that consumes `c` and nothing else does — both products in one launch
+    bool hidden_not_stored = false; // the last forward was that fused launch: `c` does not hold this forward's hidden matrix
+    void forward_stored();          // the evaluation forward as its own launch, `c` stored (what get_var(3) asks for after a fused one)
     BackwardPipeline *pipe = nullptr;       // set: the producer of c->grad may run backward_part/_finish block by block
     void backward_part(int block);
     void backward_finish();

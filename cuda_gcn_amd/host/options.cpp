@@ -27,6 +27,7 @@ HipGCNOptions HipGCNOptions::from_environment(HipGCNOptions o) {
     if (getenv("HIPGCN_NO_STRUCTURE_GROUPS")) o.structure_groups = false;
     if (getenv("HIPGCN_NO_MASK_BITS")) o.mask_bits = false;
     if (getenv("HIPGCN_NO_LOSS_EPILOGUE")) o.loss_epilogue = false;
+    if (getenv("HIPGCN_NO_EVAL_FUSION")) o.eval_fusion = false;
     if (getenv("HIPGCN_NO_SLICE_TUNING")) o.slice_tuning = false;
     if (getenv("HIPGCN_RECORD_LAUNCH")) o.loss_records_metrics = false;
     if (const char *e = getenv("HIPGCN_BWD_CHUNKS")) o.bwd_chunks = atoi(e);

@@ -357,6 +357,19 @@ class Device:
         _ck(self.lib, self.lib.gcnhip_spmm_fwd_relu(self.ctx, f.h, f.values_ptr, wb.ptr, ld_w, out.ptr, ld_out, p), "gcnhip_spmm_fwd_relu")
         return out.download()[:, :p]
 
+    def spmm_fwd_relu_matmul(self, f: "Feat", w, w2, ld_z=None):
+        """gcnhip_spmm_fwd_relu_matmul: ReLU(X . w) . w2 in one launch; returns None when the fused form is not available"""
+        w, w2 = np.asarray(w, np.float32), np.asarray(w2, np.float32)
+        p, p2 = w.shape[1], w2.shape[1]
+        ld_z = ld_z or (p2 + 3) // 4 * 4
+        wb, w2b = self.buf(w), self.padded(w2, ld_z)
+        z = self.buf(np.full((f.n_rows, ld_z), np.nan, np.float32))
+        rc = self.lib.gcnhip_spmm_fwd_relu_matmul(self.ctx, f.h, f.values_ptr, wb.ptr, p, p, w2b.ptr, ld_z, p2, z.ptr, ld_z)
+        if rc == -2:
+            return None
+        _ck(self.lib, rc, "gcnhip_spmm_fwd_relu_matmul")
+        return z.download()[:, :p2]
+
     def spmm_bwd(self, f: "Feat", dout, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, keep_mask=None, vals=None, ld_dout=None, ld_dw=None):
         dout = np.asarray(dout, np.float32)
         p = dout.shape[1]

@@ -317,6 +317,16 @@ int gcnhip_spmm_fwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, co
 /* forward without dropout, ReLU (module.cpp:175-185, keep = x > 0) applied when the result is stored */
 int gcnhip_spmm_fwd_relu(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *w, int ld_w,
                          float *out, int ld_out, int p);
+/* Evaluation forward of BOTH layers' products in one launch (round 5): z0[m x p2] = ReLU(X . w)[m x p] . w2[p x p2], the hidden
+ * matrix never stored (SparseMatmul::forward + ReLU + Matmul::forward, module.cpp:47-61, 175-185, 11-22, for a forward whose
+ * hidden activations nobody reads afterwards: GCN::eval with the aggregate-first feature object).  The first product is
+ * computed transposed on the bf16 pipe (three-plane splits, as gcnhip_spmm_fwd does at p = 128), which leaves a row's features
+ * in one lane's accumulators — the operand layout of the second product.  Available for a dense X, p = 128, p2 <= 64,
+ * 16-byte aligned rows of z0 and option gemm_bf16x3 != 0; otherwise returns GCNHIP_NOT_AVAILABLE (nothing launched: call
+ * gcnhip_spmm_fwd_relu and gcnhip_matmul_fwd instead).  Results inside the f32 summation bound of the two-call form, not its bits. */
+#define GCNHIP_NOT_AVAILABLE (-2)
+int gcnhip_spmm_fwd_relu_matmul(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *w, int ld_w, int p,
+                                const float *w2, int ld_w2, int p2, float *z0, int ld_z0);
 int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout,
                     float *dw, int ld_dw, int p, float p_drop, uint64_t seed, const uint32_t *d_epoch,
                     uint64_t nnz_offset, const uint8_t *keep_mask);

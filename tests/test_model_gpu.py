@@ -549,6 +549,36 @@ def test_f32_mfma_products_stay_selectable():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("lane", [False, True])
+def test_both_products_of_an_evaluation_in_one_launch(lane):
+    """evaluation forwards compute Z0 = ReLU((A^.X).W1).W2 in one launch, the hidden matrix staying in accumulators (default), against
+    the two launches with H1 stored (HIPGCN_NO_EVAL_FUSION): training untouched (bit-identical), evaluation losses within the
+    two-roundings tolerance, accuracies within one row; and get_var(3) after a fused evaluation still returns that evaluation's
+    hidden matrix (rebuilt on demand by the stored form: the bits of the unfused model)"""
+    from cuda_gcn_amd.model import HipGCNModel, EVAL_LANE, NO_EVAL_LANE
+    ds = datagen.make_dataset("reddit-mini")
+    fl = EVAL_LANE if lane else NO_EVAL_LANE
+    a = HipGCNModel(ds, seed=9, flags=fl, hidden_dim=128, dropout=0.5, epochs=8)
+    os.environ["HIPGCN_NO_EVAL_FUSION"] = "1"
+    try:
+        b = HipGCNModel(ds, seed=9, flags=fl, hidden_dim=128, dropout=0.5, epochs=8)
+    finally:
+        del os.environ["HIPGCN_NO_EVAL_FUSION"]
+    ta, tb = a.run_epochs(6), b.run_epochs(6)
+    assert np.array_equal(ta[:, :2].view(np.uint32), tb[:, :2].view(np.uint32))
+    assert np.abs(ta[:, 2] - tb[:, 2]).max() <= 2e-5     # (the same plane products in both forms: usually the same float, never far)
+    for s in (2, 3, 1):
+        n_s = int((ds["split"] == s).sum())
+        la, lb = a.eval(s), b.eval(s)
+        assert abs(la[0] - lb[0]) <= 2e-5 and abs(la[1] - lb[1]) <= 1.0 / n_s + 1e-7, (s, la, lb)
+    if not lane:
+        assert np.array_equal(a.var(3), b.var(3))               # H1 of eval(1), rebuilt for a; stored for b
+        assert np.array_equal(a.var(3), b.var(3))               # (and again: the rebuilt matrix stays)
+    assert a.train_epoch() == b.train_epoch()
+    assert np.array_equal(a.var(2), b.var(2)) and np.array_equal(a.var(5), b.var(5))
+    a.close(); b.close()
+
+
 def test_row_groups_are_bit_identical():
     """scheduling the aggregation label by label (the default when the labels are assortative on the
     graph, as on reddit-*) changes no number"""

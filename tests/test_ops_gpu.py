@@ -887,6 +887,40 @@ def test_class_layer_products_from_three_bf16_planes(dev, m, p):
         assert e_new <= 2 * e_old + EPS, (i, e_new, e_old)
 
 
+@pytest.mark.parametrize("N,F,p2", [(5000, 602, 41), (257, 602, 41), (70001, 96, 7), (8192 * 3 + 17, 130, 64), (40000, 602, 33)])
+def test_both_layers_products_in_one_evaluation_launch(dev, N, F, p2):
+    """gcnhip_spmm_fwd_relu_matmul (dense_bf16x3.h, ZOUT): Z0 = ReLU(X . W1) . W2 with the hidden matrix kept in accumulators —
+    against the float64 product of the float64 hidden matrix (the error of the hidden layer enters the second product: the bound
+    is the sum of both products' bounds, evaluated on absolute values) and beside the two-call form (gcnhip_spmm_fwd_relu then
+    gcnhip_matmul_fwd); ragged last block, p2 below and above 32, workgroup shares that are not multiples of eight blocks"""
+    rng = np.random.default_rng(N + F + p2)
+    vals = (rng.standard_normal(N * F) * np.exp(rng.uniform(-3, 3, N * F))).astype(np.float32)
+    fp = (np.arange(N + 1) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    w = (rng.standard_normal((F, 128)) * 0.05).astype(np.float32)
+    w2 = (rng.standard_normal((128, p2)) * 0.3).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    ld = (p2 + 15) // 16 * 16
+    got = dev.spmm_fwd_relu_matmul(f, w, w2, ld_z=ld)
+    assert got is not None
+    h_two = dev.spmm_fwd_relu(f, w)
+    two = dev.matmul_fwd(h_two, w2, lda=128, ldb=ld, ldc=ld)
+    X = vals.reshape(N, F).astype(np.float64)
+    H = X @ w.astype(np.float64)
+    magH = np.abs(X) @ np.abs(w.astype(np.float64))
+    want = np.maximum(H, 0) @ w2.astype(np.float64)
+    # |dZ0| <= (error of H) . |W2| + rounding of the second product: 8 eps (magH . |W2| + relu(H) . |W2|)
+    bound = 8 * EPS * ((magH + np.maximum(H, 0)) @ np.abs(w2.astype(np.float64))) + 1e-30
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= bound), float((np.abs(got - want) / bound).max())
+    assert np.all(np.abs(two - want) <= bound)
+    f.free()
+    # a shape the fused form does not take: the entry point says so and launches nothing
+    f2 = dev.feat((np.arange(65) * 40).astype(np.int32), np.tile(np.arange(40, dtype=np.int32), 64), rng.standard_normal(64 * 40).astype(np.float32), 40)
+    assert dev.spmm_fwd_relu_matmul(f2, rng.standard_normal((40, 16)).astype(np.float32), rng.standard_normal((16, 7)).astype(np.float32)) is None
+    f2.free()
+
+
 def test_first_layer_products_beside_a_bandwidth_hog(dev):
     """the same stress for dense_bf16x3.h (X by asm loads three chunks deep, W planes by LDS-DMA, counted waits): X of 400 001 rows x
     602 columns (963 MB, four times the Infinity Cache) multiplied beside a second context's aggregation; forward without and with
