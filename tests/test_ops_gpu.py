@@ -939,6 +939,8 @@ def test_first_layer_products_beside_a_bandwidth_hog(dev):
     dh = dev.buf((rng.standard_normal((N, p)) * 1e-3).astype(np.float32))
     out, dw = dev.buf(np.zeros((N, p), np.float32)), dev.buf(np.zeros((F, p), np.float32))
     ep = dev.buf(np.array([3], np.uint32))
+    w2 = dev.buf((rng.standard_normal((p, 48)) * 0.3).astype(np.float32))
+    z0 = dev.buf(np.zeros((N, 48), np.float32))
 
     def run():
         res = []
@@ -947,6 +949,9 @@ def test_first_layer_products_beside_a_bandwidth_hog(dev):
             res.append(out.download().copy())
         _ck(lib, lib.gcnhip_spmm_bwd(dev.ctx, f.h, f.values_ptr, dh.ptr, p, dw.ptr, p, p, 0.5, 7, ep.ptr, 0, None), "bwd")
         res.append(dw.download().copy())
+        # the evaluation form with the second product in its epilogue (a ring of 8 W k-steps instead of 10)
+        _ck(lib, lib.gcnhip_spmm_fwd_relu_matmul(dev.ctx, f.h, f.values_ptr, w.ptr, p, p, w2.ptr, 48, 41, z0.ptr, 48), "fused")
+        res.append(z0.download()[:, :41].copy())
         return res
     quiet = run()
     hog = Device(0)
@@ -961,7 +966,7 @@ def test_first_layer_products_beside_a_bandwidth_hog(dev):
             for _ in range(8):
                 _ck(hog.lib, hog.lib.gcnhip_graphsum(hog.ctx, g.h, x.ptr, 256, y.ptr, 256, 256), "hog")
             got = run()
-            for q, r, what in zip(quiet, got, ("X.W", "X~.W", "X~^T.dH0")):
+            for q, r, what in zip(quiet, got, ("X.W", "X~.W", "X~^T.dH0", "relu(X.W).W2")):
                 assert np.array_equal(q.view(np.uint32), r.view(np.uint32)), (it, what)
         hog.sync()
     finally:
