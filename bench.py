@@ -770,7 +770,8 @@ def main():
                        "transport": transport[0] if transport else None,
                        "rccl_ranks": transport[1] if (transport and transport[0] == "rccl") else None,     # ncclCommCount of the model's communicator
                        "eval_forward": "reference order A^.(X.W1)" if os.environ.get("HIPGCN_NO_AGG_FIRST_EVAL") else
-                                       "aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)",
+                                       ("aggregate-first ReLU((A^.X).W1), A^.X built once at load (dense X)" +
+                                        ("" if os.environ.get("HIPGCN_NO_EVAL_FUSION") or args.hidden != 128 else "; .W2 in the same launch, H1 not stored")),
                        "logit_rows": "all" if os.environ.get("HIPGCN_ALL_ROWS") else "rows of the scored split only"},
             "bursts": {"epochs_per_s": [round(b, 2) for b in burst_eps], "median": statistics.median(burst_eps), "min": min(burst_eps),
                        "max": max(burst_eps), "steps_each": args.steps},
