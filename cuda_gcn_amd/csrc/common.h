@@ -146,6 +146,7 @@ struct gcnhip_feat {
     int *csc_pos;       // [nnz] position jj in CSR order (selects value + dropout decision)
     float *csc_val;     // [nnz] values[csc_pos[q]]: the pristine values in CSC order (one dependent load less per entry)
     uint32_t *keep_bits; // [ceil(nnz/32)+1] input-dropout decisions of the current call (dense path)
+    int keep_layout;     // how the last producer laid keep_bits out: 0 = flat (bit e & 31 of word e >> 5), 1 = chunk-major (dense_bf16x3.h)
     // the weight gradient's task list over the CSC view (sparse X, spmm_sparse.h): a column is one task of bwd_nw waves, a
     // column longer than the segment length several tasks whose partial rows a fold launch adds in order
     int4 *bwd_tasks;    // {column, q_begin, q_end, partial slot or -1}

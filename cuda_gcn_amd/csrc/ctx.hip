@@ -763,7 +763,11 @@ static int feat_create_impl(gcnhip_ctx *c, gcnhip_feat *f, const int *h_indptr, 
     GCNHIP_TRY(hipMemcpy(f->indptr, h_indptr, (size_t)(n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
     GCNHIP_TRY(hipMalloc((void **)&f->values, (size_t)std::max<int64_t>(nnz, 4) * sizeof(float)));
     if (nnz) GCNHIP_TRY(hipMemcpy(f->values, h_values, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
-    GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (size_t)(nnz / 32 + 32) * sizeof(uint32_t)));   // slack: tiles read bits of pad columns
+    {   // flat: a bit per stored element; chunk-major (dense X, dense_bf16x3.h): a word per row and 32 columns.  Slack: tiles read bits of pad columns
+        const size_t words_cm = dense ? (size_t)n_rows * ((n_cols + 31) / 32) : 0;
+        GCNHIP_TRY(hipMalloc((void **)&f->keep_bits, (std::max((size_t)(nnz / 32), words_cm) + 32) * sizeof(uint32_t)));
+        f->keep_layout = 0;
+    }
     if (dense && n_cols % 128 != 0 && n_cols >= 64) {
         // the MFMA tiles stage X with unconditional 16-byte lane loads when every row starts on a 16-byte
         // boundary and its stride covers whole 128-column tiles (zero padded); HBM has room for the second copy

@@ -85,12 +85,74 @@ __global__ __launch_bounds__(256) void bx_pack_w_kernel(const float *__restrict_
     if ((int)blockIdx.x < n_hs) bx_pack_w_body(blockIdx.x * blockDim.x + threadIdx.x, w, ldw, K, n_hs, wp, scale);
     else bx_pack_w2_body(((int)blockIdx.x - n_hs) * 256 + threadIdx.x, w2, ldw2, p2, img);
 }
+// ---- keep bits, CHUNK-MAJOR: word [c * m + r] = the keep decisions of elements (r, 32 c .. 32 c + 31) of X, bit i = column 32 c + i
+// (bits of columns >= K: zero).  The same decisions as the flat array of dropbits_kernel (bit e & 31 of word e >> 5, e = r K + col)
+// — element e is decided by bit (off + e) of the (seed, epoch) stream — laid out for the two kernels below: the forward's lanes
+// (one row each) read the word of their chunk from ONE 128-byte line per 32 rows, the weight gradient's wave reads the 16 words
+// of its step's rows with one load and uses them as LANE MASKS (lane = column).  With the flat array the forward's wave touched
+// 19 lines per chunk for 8 bytes per lane (38 us of its 211 at Reddit scale, 26 of them the load alone) and the gradient issued
+// 8 one-word loads per step.  A workgroup makes the words of R rows: the stream's Philox blocks that cover them into LDS (every
+// block drawn once), then every (chunk, row) window out of LDS.  keep_mask != NULL: injected decisions (bytes, element order).
+struct BxBitsArgs {
+    uint32_t *bits; int m, K, n_chunks, R;      // R rows per workgroup: R * K / 32 + 12 <= BX_BITS_LDS_WORDS
+    int thr; uint64_t seed; const uint32_t *d_epoch; uint64_t off; const uint8_t *keep_mask;
+};
+constexpr int BX_BITS_LDS_WORDS = 4096;
+__device__ inline void dropbits_cm_body(int wg, int tid, const BxBitsArgs &b, uint32_t *lds) {
+    const int ra = wg * b.R, rb = min(b.m, ra + b.R);
+    if (ra >= rb) return;
+    const uint64_t bit0 = b.off + (uint64_t)ra * b.K;                     // first stream bit of this workgroup's rows
+    const uint64_t q0 = bit0 >> 7;                                        // first Philox block
+    if (!b.keep_mask) {
+        const uint64_t bit1 = b.off + (uint64_t)rb * b.K + 64;            // a window reads up to a word past its last bit
+        const int n_blk = (int)((bit1 >> 7) - q0) + 1;
+        const uint32_t epoch = b.d_epoch ? *b.d_epoch : 0u;
+        for (int blk = tid; blk < n_blk; blk += 256) {
+            const uint64_t c = q0 + (uint64_t)blk;
+            uint32_t ge[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (b.thr != 0) {
+                const int n_planes = 16 - (__ffs(b.thr) - 1);
+                for (int i = n_planes; i >= 1; i--) {                     // keep_word's recurrence (common.h), on the four groups at once
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), epoch, (uint32_t)i, (uint32_t)b.seed, (uint32_t)(b.seed >> 32), r);
+                    const bool and_plane = (b.thr >> (16 - i)) & 1;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) ge[g] = and_plane ? (r[g] & ge[g]) : (r[g] | ge[g]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) lds[4 * blk + g] = ge[g];
+        }
+    }
+    __syncthreads();
+    const int rows = rb - ra;
+    for (int idx = tid; idx < b.n_chunks * rows; idx += 256) {
+        const int c = idx / rows, r = idx - c * rows, row = ra + r;
+        const int valid = min(32, b.K - 32 * c);                          // columns of this chunk inside the matrix
+        uint32_t word;
+        if (b.keep_mask) {
+            word = 0;
+            const uint8_t *km = b.keep_mask + (size_t)row * b.K + 32 * c;
+            for (int i = 0; i < valid; i++) word |= (km[i] ? 1u : 0u) << i;
+        } else {
+            const uint32_t rel = (uint32_t)(b.off + (uint64_t)row * b.K + 32u * (uint32_t)c - (q0 << 7));
+            const uint32_t lo = lds[rel >> 5], hi = lds[(rel >> 5) + 1], sh = rel & 31u;
+            word = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+            if (valid < 32) word &= (1u << valid) - 1u;
+        }
+        b.bits[(size_t)c * b.m + row] = word;
+    }
+}
+__global__ __launch_bounds__(256) void dropbits_cm_kernel(BxBitsArgs b) {
+    __shared__ uint32_t lds[BX_BITS_LDS_WORDS];
+    dropbits_cm_body(blockIdx.x, threadIdx.x, b, lds);
+}
 // keep bits + packed W in one launch (as dropbits_pack_w_kernel of dense_persist.h)
-__global__ __launch_bounds__(256) void dropbits_bx_pack_w_kernel(uint32_t *__restrict__ bits, int64_t n_elems, int thr, uint64_t seed,
-                                                                 const uint32_t *d_epoch, uint64_t block0, int n_bits_wgs,
+__global__ __launch_bounds__(256) void dropbits_bx_pack_w_kernel(BxBitsArgs b, int n_bits_wgs,
                                                                  const float *__restrict__ w, int ldw, int K, int n_hs,
                                                                  uint4 *__restrict__ wp, float scale) {
-    if ((int)blockIdx.x < n_bits_wgs) dropbits_block_body((int64_t)blockIdx.x * 256 + threadIdx.x, bits, n_elems, thr, seed, d_epoch, block0);
+    __shared__ uint32_t lds[BX_BITS_LDS_WORDS];
+    if ((int)blockIdx.x < n_bits_wgs) dropbits_cm_body(blockIdx.x, threadIdx.x, b, lds);
     else bx_pack_w_body(((int)blockIdx.x - n_bits_wgs) * 256 + threadIdx.x, w, ldw, K, n_hs, wp, scale);
 }
 
@@ -99,7 +161,7 @@ struct Bx3FwdArgs {
     const uint4 *wp;                  // packed planes of W (bx_pack_w_kernel): 2 * n_chunks blocks of 12 KB
     float *out; int ldo;              // H0 [m x 128]; m * ldo * 4 < 2^32 (buffer stores)
     int m, K, n_chunks, n_rb;         // n_chunks = ceil(K / 32); n_rb = ceil(m / 32)
-    const uint32_t *bits;             // keep bits of the stored elements (element row*K + col), NULL: no dropout
+    const uint32_t *bits;             // keep bits, chunk-major (dropbits_cm_body: word c * m + row), NULL: no dropout
     int relu;
     // ZOUT form (evaluation): the second layer's product rides in the epilogue — Z0 = relu(X.W) . W2 leaves, H never does
     const uint4 *w2p;                 // planes of W2 as the A operand of Z0^T = W2^T . H^T (bx_pack_w2_body): 16 pieces of 3 KB
@@ -109,7 +171,7 @@ constexpr int BX_W2_BYTES = 8 * 2 * 3 * 1024;                // 49152
 
 struct BxB3 { bf16x8 h, m, l; };
 template <int N> struct BxN { static constexpr int value = N; };
-struct BxRaw { f32x4 v[4]; u32x2 kw; };                       // one chunk of this lane's row: 16 floats (k = 16 hh + 0..15) + the keep words
+struct BxRaw { f32x4 v[4]; uint32_t kw; };                    // one chunk of this lane's row: 16 floats (k = 16 hh + 0..15) + the chunk's keep word of the row
 
 // Every vector-memory operation of the kernel is inline asm, so that ONE hand-kept count covers them all (vmcnt counts loads,
 // LDS-DMA pieces and stores together, in issue order; hipcc neither sees these nor waits for them).
@@ -117,8 +179,8 @@ template <int OFF>
 __device__ __forceinline__ void bx_gload16(f32x4 &dst, const float *p) {
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void bx_gload8(u32x2 &dst, const uint32_t *p) {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+__device__ __forceinline__ void bx_gload4(uint32_t &dst, const uint32_t *p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 // wait until at most N vector-memory operations of this wave are outstanding; the registers of `r` are tied to the statement so
 // that no use of them can be scheduled ahead of it
@@ -160,13 +222,14 @@ __device__ __forceinline__ void bx_ldsread16(bf16x8 &dst, uint32_t addr) {
 // 4 h of the 16) exactly as bx_pack_w2_body lays W2 out.  At the end of a round the 32 x 128 tile of H is clamped at zero, split
 // into planes in registers and multiplied by the W2 image (48 KB of LDS beside a ring of 8 instead of 10 W k-steps); Z0's 32 x p2
 // tile is stored, H is not: 119 MB less written, 119 MB less read, one launch less per evaluation forward.
-template <bool DROP, int NP, int ABL = 0, int NW = 8, bool ZOUT = false>
+template <bool DROP, int NP, int ABL = 0, int NW = 8, bool ZOUT = false, int PD_ = 0>
 __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs a) {
+    constexpr int PD = PD_ ? PD_ : BX_PD;                        // W k-steps in flight ahead of their use
     static_assert(NW == 8 || NW == 4, "12 W pieces per k-step: two per wave of eight (four of them duplicates) or three per wave of four");
     // ring slots: k-step h + BX_PD is written (after the barrier of half-item h) into the slot of k-step h + BX_PD - NBV, which
     // every wave has finished reading once it is past half-item h - 1: NBV >= BX_PD + 1
     constexpr int NBV = ZOUT ? 8 : BX_NB;
-    static_assert(NBV >= BX_PD + 1, "ring too short for the prefetch distance");
+    static_assert(NBV >= PD + 1, "ring too short for the prefetch distance");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NBV * BX_BH_BYTES + (ZOUT ? BX_W2_BYTES : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,14 +252,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         const float *p = a.x + (size_t)row * a.ldx + c * BX_BK + 16 * hh;
         if (ABL & 1) p = a.x + lane * 16;
         bx_gload16<0>(r.v[0], p); bx_gload16<16>(r.v[1], p); bx_gload16<32>(r.v[2], p); bx_gload16<48>(r.v[3], p);
-        if (DROP) {
-            const uint64_t e0 = (uint64_t)row * a.K + c * BX_BK + 16 * hh;
-            bx_gload8(r.kw, a.bits + (e0 >> 5));
+        if (DROP && !(ABL & 64)) {
+            bx_gload4(r.kw, a.bits + (size_t)c * a.m + row);    // 32 consecutive rows: one line (both lane halves read the same words)
         } else {
-            r.kw = (u32x2){0u, 0u};
+            r.kw = 0u;
         }
     };
-    constexpr int LA = DROP ? 5 : 4;                             // vector-memory operations of one load_raw
+    constexpr int LA = (DROP && !(ABL & 64)) ? 5 : 4;                             // vector-memory operations of one load_raw
     // the W k-step of half-item hq (its index inside the round repeats with every round) into ring slot hq % BX_NB
     auto issue_b = [&](int hq) __attribute__((always_inline)) {
         if (ABL & 2) return;
@@ -208,7 +270,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         if (NW == 4) pg_glds16(src + (wave + 8) * 64 + lane, dst + (wave + 8) * 1024);
     };
     // what the W wait allows: the younger W pieces of this wave, BX_PD - 2 k-steps of 2 (eight waves) or 3 (four waves) pieces
-#define BX_WAIT_W() do { if (ABL & 16) PG_WAIT_BARRIER(0); else if (NW == 4) PG_WAIT_BARRIER(12); else PG_WAIT_BARRIER(8); } while (0)
+    static_assert(PD >= 5 && PD <= 9, "BX_WAIT_W spells the counts out");
+#define BX_WAIT_W() do { constexpr int n_ = (NW == 4 ? 3 : 2) * (PD - 2); \
+        if (ABL & 16) PG_WAIT_BARRIER(0); else if (n_ == 6) PG_WAIT_BARRIER(6); else if (n_ == 8) PG_WAIT_BARRIER(8); else if (n_ == 9) PG_WAIT_BARRIER(9); \
+        else if (n_ == 10) PG_WAIT_BARRIER(10); else if (n_ == 12) PG_WAIT_BARRIER(12); else if (n_ == 14) PG_WAIT_BARRIER(14); \
+        else if (n_ == 15) PG_WAIT_BARRIER(15); else if (n_ == 18) PG_WAIT_BARRIER(18); else if (n_ == 21) PG_WAIT_BARRIER(21); else PG_WAIT_BARRIER(0); } while (0)
 
     f32x16 acc[4];
 #pragma unroll
@@ -233,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     auto split_pair = [&](BxPlanes &P, const BxRaw &r, uint32_t win, int s, int i) __attribute__((always_inline)) {
         const f32x4 v = r.v[2 * s + (i >> 1)];
         float x0 = (i & 1) ? v[2] : v[0], x1 = (i & 1) ? v[3] : v[1];
-        if (DROP) {
+        if (DROP && !(ABL & 32)) {
             const int j = 8 * s + 2 * i;                         // bit j of the window <-> this lane's k value j of the chunk
             x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)(((int32_t)(win << (31 - j))) >> 31));
             x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)(((int32_t)(win << (30 - j))) >> 31));
@@ -243,9 +309,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     };
     auto window = [&](const BxRaw &r, int t, int c) __attribute__((always_inline)) -> uint32_t {
         if (!DROP) return 0u;
-        const int row = min((rb_lo + NW * t + wave) * 32 + li, row_last);
-        const uint32_t sh = (uint32_t)(((uint64_t)row * a.K + c * BX_BK + 16 * hh) & 31);
-        return (uint32_t)(((((uint64_t)r.kw[1]) << 32) | r.kw[0]) >> sh);
+        return r.kw >> (16 * hh);                                // bit j <-> k value 16 hh + j of the chunk
     };
     // the three planes of column block N of the W k-step in ring slot hq % BX_NB: issued, not waited for
     auto read_b = [&](BxB3 &b, int hq, auto n_tag) __attribute__((always_inline)) {
@@ -347,7 +411,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     // ---- prologue: W k-steps 0 .. BX_PD-1, X chunks 0 and 1; everything landed
     BxRaw R0, R1, R2;
 #pragma unroll
-    for (int q = 0; q < BX_PD; q++) issue_b(q);
+    for (int q = 0; q < PD; q++) issue_b(q);
     load_raw(R0, 0, 0);
     {
         const int t1 = a.n_chunks > 1 ? 0 : 1, c1 = a.n_chunks > 1 ? 1 : 0;
@@ -396,8 +460,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         // W k-step h0+1 has landed: issued BX_PD-1 half-items ago, BX_PD-2 younger k-steps of two pieces each.  Every wave is past
         // half-item h0-1: its ring slot takes k-step h0+BX_PD
         BX_WAIT_W();
-        static_assert(2 * (BX_PD - 2) == 8 && 3 * (BX_PD - 2) == 12, "the W wait above allows the younger W pieces: 2 (3) per k-step");
-        issue_b(h0 + BX_PD);
+        issue_b(h0 + PD);
         load_raw(Rc, t2, c2);
         read_b(Bn, h0, BxN<3>());
         __builtin_amdgcn_sched_barrier(0);
@@ -418,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         // ================= half-item (g, 1): MFMAs on P1; raw[g+1]'s first half -> P0
         // raw[g+1] has landed: issued three half-items ago; the younger loads of its kind are raw[g+2]'s
         if (ABL & 16) BX_WAIT_RAW(0, Rb);
-        else if (DROP) BX_WAIT_RAW(5, Rb);
+        else if (DROP && !(ABL & 64)) BX_WAIT_RAW(5, Rb);
         else BX_WAIT_RAW(4, Rb);
         const uint32_t wb = window(Rb, t1, c1);
         read_b(Bn, h0 + 1, BxN<1>());
@@ -438,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         __builtin_amdgcn_sched_barrier(0);
         BX_WAIT_LDS(Bc);
         BX_WAIT_W();
-        issue_b(h0 + 1 + BX_PD);
+        issue_b(h0 + 1 + PD);
         read_b(Bn, h0 + 1, BxN<3>());
         __builtin_amdgcn_sched_barrier(0);
         split_pair(P0, Rb, wb, 0, 2);
@@ -504,7 +567,7 @@ struct Bx3BwdArgs {
     float *slab; int p_ld;            // [gridDim.y][K][p_ld]
     int m, K, rps;                    // rows per split: a multiple of 16
     int split0;                       // blockIdx.y == 0 is row split number split0 (a launch may cover a range of the splits)
-    const uint32_t *bits;             // keep bits of X (element row*K + col), NULL: no dropout
+    const uint32_t *bits;             // keep bits of X, chunk-major (dropbits_cm_body), NULL: no dropout
     float scale;                      // 1 / (1 - p) with dropout, applied to the stored partial
 };
 
@@ -517,10 +580,10 @@ __device__ __forceinline__ float bx_keep(float x, uint64_t lane_mask) {     // x
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(y) : "v"(x), "s"(lane_mask));
     return y;
 }
-struct BxRaw8 { float a[8], b[8]; uint32_t k[8]; };          // k: with dropout, the word of the keep-bit array that holds the bit of a[j]
+struct BxRaw8 { float a[8], b[8]; uint32_t k; };             // k: with dropout, lane l holds the keep word of row 16 s + (l & 15) for this wave's 32 features
 #define BX_WAIT_RAW8(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((r).a[0]), "+v"((r).a[1]), "+v"((r).a[2]), "+v"((r).a[3]), "+v"((r).a[4]), "+v"((r).a[5]), "+v"((r).a[6]), "+v"((r).a[7]), \
                                                                    "+v"((r).b[0]), "+v"((r).b[1]), "+v"((r).b[2]), "+v"((r).b[3]), "+v"((r).b[4]), "+v"((r).b[5]), "+v"((r).b[6]), "+v"((r).b[7]), \
-                                                                   "+v"((r).k[0]), "+v"((r).k[1]), "+v"((r).k[2]), "+v"((r).k[3]), "+v"((r).k[4]), "+v"((r).k[5]), "+v"((r).k[6]), "+v"((r).k[7]) :: "memory")
+                                                                   "+v"((r).k) :: "memory")
 
 template <bool DROP, int NP>
 __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) {
@@ -543,25 +606,22 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) 
     const uint32_t vo_x0 = ((uint32_t)(r_lo + 8 * hh) * (uint32_t)a.ldx + (uint32_t)(F0 + li)) * 4u;
     const uint32_t vo_d0 = ((uint32_t)(r_lo + 8 * hh) * (uint32_t)a.ldd + (uint32_t)(32 * wave + li)) * 4u;
     const uint32_t step_x = 16u * (uint32_t)a.ldx * 4u, step_d = 16u * (uint32_t)a.ldd * 4u;
-    const u32x4 rs_k = bx_make_rsrc(a.bits, ((uint32_t)(((uint64_t)a.m * a.K) >> 5) + 2u) * 4u);
-    const uint32_t e_lane0 = (uint32_t)(r_lo + 8 * hh) * (uint32_t)a.K + (uint32_t)(F0 + li);   // element index of value j = 0 of step 0 (m * K < 2^32: checked at the launch site)
-    constexpr int LR = DROP ? 24 : 16;                           // vector-memory operations of one load_raw
+    // chunk-major keep words: this wave's 32 features are chunk F0 / 32 (a chunk past the matrix: out of the buffer's range, zeros)
+    const u32x4 rs_k = bx_make_rsrc(a.bits, (uint32_t)((a.K + 31) / 32) * (uint32_t)a.m * 4u);
+    const uint32_t vo_k0 = ((uint32_t)(F0 >> 5) * (uint32_t)a.m + (uint32_t)(r_lo + (lane & 15))) * 4u;   // (4 * chunks * m < 2^32: checked at the launch site)
+    constexpr int LR = DROP ? 17 : 16;                           // vector-memory operations of one load_raw
     auto load_raw = [&](BxRaw8 &r, int s) __attribute__((always_inline)) {
         const uint32_t vx = vo_x0 + (uint32_t)s * step_x, vd = vo_d0 + (uint32_t)s * step_d;
 #pragma unroll
         for (int j = 0; j < 8; j++) bx_bload4(r.a[j], vx, rs_x, so_x[j]);
 #pragma unroll
         for (int j = 0; j < 8; j++) bx_bload4(r.b[j], vd, rs_d, so_d[j]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (DROP) {
-                const uint32_t e = e_lane0 + (uint32_t)(16 * s + j) * (uint32_t)a.K;
-                uint32_t w;
-                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(w) : "v"((e >> 5) << 2), "s"(rs_k) : "memory");
-                r.k[j] = w;
-            } else {
-                r.k[j] = 0u;
-            }
+        if (DROP) {
+            uint32_t w;
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(w) : "v"(vo_k0 + (uint32_t)s * 64u), "s"(rs_k) : "memory");
+            r.k = w;
+        } else {
+            r.k = 0u;
         }
     };
     // lane masks of step s: bit l of M[j] = value j of lane l counts (its row is inside the split; with dropout: and is kept)
@@ -569,21 +629,22 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) 
     auto field = [&](int row) __attribute__((always_inline)) -> uint32_t {       // all ones when `row` is inside this split
         return row < r_hi ? 0xFFFFFFFFu : 0u;
     };
-    auto make_masks = [&](Masks &M, int s) __attribute__((always_inline)) {
+    // (with dropout: after raw(s) has landed — the keep word of row r0 + q sits in lane q and IS the lane mask of that row's values)
+    auto make_masks = [&](Masks &M, int s, const BxRaw8 &r) __attribute__((always_inline)) {
         const int r0 = r_lo + 16 * s;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            M.m[j] = (uint64_t)field(r0 + j) | ((uint64_t)field(r0 + 8 + j) << 32);
+            uint32_t lo = field(r0 + j), hi = field(r0 + 8 + j);
+            if (DROP) {
+                lo &= (uint32_t)__builtin_amdgcn_readlane((int)r.k, j);
+                hi &= (uint32_t)__builtin_amdgcn_readlane((int)r.k, 8 + j);
+            }
+            M.m[j] = (uint64_t)lo | ((uint64_t)hi << 32);
             asm volatile("" : "+s"(M.m[j]));                     // an SGPR pair whatever the value (v_cndmask takes no literal mask)
         }
     };
     auto split_a_pair = [&](BxPlanes &P, const BxRaw8 &r, const Masks &M, int s, int i) __attribute__((always_inline)) {
-        float x0 = bx_keep(r.a[2 * i], M.m[2 * i]), x1 = bx_keep(r.a[2 * i + 1], M.m[2 * i + 1]);
-        if (DROP) {
-            const uint32_t e0 = e_lane0 + (uint32_t)(16 * s + 2 * i) * (uint32_t)a.K, e1 = e0 + (uint32_t)a.K;
-            x0 = __uint_as_float(__float_as_uint(x0) & (uint32_t)(((int32_t)((r.k[2 * i] >> (e0 & 31)) << 31)) >> 31));
-            x1 = __uint_as_float(__float_as_uint(x1) & (uint32_t)(((int32_t)((r.k[2 * i + 1] >> (e1 & 31)) << 31)) >> 31));
-        }
+        const float x0 = bx_keep(r.a[2 * i], M.m[2 * i]), x1 = bx_keep(r.a[2 * i + 1], M.m[2 * i + 1]);
         bx_split2(x0, x1, P.w[0][i], P.w[1][i], P.w[2][i]);
     };
     auto split_b_pair = [&](BxPlanes &P, const BxRaw8 &r, int i) __attribute__((always_inline)) {
@@ -632,10 +693,10 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) 
         BxRaw8 R0, R1;
         load_raw(R0, 0);
         load_raw(R1, 1);                                         // (past the split's end: masked; past m: zeros)
-        if (DROP) BX_WAIT_RAW8(24, R0); else BX_WAIT_RAW8(16, R0);
+        if (DROP) BX_WAIT_RAW8(17, R0); else BX_WAIT_RAW8(16, R0);
         BxPlanes PA0, PA1, PB;
         Masks M;
-        make_masks(M, 0);
+        make_masks(M, 0, R0);
 #pragma unroll
         for (int i = 0; i < 4; i++) { split_a_pair(PA0, R0, M, 0, i); split_b_pair(PB, R0, i); }
         write_b(PB, 0);
@@ -647,8 +708,8 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) 
         auto step = [&](BxPlanes &PAc, BxPlanes &PAn, BxRaw8 &Rn, BxRaw8 &Rf, int s) __attribute__((always_inline)) {
             const int slot = s & 1;
             load_raw(Rf, s + 2);
-            make_masks(M, s + 1);
-            if (DROP) BX_WAIT_RAW8(24, Rn); else BX_WAIT_RAW8(16, Rn);   // raw(s+1): issued a step ago; younger: the loads just issued
+            if (DROP) BX_WAIT_RAW8(17, Rn); else BX_WAIT_RAW8(16, Rn);   // raw(s+1): issued a step ago; younger: the loads just issued
+            make_masks(M, s + 1, Rn);
             read_b(Bn, slot, BxN<1>());
             __builtin_amdgcn_sched_barrier(0);
             split_b_pair(PB, Rn, 0); split_b_pair(PB, Rn, 1);

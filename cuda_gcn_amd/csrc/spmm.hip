@@ -162,6 +162,7 @@ static inline bool keep_bits_by_block(const DropSpec &d) { return !d.keep_mask &
 
 static int make_keep_bits(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d) {
     if (!f->keep_bits) return gcnhip_fail("input dropout on a feature object without a keep-bit array (gcnhip_feat_create_aggregated builds evaluation-only objects)");
+    const_cast<gcnhip_feat *>(f)->keep_layout = 0;
     const int64_t words = (f->nnz + 31) / 32;
     if (keep_bits_by_block(d))
         dropbits_block_kernel<<<ceil_div((words + 3) / 4, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7);
@@ -169,6 +170,30 @@ static int make_keep_bits(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d
         dropbits_kernel<<<ceil_div(words, 256), 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off, d.keep_mask);
     GCNHIP_LAUNCH_CHECK();
     return 0;
+}
+
+// the same decisions chunk-major (dense X; dense_bf16x3.h): what the bf16x3 kernels read
+static BxBitsArgs keep_bits_cm_args(const gcnhip_feat *f, const DropSpec &d) {
+    BxBitsArgs b;
+    b.bits = f->keep_bits; b.m = f->n_rows; b.K = f->n_cols; b.n_chunks = (f->n_cols + 31) / 32;
+    b.R = std::max(1, std::min(128, (BX_BITS_LDS_WORDS - 12) * 32 / std::max(1, f->n_cols)));
+    b.thr = d.thr; b.seed = d.seed; b.d_epoch = d.d_epoch; b.off = d.off; b.keep_mask = d.keep_mask;
+    return b;
+}
+static inline bool keep_bits_cm_fit(const gcnhip_feat *f) { return f->dense && f->keep_bits && f->n_cols / 32 + 16 <= BX_BITS_LDS_WORDS; }
+static int make_keep_bits_cm(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d) {
+    if (!keep_bits_cm_fit(f)) return gcnhip_fail("chunk-major keep bits: not a dense feature object with a keep-bit array");
+    const BxBitsArgs b = keep_bits_cm_args(f, d);
+    const_cast<gcnhip_feat *>(f)->keep_layout = 1;
+    dropbits_cm_kernel<<<ceil_div(b.m, b.R), 256, 0, c->stream>>>(b);
+    GCNHIP_LAUNCH_CHECK();
+    return 0;
+}
+// A consumer that did not make the decisions itself (gcnhip_spmm_bwd_part with make_decisions = 0) finds them in the layout of
+// whoever did; the decisions are a pure function of (seed, epoch, offset), so the other layout is one launch away.
+static int want_keep_layout(gcnhip_ctx *c, const gcnhip_feat *f, const DropSpec &d, int layout, bool fresh = false) {
+    if (!d.on || (!fresh && f->keep_layout == layout)) return 0;
+    return layout ? make_keep_bits_cm(c, f, d) : make_keep_bits(c, f, d);
 }
 
 static int x_vec_width(const gcnhip_feat *f, const float *vals) {
@@ -215,17 +240,17 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
         if (zf && !(fast && p == 128 && !tiles_only && bx && !d.on && aligned16(t.x) && zf->p2 >= 1 && zf->p2 <= 64 && zf->ld_z0 % 4 == 0 &&
                     zf->ld_z0 >= zf->p2 && zf->ld_w2 >= zf->p2 && aligned16(zf->z0) && (size_t)n_chunks * 2 * BX_BH_BYTES + BX_W2_BYTES <= c->wpack_bytes))
             return GCNHIP_NOT_AVAILABLE;                          // the caller runs the two products one after the other
-        if (fast && p == 128 && !tiles_only && bx && (zf || ((bx >= 2 || !c->corun) && aligned16(out) &&
+        if (fast && p == 128 && !tiles_only && bx && (!d.on || keep_bits_cm_fit(f)) && (zf || ((bx >= 2 || !c->corun) && aligned16(out) &&
             (uint64_t)(t.m + 256) * (uint64_t)ld_out * 4u < (1ull << 32))) && aligned16(t.x) && (size_t)n_chunks * 2 * BX_BH_BYTES <= c->wpack_bytes) {
             const int n_hs = 2 * n_chunks;
             uint4 *wp3 = reinterpret_cast<uint4 *>(c->wpack);
             uint4 *w2img = wp3 + (size_t)n_hs * (BX_BH_BYTES / 16);
-            if (d.on && keep_bits_by_block(d)) {         // keep bits and the packed planes of W from one launch
-                const int n_bits_wgs = (int)ceil_div(((f->nnz + 31) / 32 + 3) / 4, (int64_t)256);
-                dropbits_bx_pack_w_kernel<<<n_bits_wgs + n_hs, 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7, n_bits_wgs,
-                                                                                     w, ld_w, t.K, n_hs, wp3, t.scale);
+            if (d.on) {                                  // keep words (chunk-major) and the packed planes of W from one launch
+                const BxBitsArgs kb = keep_bits_cm_args(f, d);
+                const int n_bits_wgs = ceil_div(kb.m, kb.R);
+                const_cast<gcnhip_feat *>(f)->keep_layout = 1;
+                dropbits_bx_pack_w_kernel<<<n_bits_wgs + n_hs, 256, 0, c->stream>>>(kb, n_bits_wgs, w, ld_w, t.K, n_hs, wp3, t.scale);
             } else {
-                if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
                 if (zf) bx_pack_w_kernel<<<n_hs + 4, 256, 0, c->stream>>>(w, ld_w, t.K, n_hs, wp3, 1.f, zf->w2, zf->ld_w2, zf->p2, w2img);
                 else bx_pack_w_kernel<<<n_hs, 256, 0, c->stream>>>(w, ld_w, t.K, n_hs, wp3, t.bits ? t.scale : 1.f);
             }
@@ -257,6 +282,7 @@ static int spmm_fwd_impl(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
             (uint64_t)(t.m + PG_ROWS) * (uint64_t)ld_out * 4u < (1ull << 32) && (size_t)n_chunks * 4096 * sizeof(float) <= c->wpack_bytes) {
             if (d.on && keep_bits_by_block(d)) {         // keep bits and the packed W from one launch
                 const int n_bits_wgs = (int)ceil_div(((f->nnz + 31) / 32 + 3) / 4, (int64_t)256);
+                const_cast<gcnhip_feat *>(f)->keep_layout = 0;
                 dropbits_pack_w_kernel<<<n_bits_wgs + n_chunks * 4, 256, 0, c->stream>>>(f->keep_bits, f->nnz, d.thr, d.seed, d.d_epoch, d.off >> 7, n_bits_wgs,
                                                                                        w, ld_w, t.K, n_chunks * 4, c->wpack, t.scale);
             } else {
@@ -469,13 +495,17 @@ static int dense_bwd_persist(gcnhip_ctx *c, const gcnhip_feat *f, const float *v
 #endif
 
 // splits [s0, s1) of the plan into their slabs
+// fresh: the keep decisions of this call have not been made yet (else: whoever made them left them in f->keep_bits)
 static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,
-                          const DropSpec &d, int s0, int s1) {
+                          const DropSpec &d, int s0, int s1, bool fresh) {
     int rps, S;
     if (!dense_bwd_plan(c, f, p, &rps, &S) || s0 < 0 || s1 > S || s0 > s1) return -1;
     if (s0 == s1) return 0;
     if (d.on && !f->keep_bits) return gcnhip_fail("input dropout on a feature object without a keep-bit array");
     if (s0 == 0 && s1 == S) {                    // every split at once: the persistent form when the shape is its
+#ifdef GCNHIP_EXPERIMENTS
+        if (c->opt.gemm_persist_bwd != 0) { const int rl = want_keep_layout(c, f, d, 0, fresh); if (rl) return rl; fresh = false; }
+#endif
         const int rc = dense_bwd_persist(c, f, vals, dout, ld_dout, p, d);
         if (rc <= 0) return rc;
     }
@@ -491,7 +521,9 @@ static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals
         const bool padded = vals == f->values && f->values_pad && f->ld_pad >= kt * 128;
         if (bx && (bx >= 2 || !c->corun) && p == 128 && padded && rps % 16 == 0 && ld_dout % 4 == 0 && aligned16(dout) &&
             (uint64_t)f->n_rows * (uint64_t)f->ld_pad * 4u < (1ull << 32) && (uint64_t)f->n_rows * (uint64_t)ld_dout * 4u < (1ull << 32) &&
-            (uint64_t)f->n_rows * (uint64_t)f->n_cols < (1ull << 32)) {
+            (uint64_t)f->n_rows * (uint64_t)f->n_cols < (1ull << 32) && (uint64_t)kt * 16u * (uint64_t)f->n_rows < (1ull << 32) &&
+            (!d.on || keep_bits_cm_fit(f))) {
+            { const int rl = want_keep_layout(c, f, d, 1, fresh); if (rl) return rl; }
             Bx3BwdArgs b;
             b.x = f->values_pad; b.ldx = f->ld_pad; b.dout = dout; b.ldd = ld_dout; b.slab = c->slab; b.p_ld = p_ld;
             b.m = f->n_rows; b.K = f->n_cols; b.rps = rps; b.split0 = s0; b.bits = d.on ? f->keep_bits : nullptr; b.scale = d.on ? d.scale : 1.f;
@@ -502,6 +534,7 @@ static int dense_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals
             return 0;
         }
     }
+    { const int rl = want_keep_layout(c, f, d, 0, fresh); if (rl) return rl; }
     Tile128Args t;
     t.x = vals; t.ldx = f->n_cols; t.w = dout; t.ldw = ld_dout; t.out = c->slab; t.ldo = p_ld;
     int vx = x_vec_width(f, vals);
@@ -544,8 +577,7 @@ int gcnhip_spmm_bwd_part(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals,
     if (!c || !f || !vals || !dout || p <= 0 || ld_dout < p) return -1;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return -1;
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
-    if (d.on && make_decisions) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
-    return dense_bwd_part(c, f, vals, dout, ld_dout, p, d, split_begin, split_end);
+    return dense_bwd_part(c, f, vals, dout, ld_dout, p, d, split_begin, split_end, make_decisions != 0);
 }
 
 int gcnhip_spmm_bwd_finish(gcnhip_ctx *c, const gcnhip_feat *f, float *dw, int ld_dw, int p) {
@@ -561,8 +593,7 @@ int gcnhip_spmm_bwd(gcnhip_ctx *c, const gcnhip_feat *f, const float *vals, cons
     const DropSpec d = make_drop(p_drop, seed, d_epoch, nnz_offset, keep_mask);
     int rps, S;
     if (dense_bwd_plan(c, f, p, &rps, &S)) {          // split-K 128 x 128 MFMA tiles + ordered slab sum
-        if (d.on) { const int rc = make_keep_bits(c, f, d); if (rc) return rc; }
-        const int rc = dense_bwd_part(c, f, vals, dout, ld_dout, p, d, 0, S);
+        const int rc = dense_bwd_part(c, f, vals, dout, ld_dout, p, d, 0, S, true);
         if (rc) return rc;
         return dense_bwd_finish(c, f, dw, ld_dw, p);
     }

@@ -390,8 +390,9 @@ class Device:
         _ck(self.lib, self.lib.gcnhip_spmm_bwd_plan(self.ctx, f.h, p, C.byref(rps), C.byref(ns)), "gcnhip_spmm_bwd_plan")
         return rps.value, ns.value
 
-    def spmm_bwd_parts(self, f: "Feat", dout, cuts, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, order=None):
-        """the weight gradient as gcnhip_spmm_bwd_part calls on the split ranges between `cuts` (in `order`), then _finish"""
+    def spmm_bwd_parts(self, f: "Feat", dout, cuts, p_drop=0.0, seed=0, epoch=0, nnz_offset=0, order=None, make_first=True):
+        """the weight gradient as gcnhip_spmm_bwd_part calls on the split ranges between `cuts` (in `order`), then _finish;
+        make_first=False: no part makes the keep decisions (a forward with the same arguments left them in the feature object)"""
         dout = np.asarray(dout, np.float32)
         p = dout.shape[1]
         db = self.padded(dout, p)
@@ -400,7 +401,7 @@ class Device:
         ranges = list(zip(cuts[:-1], cuts[1:]))
         for k, i in enumerate(order if order is not None else range(len(ranges))):
             _ck(self.lib, self.lib.gcnhip_spmm_bwd_part(self.ctx, f.h, f.values_ptr, db.ptr, p, p, p_drop, seed, ep.ptr, nnz_offset, None,
-                                                         ranges[i][0], ranges[i][1], 1 if k == 0 else 0), "gcnhip_spmm_bwd_part")
+                                                         ranges[i][0], ranges[i][1], 1 if (k == 0 and make_first) else 0), "gcnhip_spmm_bwd_part")
         _ck(self.lib, self.lib.gcnhip_spmm_bwd_finish(self.ctx, f.h, dw.ptr, p, p), "gcnhip_spmm_bwd_finish")
         return dw.download()
 

@@ -729,6 +729,64 @@ def test_spmm_dense_vs_oracle(dev, oracle, N, F, p):
     f.free()
 
 
+@pytest.mark.parametrize("N,F", [(257, 602), (1000, 96), (4099, 33), (40000, 200), (129, 64)])
+@pytest.mark.parametrize("p_drop,off", [(0.5, 0), (0.5, 4 * 1001), (0.3, 128 * 5), (0.3, 77)])
+def test_first_layer_dropout_from_chunk_major_keep_words(dev, oracle, N, F, p_drop, off):
+    """p = 128, dense X: the bf16x3 kernels read the input-dropout decisions CHUNK-MAJOR (a word per row and 32 columns, made
+    from the same Philox stream by dropbits_cm_body: dense_bf16x3.h).  Forward and weight gradient against the oracle fed
+    with the documented decisions of the stream, for stream offsets that are whole Philox blocks, whole words or neither, a
+    rate that needs several bit planes, K with a partial last chunk, and rows that are not a multiple of the generator's
+    row groups.  (F = 33: no padded copy of X, so the tile kernels and their flat keep bits run — the same check.)"""
+    rng = np.random.default_rng(N + F)
+    vals = rng.standard_normal(N * F).astype(np.float32)
+    fp = (np.arange(N + 1) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    w = rng.standard_normal((F, 128)).astype(np.float32)
+    dout = rng.standard_normal((N, 128)).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    assert f.dense
+    seed, epoch = 0x5eed1234, 9
+    k = philox_keep(seed, epoch, np.arange(N * F, dtype=np.uint64) + np.uint64(off), thr_of(p_drop))
+    scale = np.float32(1) / (np.float32(1) - np.float32(p_drop))
+    vd = (vals * np.where(k, scale, np.float32(0))).astype(np.float32)
+    kw = dict(p_drop=p_drop, seed=seed, epoch=epoch, nnz_offset=off)
+    close_mag(dev.spmm_fwd(f, w, **kw), oracle.spmm_fwd(fp, fi, vd, w, 128), oracle.spmm_fwd(fp, fi, np.abs(vd), np.abs(w), 128))
+    close_mag(dev.spmm_bwd(f, dout, **kw), oracle.spmm_bwd(fp, fi, vd, dout, F, 128), oracle.spmm_bwd(fp, fi, np.abs(vd), np.abs(dout), F, 128))
+    f.free()
+
+
+def test_keep_decisions_change_layout_between_the_forward_and_the_gradient(dev):
+    """gcnhip_spmm_bwd_part with make_decisions = 0 reads the decisions the forward left in the feature object.  When the two
+    run on different kernel families (option gemm_bf16x3 switched in between) the layouts differ (flat / chunk-major): the
+    gradient re-derives its own from (seed, epoch, offset) — the same bits as a call that makes them itself."""
+    from cuda_gcn_amd.ops import _ck
+    N, F = 3000, 602
+    rng = np.random.default_rng(3)
+    vals = rng.standard_normal(N * F).astype(np.float32)
+    fp = (np.arange(N + 1) * F).astype(np.int32)
+    fi = np.tile(np.arange(F, dtype=np.int32), N)
+    w = rng.standard_normal((F, 128)).astype(np.float32)
+    dout = rng.standard_normal((N, 128)).astype(np.float32)
+    f = dev.feat(fp, fi, vals, F)
+    bx = C.c_int()
+    _ck(dev.lib, dev.lib.gcnhip_ctx_get_option(dev.ctx, b"gemm_bf16x3", C.byref(bx)), "get_option")
+    kw = dict(p_drop=0.5, seed=11, epoch=4)
+    _, S = dev.spmm_bwd_plan(f, 128)
+    try:
+        for fwd_opt, bwd_opt in ((0, 1), (1, 0), (1, 1), (0, 0)):
+            _ck(dev.lib, dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", bwd_opt), "set_option")
+            want = dev.spmm_bwd(f, dout, **kw)
+            dev.spmm_fwd(f, w, p_drop=0.5, seed=99, epoch=1)         # other decisions in the object, in the gradient's layout
+            _ck(dev.lib, dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", fwd_opt), "set_option")
+            dev.spmm_fwd(f, w, **kw)
+            _ck(dev.lib, dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", bwd_opt), "set_option")
+            got = dev.spmm_bwd_parts(f, dout, [0, S], make_first=False, **kw)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (fwd_opt, bwd_opt)
+    finally:
+        _ck(dev.lib, dev.lib.gcnhip_ctx_set_option(dev.ctx, b"gemm_bf16x3", bx.value), "set_option")
+    f.free()
+
+
 @pytest.mark.parametrize("N,F", [(5000, 602), (257, 602), (70000, 96), (31, 40)])
 def test_dense_forward_persistent_and_tile_kernels_give_the_same_bits(dev, N, F):
     """p = 128, dense X: the persistent LDS-DMA kernel (dense_persist.h) and the 128 x 128 tile kernel (dense_tile128.h; what

@@ -101,6 +101,18 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbits, hbits.data(), hbits.size() * 4, hipMemcpyHostToDevice));
+    // the same decisions chunk-major (word c * m + r = columns 32 c .. 32 c + 31 of row r): what the bf16x3 kernels read
+    uint32_t *dcm;
+    {
+        std::vector<uint32_t> hcm((size_t)n_chunks * m + 32, 0u);
+        for (int r = 0; r < m; r++)
+            for (int k = 0; k < K; k++) {
+                const size_t e = (size_t)r * K + k;
+                if ((hbits[e >> 5] >> (e & 31)) & 1) hcm[(size_t)(k >> 5) * m + r] |= 1u << (k & 31);
+            }
+        CK(hipMalloc(&dcm, hcm.size() * 4));
+        CK(hipMemcpy(dcm, hcm.data(), hcm.size() * 4, hipMemcpyHostToDevice));
+    }
 
     // sampled rows for the error check
     std::vector<int> rows;
@@ -153,10 +165,23 @@ int main(int argc, char **argv) {
         printf("  ablation  2 (no W DMA):       %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 2><<<n_cu, 512>>>(a); }));
         printf("  ablation  4 (no split):       %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 4><<<n_cu, 512>>>(a); }));
         printf("  ablation  8 (no W LDS reads): %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 8><<<n_cu, 512>>>(a); }));
+        a.bits = dcm;
+        printf("  dropout, full:                %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0><<<n_cu, 512>>>(a); }));
+        printf("  dropout, mask not applied:    %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 32><<<n_cu, 512>>>(a); }));
+        printf("  dropout, keep words not read: %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 64><<<n_cu, 512>>>(a); }));
+        printf("  dropout, neither:             %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 96><<<n_cu, 512>>>(a); }));
+        printf("  no dropout:                   %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0><<<n_cu, 512>>>(a); }));
+        // W k-steps in flight ahead of use (the W wait counts this wave's YOUNGER W pieces; X loads still in flight count against it)
+        printf("  prefetch distance 6 / 7 / 8 / 9, no dropout: %.4f %.4f %.4f %.4f ms\n",
+               time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0, 8, false, 6><<<n_cu, 512>>>(a); }), time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0, 8, false, 7><<<n_cu, 512>>>(a); }),
+               time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0, 8, false, 8><<<n_cu, 512>>>(a); }), time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0, 8, false, 9><<<n_cu, 512>>>(a); }));
+        printf("  prefetch distance 6 / 7 / 8 / 9, dropout:    %.4f %.4f %.4f %.4f ms\n",
+               time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0, 8, false, 6><<<n_cu, 512>>>(a); }), time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0, 8, false, 7><<<n_cu, 512>>>(a); }),
+               time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0, 8, false, 8><<<n_cu, 512>>>(a); }), time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0, 8, false, 9><<<n_cu, 512>>>(a); }));
         printf("  ablation 15 (all of them):    %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 15><<<n_cu, 512>>>(a); }));
         for (int np = 6; np <= 8; np += 2)
             for (int drop = 0; drop < 2; drop++) {
-                a.bits = drop ? dbits : nullptr;
+                a.bits = drop ? dcm : nullptr;
                 const float scale = drop ? 2.f : 1.f;
                 auto run = [&]() {
                     bx_pack_w_kernel<<<(n_chunks * 512 + 255) / 256, 256>>>(dw, p, K, 2 * n_chunks, dwp, scale);
@@ -270,7 +295,7 @@ int main(int argc, char **argv) {
             check_dw(ddw2, "f32 MFMA", drop, t.scale);
         }
         for (int drop = 0; drop < 2; drop++) {
-            Bx3BwdArgs b{dxp, ldp, dd, p, dslab, p, m, K, rps, 0, drop ? dbits : nullptr, drop ? 2.f : 1.f};
+            Bx3BwdArgs b{dxp, ldp, dd, p, dslab, p, m, K, rps, 0, drop ? dcm : nullptr, drop ? 2.f : 1.f};
             dim3 grid(n_fr, S);
             const float ms = time_ms(iters, [&]() {
                 if (drop) dense_bwd_bf16x3_kernel<true, 6><<<grid, 256>>>(b); else dense_bwd_bf16x3_kernel<false, 6><<<grid, 256>>>(b);
