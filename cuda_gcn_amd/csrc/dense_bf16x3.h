@@ -126,8 +126,11 @@ __device__ inline void dropbits_cm_body(int wg, int tid, const BxBitsArgs &b, ui
     }
     __syncthreads();
     const int rows = rb - ra;
+    const uint32_t rel0 = (uint32_t)(bit0 - (q0 << 7));                   // this workgroup's first bit inside the LDS image
     for (int idx = tid; idx < b.n_chunks * rows; idx += 256) {
-        const int c = idx / rows, r = idx - c * rows, row = ra + r;
+        int c, r;
+        if (rows == 128) { c = idx >> 7; r = idx & 127; } else { c = idx / rows; r = idx - c * rows; }
+        const int row = ra + r;
         const int valid = min(32, b.K - 32 * c);                          // columns of this chunk inside the matrix
         uint32_t word;
         if (b.keep_mask) {
@@ -135,7 +138,7 @@ __device__ inline void dropbits_cm_body(int wg, int tid, const BxBitsArgs &b, ui
             const uint8_t *km = b.keep_mask + (size_t)row * b.K + 32 * c;
             for (int i = 0; i < valid; i++) word |= (km[i] ? 1u : 0u) << i;
         } else {
-            const uint32_t rel = (uint32_t)(b.off + (uint64_t)row * b.K + 32u * (uint32_t)c - (q0 << 7));
+            const uint32_t rel = rel0 + (uint32_t)r * (uint32_t)b.K + 32u * (uint32_t)c;
             const uint32_t lo = lds[rel >> 5], hi = lds[(rel >> 5) + 1], sh = rel & 31u;
             word = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
             if (valid < 32) word &= (1u << valid) - 1u;
