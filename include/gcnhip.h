@@ -337,8 +337,10 @@ int gcnhip_spmm_bwd(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, co
  * still being produced:  _plan reports the ranges (n_splits == 0: this shape does not take the split-K path, use
  * gcnhip_spmm_bwd);  _part computes splits [split_begin, split_end) into the context's slabs — rows
  * [split_begin * rows_per_split, min(n_rows, split_end * rows_per_split)) of X and dOut are all it reads;
- * make_decisions != 0 (re)generates the input-dropout decisions first, once per backward;  _finish sums the slabs of
- * the same context.  gcnhip_spmm_bwd is exactly _part(0, n_splits, 1) + _finish. */
+ * make_decisions != 0 (re)generates the input-dropout decisions first, once per backward (0: the decisions a forward or an
+ * earlier part made with the same p_drop / seed / epoch / nnz_offset are still in the feature object; their bit layout is the
+ * library's own — flat or a word per row and 32 columns, by kernel family — and a part that needs the other one re-derives it
+ * from the same arguments);  _finish sums the slabs of the same context.  gcnhip_spmm_bwd is exactly _part(0, n_splits, 1) + _finish. */
 int gcnhip_spmm_bwd_plan(const gcnhip_ctx *ctx, const gcnhip_feat *f, int p, int *rows_per_split, int *n_splits);
 int gcnhip_spmm_bwd_part(gcnhip_ctx *ctx, const gcnhip_feat *f, const float *vals, const float *dout, int ld_dout, int p,
                          float p_drop, uint64_t seed, const uint32_t *d_epoch, uint64_t nnz_offset, const uint8_t *keep_mask,
