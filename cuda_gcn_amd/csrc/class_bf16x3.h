@@ -209,12 +209,12 @@ __global__ __launch_bounds__(512) void class_bwd_bf16x3_kernel(ClsBwdArgs a) {
     auto issue_l1 = [&](int b) __attribute__((always_inline)) {
         const uint32_t row = (uint32_t)(b * 32 + li);
         const uint32_t vz = (row * (uint32_t)a.lddz + 8u * hh) * 4u;
+        if constexpr (ABL & 4) { bx_bload16<0>(KB, row * 16u, rs_b); bx_bload4(RSC, row * 4u, rs_s, 0u); }      // (experiment: the small loads first)
         bx_bload16<0>(Z[0], vz, rs_z); bx_bload16<16>(Z[1], vz, rs_z);
         if constexpr (NKS > 1) { bx_bload16<64>(Z[2], vz, rs_z); bx_bload16<80>(Z[3], vz, rs_z); }
         if constexpr (NKS > 2) { bx_bload16<128>(Z[4], vz, rs_z); bx_bload16<144>(Z[5], vz, rs_z); }
         if constexpr (NKS > 3) { bx_bload16<192>(Z[6], vz, rs_z); bx_bload16<208>(Z[7], vz, rs_z); }
-        bx_bload16<0>(KB, row * 16u, rs_b);
-        bx_bload4(RSC, row * 4u, rs_s, 0u);
+        if constexpr (!(ABL & 4)) { bx_bload16<0>(KB, row * 16u, rs_b); bx_bload4(RSC, row * 4u, rs_s, 0u); }
     };
     constexpr int NL1 = 2 * NKS + 2;
     ClsCol Cc;

@@ -254,9 +254,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         const int row = min((rb_lo + NW * t + wave) * 32 + li, row_last);
         const float *p = a.x + (size_t)row * a.ldx + c * BX_BK + 16 * hh;
         if (ABL & 1) p = a.x + lane * 16;
+        // the keep word FIRST: 32 consecutive rows = one line (both lane halves read the same words).  Issued after the four
+        // X loads the same load cost 9 us more per launch (tools/gemm_bf16x3.hip, ablation 128)
+        if (DROP && !(ABL & 64) && !(ABL & 128)) bx_gload4(r.kw, a.bits + (size_t)c * a.m + row);
         bx_gload16<0>(r.v[0], p); bx_gload16<16>(r.v[1], p); bx_gload16<32>(r.v[2], p); bx_gload16<48>(r.v[3], p);
         if (DROP && !(ABL & 64)) {
-            bx_gload4(r.kw, a.bits + (size_t)c * a.m + row);    // 32 consecutive rows: one line (both lane halves read the same words)
+            if (ABL & 128) bx_gload4(r.kw, a.bits + (size_t)c * a.m + row);
         } else {
             r.kw = 0u;
         }
@@ -463,8 +466,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         // W k-step h0+1 has landed: issued BX_PD-1 half-items ago, BX_PD-2 younger k-steps of two pieces each.  Every wave is past
         // half-item h0-1: its ring slot takes k-step h0+BX_PD
         BX_WAIT_W();
-        issue_b(h0 + PD);
-        load_raw(Rc, t2, c2);
+        if (ABL & 256) { load_raw(Rc, t2, c2); issue_b(h0 + PD); }      // (experiment: the X loads ahead of the W pieces)
+        else { issue_b(h0 + PD); load_raw(Rc, t2, c2); }
         read_b(Bn, h0, BxN<3>());
         __builtin_amdgcn_sched_barrier(0);
         split_pair(P1, Ra, wa, 1, 2);
@@ -588,7 +591,7 @@ struct BxRaw8 { float a[8], b[8]; uint32_t k; };             // k: with dropout,
                                                                    "+v"((r).b[0]), "+v"((r).b[1]), "+v"((r).b[2]), "+v"((r).b[3]), "+v"((r).b[4]), "+v"((r).b[5]), "+v"((r).b[6]), "+v"((r).b[7]), \
                                                                    "+v"((r).k) :: "memory")
 
-template <bool DROP, int NP>
+template <bool DROP, int NP, int ORD = 0>      // ORD: load-order experiments of tools/gemm_bf16x3.hip (1: keep word first, 2: dH0 before X, 4: X and dH0 interleaved)
 __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BX_BH_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -615,17 +618,28 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_bf16x3_kernel(Bx3BwdArgs a) 
     constexpr int LR = DROP ? 17 : 16;                           // vector-memory operations of one load_raw
     auto load_raw = [&](BxRaw8 &r, int s) __attribute__((always_inline)) {
         const uint32_t vx = vo_x0 + (uint32_t)s * step_x, vd = vo_d0 + (uint32_t)s * step_d;
-#pragma unroll
-        for (int j = 0; j < 8; j++) bx_bload4(r.a[j], vx, rs_x, so_x[j]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) bx_bload4(r.b[j], vd, rs_d, so_d[j]);
-        if (DROP) {
+        auto load_k = [&]() __attribute__((always_inline)) {
             uint32_t w;
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(w) : "v"(vo_k0 + (uint32_t)s * 64u), "s"(rs_k) : "memory");
             r.k = w;
+        };
+        if (DROP && (ORD & 1)) load_k();
+        if (ORD & 4) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { bx_bload4(r.a[j], vx, rs_x, so_x[j]); bx_bload4(r.b[j], vd, rs_d, so_d[j]); }
+        } else if (ORD & 2) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) bx_bload4(r.b[j], vd, rs_d, so_d[j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) bx_bload4(r.a[j], vx, rs_x, so_x[j]);
         } else {
-            r.k = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) bx_bload4(r.a[j], vx, rs_x, so_x[j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) bx_bload4(r.b[j], vd, rs_d, so_d[j]);
         }
+        if (DROP && !(ORD & 1)) load_k();
+        if (!DROP) r.k = 0u;
     };
     // lane masks of step s: bit l of M[j] = value j of lane l counts (its row is inside the split; with dropout: and is kept)
     struct Masks { uint64_t m[8]; };

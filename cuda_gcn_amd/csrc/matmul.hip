@@ -37,9 +37,9 @@ static int launch_class_bwd(gcnhip_ctx *c, const float *a, int lda, const float 
         GCNHIP_TRY(hipFuncSetAttribute((const void *)class_bwd_bf16x3_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, CLS_BWD_LDS)); \
         class_bwd_bf16x3_kernel<__VA_ARGS__><<<grid, 512, CLS_BWD_LDS, c->stream>>>(k);                                          \
     } while (0)
-    const int abl = c->opt.cls_abl & 3;                       // measurement aid (tools/bench_class.py), p = 33..48 only
+    const int abl = c->opt.cls_abl & 7;                       // measurement aid (tools/bench_class.py), p = 33..48 only
     if (abl && nks == 3) {
-        if (abl == 1) CLS_BWD(3, 1); else if (abl == 2) CLS_BWD(3, 2); else CLS_BWD(3, 3);
+        if (abl == 1) CLS_BWD(3, 1); else if (abl == 2) CLS_BWD(3, 2); else if (abl == 3) CLS_BWD(3, 3); else CLS_BWD(3, 4);
     } else {
         switch (nks) {
             case 1: CLS_BWD(1); break;

@@ -66,6 +66,13 @@ def main():
                                                              bits.ptr, 4, rs.ptr), "bwd"))
         res[f"ablation_{abl}"] = {"what": what, "fwd_ms": f, "bwd_ms": b}
         print(f"[bench_class] bf16x3, {what}: H1.W2 {f * 1e3:.1f} us, dH1 + dW2 {b * 1e3:.1f} us", flush=True)
+    for rep in range(3):                                  # load order of the backward's row loads (rotated: the clock drifts)
+        for abl, what in ((0, "dZ0 row, mask words, row factor"), (4, "mask words and row factor first")):
+            lib.gcnhip_ctx_set_option(dev.ctx, b"cls_abl", abl)
+            b = timeit(lambda: _ck(lib, lib.gcnhip_matmul_bwd_ex(dev.ctx, h1.ptr, h, w2.ptr, ldc, dz.ptr, ldc, dh.ptr, h, dw2.ptr, ldc, N, h, Cc, 2.0,
+                                                                 bits.ptr, 4, rs.ptr), "bwd"))
+            res.setdefault(f"bwd_load_order_{abl}", []).append(b)
+            print(f"[bench_class] bf16x3 backward, {what}: {b * 1e3:.1f} us", flush=True)
     lib.gcnhip_ctx_set_option(dev.ctx, b"cls_abl", 0)
     for wgs in (1, 2, 3):
         lib.gcnhip_ctx_set_option(dev.ctx, b"cls_wgs", wgs)

@@ -167,6 +167,10 @@ int main(int argc, char **argv) {
         printf("  ablation  8 (no W LDS reads): %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 8><<<n_cu, 512>>>(a); }));
         a.bits = dcm;
         printf("  dropout, full:                %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0><<<n_cu, 512>>>(a); }));
+        printf("  dropout, keep word loaded last:  %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 128><<<n_cu, 512>>>(a); }));
+        printf("  dropout, full (again):        %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0><<<n_cu, 512>>>(a); }));
+        printf("  X loads ahead of the W pieces: dropout %.4f, none %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 256><<<n_cu, 512>>>(a); }),
+               time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 256><<<n_cu, 512>>>(a); }));
         printf("  dropout, mask not applied:    %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 32><<<n_cu, 512>>>(a); }));
         printf("  dropout, keep words not read: %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 64><<<n_cu, 512>>>(a); }));
         printf("  dropout, neither:             %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 96><<<n_cu, 512>>>(a); }));
@@ -304,6 +308,19 @@ int main(int argc, char **argv) {
             CK(hipGetLastError());
             printf("bf16x3 weight gradient, 6 plane products, dropout %d: %.4f ms  %.1f TF/s algorithmic\n", drop, ms, 2.0 * m * K * p / ms / 1e9);
             check_dw(ddw, "bf16x3, 6 plane products", drop, b.scale);
+        }
+        {   // the order in which a step's loads are issued (kernel alone, no slab sum)
+            Bx3BwdArgs b{dxp, ldp, dd, p, dslab, p, m, K, rps, 0, dcm, 2.f};
+            dim3 grid(n_fr, S);
+            for (int rep = 0; rep < 3; rep++)    // (rotated: the clock drifts with what ran before)
+                printf("  weight gradient with dropout, kernel alone; X, dH0, keep word: %.4f  keep word first: %.4f  dH0 first: %.4f  interleaved: %.4f  interleaved + keep word first: %.4f ms\n",
+                       time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<true, 6, 0><<<grid, 256>>>(b); }),
+                       time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<true, 6, 1><<<grid, 256>>>(b); }), time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<true, 6, 2><<<grid, 256>>>(b); }),
+                       time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<true, 6, 4><<<grid, 256>>>(b); }), time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<true, 6, 5><<<grid, 256>>>(b); }));
+            b.bits = nullptr; b.scale = 1.f;
+            printf("  weight gradient without dropout, kernel alone; X, dH0: %.4f  dH0 first: %.4f  interleaved: %.4f ms\n",
+                   time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<false, 6, 0><<<grid, 256>>>(b); }), time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<false, 6, 2><<<grid, 256>>>(b); }),
+                   time_ms(iters, [&]() { dense_bwd_bf16x3_kernel<false, 6, 4><<<grid, 256>>>(b); }));
         }
     }
     return 0;
