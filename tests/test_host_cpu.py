@@ -65,6 +65,45 @@ def test_parser_vs_oracle_and_binary_cache(oracle):
         assert (c["num_nodes"], c["input_dim"], c["output_dim"]) == (ds["num_nodes"], ds["input_dim"], ds["output_dim"])
 
 
+def test_seeding_is_private_to_the_model():
+    """Several models are built at the same time in one process (gcn-hip: a host thread per GPU; the tests: logical ranks as
+    threads).  The reference seeds through libc's process-wide srand / rand; with that, two threads seeding at once drew each
+    other's numbers and a rank started from other weights than its peers.  Eight threads seed and draw 3 000 times each,
+    half of them with another seed, while the main thread hammers the process-wide generator: every draw must be the
+    reference's weights for ITS seed (the golden fixture for seed 7)."""
+    import ctypes, threading
+    from cuda_gcn_amd import model
+    mods = np.load(os.path.join(GOLD, "modules.npz"))
+    want7 = mods["glorot_seed7_30x20"]
+    want9 = model.glorot(600, 30, 20, seed=9)
+    assert not np.array_equal(want7, want9)
+    libc = ctypes.CDLL(None)
+    stop, bad = threading.Event(), []
+
+    def body(k):
+        seed, want = (7, want7) if k % 2 == 0 else (9, want9)
+        for _ in range(3000):
+            if not np.array_equal(model.glorot(600, 30, 20, seed=seed), want):
+                bad.append(k)
+                return
+
+    def noise():
+        while not stop.is_set():
+            libc.srand(123)
+            libc.rand()
+
+    th = [threading.Thread(target=body, args=(k,)) for k in range(8)]
+    nz = threading.Thread(target=noise)
+    nz.start()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stop.set()
+    nz.join()
+    assert not bad, bad
+
+
 def test_glorot_and_masks_replay_reference_rng(oracle):
     """the host RNG in the product must reproduce the reference's stream: same seed ->
     same initial weights as gcn-seq, same dropout decisions in HOST_MASKS mode"""

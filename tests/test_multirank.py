@@ -148,8 +148,8 @@ def test_logical_ranks_as_threads_match_single_gpu(name, world, dropout, run_asy
     hidden = 128 if name.startswith("reddit") else 16
     ds = datagen.make_dataset(name)
     got = run_ranks(ds, world, flags, epochs, hidden, dropout, run_async=bool(run_async))
-    for tr in got["traces"][1:]:
-        assert np.array_equal(tr, got["traces"][0])          # every rank reads the same all-reduced scalars
+    for r, tr in enumerate(got["traces"][1:], 1):            # every rank reads the same all-reduced scalars
+        assert np.array_equal(tr, got["traces"][0]), (r, np.argwhere(tr != got["traces"][0]).tolist(), tr.tolist(), got["traces"][0].tolist())
     m = HipGCNModel(ds, seed=4, flags=flags & (1 | 2), hidden_dim=hidden, dropout=dropout, epochs=epochs)
     want = np.array([m.train_epoch() + m.eval(2) for _ in range(epochs)], np.float32)
     wtest = m.eval(3)
