@@ -211,7 +211,10 @@ __device__ __forceinline__ void bx_ldsread16(bf16x8 &dst, uint32_t addr) {
 //    group are read while this group's MFMAs run, the barrier (W k-step h+1 landed, ring slot free) sits between G1 and G2.
 // The last round of a workgroup may have fewer than 8 row blocks: waves without one run the same instruction stream on the
 // share's last row and store nothing (the counted waits need every wave to issue the same operations).
-// ABL (timing experiments only, wrong results): 1 no X loads, 2 no W DMA, 4 no split, 8 no W LDS reads
+// ABL (timing experiments of tools/gemm_bf16x3.hip only; 1-8, 32 and 64 give wrong results): 1 no X loads, 2 no W DMA, 4 no split,
+// 8 no W LDS reads, 16 every wait vmcnt(0), 32 keep words loaded but not applied, 64 applied but not loaded, 128 keep word after the
+// X loads (+9 us), 256 X loads ahead of the chunk's W pieces (+40 us), 512 X loads at the top of the chunk (+9..14 us).
+// PD_: W k-steps in flight (6..9 measure the same).
 // NW = waves per workgroup.  8: the whole-chip form (two waves per SIMD fill the CU's register file).  4 (round 5, for a context
 // that runs BESIDE another stream's kernels — the validation lane): one wave per SIMD and half the register file, so that a
 // gather-bound kernel's waves can be resident on the same CU at the same time.  The eight-wave workgroup needs an EMPTY CU to
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         const int h0 = 2 * g;
         const uint32_t wa = window(Ra, t, c);
         // ================= half-item (g, 0): MFMAs on P0; raw[g]'s second half -> P1; raw[g+2] issued
+        if (ABL & 512) load_raw(Rc, t2, c2);                     // (experiment: the X loads at the top of the chunk)
         read_b(Bn, h0, BxN<1>());
         __builtin_amdgcn_sched_barrier(0);
         split_pair(P1, Ra, wa, 1, 0);
@@ -467,6 +471,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
         // half-item h0-1: its ring slot takes k-step h0+BX_PD
         BX_WAIT_W();
         if (ABL & 256) { load_raw(Rc, t2, c2); issue_b(h0 + PD); }      // (experiment: the X loads ahead of the W pieces)
+        else if (ABL & 512) issue_b(h0 + PD);
         else { issue_b(h0 + PD); load_raw(Rc, t2, c2); }
         read_b(Bn, h0, BxN<3>());
         __builtin_amdgcn_sched_barrier(0);

@@ -171,6 +171,10 @@ int main(int argc, char **argv) {
         printf("  dropout, full (again):        %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0><<<n_cu, 512>>>(a); }));
         printf("  X loads ahead of the W pieces: dropout %.4f, none %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 256><<<n_cu, 512>>>(a); }),
                time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 256><<<n_cu, 512>>>(a); }));
+        for (int rep = 0; rep < 2; rep++)
+            printf("  X loads at the top of the chunk: dropout %.4f (default %.4f), none %.4f (default %.4f) ms\n",
+                   time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 512><<<n_cu, 512>>>(a); }), time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 0><<<n_cu, 512>>>(a); }),
+                   time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 512><<<n_cu, 512>>>(a); }), time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0><<<n_cu, 512>>>(a); }));
         printf("  dropout, mask not applied:    %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 32><<<n_cu, 512>>>(a); }));
         printf("  dropout, keep words not read: %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 64><<<n_cu, 512>>>(a); }));
         printf("  dropout, neither:             %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<true, 6, 96><<<n_cu, 512>>>(a); }));
