@@ -20,10 +20,18 @@ HOBJ = $(patsubst $(PKG)/host/%.cpp,$(OBJDIR)/host_%.o,$(HSRC))
 
 all: kernels host oracle
 
+# the flavour the objects were compiled in: switching EXPERIMENTS rebuilds them (make does not see a changed flag by itself,
+# and a library mixing the two flavours reports gcnhip_experiments() of whichever ctx.hip it happened to keep)
+FLAVOUR = $(OBJDIR)/.flavour
+$(FLAVOUR): FORCE
+	@mkdir -p $(OBJDIR)
+	@echo '$(EXPFLAG)' | cmp -s - $@ || echo '$(EXPFLAG)' > $@
+FORCE:
+
 kernels: $(LIBDIR)/libgcnhip.so
 host: $(LIBDIR)/libgcnhost.so $(BINDIR)/gcn-hip
 
-$(OBJDIR)/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) include/gcnhip.h
+$(OBJDIR)/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) include/gcnhip.h $(FLAVOUR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -31,7 +39,7 @@ $(LIBDIR)/libgcnhip.so: $(KOBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(KOBJ) -o $@
 
-$(OBJDIR)/host_%.o: $(PKG)/host/%.cpp $(wildcard $(PKG)/host/*.h) include/gcnhip.h include/gcnhost.h
+$(OBJDIR)/host_%.o: $(PKG)/host/%.cpp $(wildcard $(PKG)/host/*.h) include/gcnhip.h include/gcnhost.h $(FLAVOUR)
 	@mkdir -p $(OBJDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
@@ -41,7 +49,7 @@ $(LIBDIR)/libgcnhost.so: $(HOBJ) $(LIBDIR)/libgcnhip.so
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -o $@
 
 # the program links the host objects directly (libgcnhost.so exports only its C entry points)
-$(BINDIR)/gcn-hip: $(PKG)/host/main.cpp $(HOBJ) $(LIBDIR)/libgcnhip.so
+$(BINDIR)/gcn-hip: $(PKG)/host/main.cpp $(HOBJ) $(LIBDIR)/libgcnhip.so $(FLAVOUR)
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) $< $(HOBJ) -L$(LIBDIR) -lgcnhip -L/opt/rocm/lib -lrccl -lamdhip64 -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib -o $@
