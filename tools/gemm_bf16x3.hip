@@ -3,6 +3,10 @@
 // (m = 232 965, K = 602, p = 128; reference: SparseMatmul::forward, /root/reference/src/seq/module.cpp:47-61):
 // time per launch (HIP events, back to back) and the error of both against a float64 product on sampled rows, in units of
 // eps_f32 * sum_k |x_k w_k| (the bound the parity tests use is 8 of those units).
+// Also here: the template ablations of the forward (which stream costs what), the dropout ablations that led to the chunk-major
+// keep words, the W prefetch distance, and the load-ORDER experiments of both kernels (runs rotated: the clock drifts with what ran
+// before) — docs/NOTEBOOK_r5.md §2.  The bf16x3 kernels read keep words chunk-major; the tool derives them from the flat bits the
+// f32 kernels and the float64 check use.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icuda_gcn_amd/csrc tools/gemm_bf16x3.hip -o build/gemm_bf16x3
 //   build/gemm_bf16x3 [m] [K] [iters]
 #include <hip/hip_runtime.h>
