@@ -31,7 +31,7 @@ FORCE:
 kernels: $(LIBDIR)/libgcnhip.so
 host: $(LIBDIR)/libgcnhost.so $(BINDIR)/gcn-hip
 
-$(OBJDIR)/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) include/gcnhip.h $(FLAVOUR)
+$(OBJDIR)/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h) $(FLAVOUR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -39,7 +39,7 @@ $(LIBDIR)/libgcnhip.so: $(KOBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(KOBJ) -o $@
 
-$(OBJDIR)/host_%.o: $(PKG)/host/%.cpp $(wildcard $(PKG)/host/*.h) include/gcnhip.h include/gcnhost.h $(FLAVOUR)
+$(OBJDIR)/host_%.o: $(PKG)/host/%.cpp $(wildcard $(PKG)/host/*.h) $(wildcard include/*.h) $(FLAVOUR)
 	@mkdir -p $(OBJDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 

@@ -14,13 +14,14 @@ N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
 RANK / WORLD_SIZE are then set), or this file does: a parent that has not
 touched the GPU (no torch import, no native library) starts the N ranks with
-torch.distributed.run as CHILD processes, relays rank 0's JSON line and exits
-with their return code (a hung child group is killed after GCN_BENCH_TIMEOUT
-seconds).  It first runs the RCCL self-test (all-gather, all-reduce, halo
-send/receive, split communicator) as a throw-away group of ranks, then the plain
-one-stream schedule, then tries the two overlapped schedules (exchanges on their
-own stream beside the locally owned columns' aggregation; validation forward on
-a second stream) as fresh children, and prints the fastest valid line.
+torch.distributed.run as CHILD processes under ONE overall deadline
+(GCN_BENCH_DEADLINE, default 420 s).  It first runs the RCCL self-test
+(all-gather, all-reduce, halo send/receive, split communicator) as a throw-away
+group of ranks, then the plain one-stream schedule, whose JSON line it prints at
+once; then, while enough of the deadline is left, the two overlapped schedules
+(exchanges on their own stream beside the locally owned columns' aggregation;
+validation forward on a second stream) as fresh children, and prints the fastest
+valid line last.
 
 Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
   * `value` / `ms_per_step`: exactly K epochs, barrier + synchronize on both sides, max over ranks,
@@ -52,11 +53,11 @@ L2_AGG_GBPS = 34500.0         # "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggreg
 MALL_GATHER_GBPS = 8600.0     # "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache: 33.5 GB/s per CU = 8.6 TB/s
 F32_MFMA_PEAK_TF = 157.3      # "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 64 FLOP/clk/SIMD at 2.4 GHz
 BF16_MFMA_PEAK_TF = 2500.0    # "Peak BF16/FP16 MFMA": ~2.5 PF dense
-PMC_FILES = ["r05_graphsum_pmc.json", "r04_graphsum_pmc.json", "r03_graphsum_pmc.json", "r02_graphsum_pmc.json"]           # newest first (profiles/)
-PMC_RMAT_FILES = ["r05_graphsum_pmc_rmat.json", "r04_graphsum_pmc_rmat.json", "r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
+PMC_FILES = ["r06_graphsum_pmc.json", "r05_graphsum_pmc.json", "r04_graphsum_pmc.json", "r03_graphsum_pmc.json", "r02_graphsum_pmc.json"]           # newest first (profiles/)
+PMC_RMAT_FILES = ["r06_graphsum_pmc_rmat.json", "r05_graphsum_pmc_rmat.json", "r04_graphsum_pmc_rmat.json", "r03_graphsum_pmc_rmat.json", "r02_graphsum_pmc_rmat.json"]
 PMC_RMAT22_FILES = ["r04_graphsum_pmc_rmat22.json"]                      # the in-model launch of BASELINE configs[4] (scale 22, 2 GiB table)
-GATHER_PEAK_FILES = ["r05_gather_peak.json", "r04_gather_peak.json"]     # measured ceiling of the cache-regime gather (tools/gather_peak.py)
-GEMM_PMC_FILES = ["r05_gemm_bf16x3_pmc.json", "r05_gemm_pmc.json"]                                   # SQ_VALU_MFMA_BUSY_CYCLES etc. of the dense first-layer kernels (tools/pmc_gemm.sh)
+GATHER_PEAK_FILES = ["r06_gather_peak.json", "r05_gather_peak.json", "r04_gather_peak.json"]     # measured ceiling of the cache-regime gather (tools/gather_peak.py)
+GEMM_PMC_FILES = ["r06_gemm_bf16x3_pmc.json", "r05_gemm_bf16x3_pmc.json", "r05_gemm_pmc.json"]                                   # SQ_VALU_MFMA_BUSY_CYCLES etc. of the dense first-layer kernels (tools/pmc_gemm.sh)
 STRUCTURE_LEGS = [("value_structure_free", "reddit-syn-h0"), ("value_h03", "reddit-syn-h03"), ("value_zipf", "reddit-syn-zipf")]
 GS_KERNEL = "graphsum_vec_kernel<16, 4, true, false>"       # the hidden-width launch on a cache-resident table (graphsum.hip, launch_vec)
 GS_KERNEL_HBM = "graphsum_vec_kernel<16, 2, true, false>"   # ... past the Infinity Cache (two row loads in flight)
@@ -169,42 +170,71 @@ def launch_ranks(n_gpus, argv):
     """Parent of an N-rank run.  Runs before torch or any native library is imported: this process never
     initialises the GPU, it only starts children, so nothing here is an exec from a GPU process.
 
-    Order (each step a fresh group of children, so that a hang or failure of a later, less proven step cannot take an
-    earlier result with it):
+    ONE overall deadline (GCN_BENCH_DEADLINE seconds from now, default 420) covers everything below; every step takes its
+    time limit from what is left and an OPTIONAL step is skipped when less than its own estimate remains, so the whole
+    call ends inside the deadline whatever hangs.  Order (each step a fresh group of children, so that a hang or failure
+    of a later, less proven step cannot take an earlier result with it):
       0. the RCCL self-test (gcnhost_rccl_selftest_world: all-gather, all-reduce, the halo exchange by grouped
-         ncclSend/ncclRecv, the split communicator) with a short deadline.  Passed: the model runs may pick the exchange
-         per graph (HIPGCN_EXCHANGE=auto).  Failed or hung: they are pinned to the in-place all-gather.
-      1. the plain schedule: everything on one stream.  Its line is the safe result.  If it fails with a per-graph
-         exchange it is retried once pinned to the all-gather.
+         ncclSend/ncclRecv, the split communicator) with a short limit.  Passed: the model runs may pick the exchange
+         per graph (HIPGCN_EXCHANGE=auto).  Failed, hung or skipped: they are pinned to the in-place all-gather.
+      1. the plain schedule: everything on one stream.  Its JSON line is the safe result and is PRINTED THE MOMENT IT
+         EXISTS (flushed), before anything optional is started.  If it fails with a per-graph exchange it is retried once
+         pinned to the all-gather — if the time left allows.
       2. unless the caller chose a schedule: `--overlap on` (exchanges on their own stream beside the aggregation of the
          locally owned columns), then `--eval-lane on` (validation forward on a second stream and communicator).
-    The fastest valid line is printed; `config.schedule` says which, the others are kept in `other_schedules`."""
+    When an optional schedule beat the plain one, the best line is printed LAST (a reader that keeps the last JSON line
+    gets the best valid result, one that keeps the first gets the safe one); `config.schedule` says which and
+    `other_schedules` lists the rest, with what was skipped or killed and why."""
+    t_start = time.monotonic()
+    deadline = t_start + float(os.environ.get("GCN_BENCH_DEADLINE", "420"))
+    margin = 5.0                                     # to kill a group, collect its output and print
+
+    def left():
+        return deadline - time.monotonic() - margin
     timeout = float(os.environ.get("GCN_BENCH_TIMEOUT", "600"))
     t_try = float(os.environ.get("GCN_BENCH_LANE_TIMEOUT", "300"))
     argv = list(argv)
     env = {}
+    # what a plain run needs at the very least (import torch on a fresh box, the dataset, the model build, the epochs): never
+    # spend on the self-test what would leave the safe result less than this
+    plain_estimate = float(os.environ.get("GCN_BENCH_PLAIN_ESTIMATE", "150"))
     if "HIPGCN_EXCHANGE" not in os.environ and os.environ.get("GCN_BENCH_TRANSPORT") != "host":
-        rc0, line0 = _run_ranks(n_gpus, ["--gpus", str(n_gpus), "--selftest"], float(os.environ.get("GCN_BENCH_SELFTEST_TIMEOUT", "180")))
-        selftest_ok = rc0 == 0
+        t_self = min(float(os.environ.get("GCN_BENCH_SELFTEST_TIMEOUT", "180")), left() - plain_estimate)
+        if t_self >= 30:
+            rc0, line0 = _run_ranks(n_gpus, ["--gpus", str(n_gpus), "--selftest"], t_self)
+            selftest_ok = rc0 == 0
+            log("RCCL self-test", "passed: exchange decided per graph" if selftest_ok else f"FAILED (rc {rc0}): every exchange pinned to the all-gather")
+        else:
+            selftest_ok = False
+            log(f"RCCL self-test skipped ({left():.0f} s left of the deadline): every exchange pinned to the all-gather")
         env["HIPGCN_EXCHANGE"] = "auto" if selftest_ok else "allgather"
-        log("RCCL self-test", "passed: exchange decided per graph" if selftest_ok else f"FAILED (rc {rc0}): every exchange pinned to the all-gather")
     chosen = "--eval-lane" in argv or "--overlap" in argv
     base = argv if chosen else argv + ["--eval-lane", "off", "--overlap", "off"]
-    rc, line = _run_ranks(n_gpus, base, timeout, env)
-    if rc != 0 and env.get("HIPGCN_EXCHANGE") == "auto":
+    t0 = time.monotonic()
+    rc, line = _run_ranks(n_gpus, base, max(10.0, min(timeout, left())), env)
+    t_plain = time.monotonic() - t0
+    if rc != 0 and env.get("HIPGCN_EXCHANGE") == "auto" and left() >= min(plain_estimate, 1.2 * t_plain):
         log(f"run failed (rc {rc}) with a per-graph exchange: retrying pinned to the all-gather")
         env["HIPGCN_EXCHANGE"] = "allgather"
-        rc, line = _run_ranks(n_gpus, base, timeout, env)
+        t0 = time.monotonic()
+        rc, line = _run_ranks(n_gpus, base, max(10.0, min(timeout, left())), env)
+        t_plain = time.monotonic() - t0
     if rc != 0:
         log(f"plain schedule failed (rc {rc})")
         return rc
+    print(line, flush=True)                          # the safe result: out before any optional step starts
     if chosen:
-        print(line, flush=True)
         return 0
     lines = [json.loads(line)]
     others = []
+    # an optional schedule runs what the plain one ran without the CPU baseline: its own duration + slack is the estimate
+    estimate = 1.2 * t_plain
     for extra in (["--eval-lane", "off", "--overlap", "on"], ["--eval-lane", "on", "--overlap", "off"]):
-        rc2, line2 = _run_ranks(n_gpus, argv + extra + ["--no-cpu-baseline"], t_try, env)
+        if left() < estimate:
+            log(f"schedule {extra} skipped: {left():.0f} s left of the deadline, a run needs ~{estimate:.0f} s")
+            others.append({"schedule": " ".join(extra), "value": None, "skipped": f"{left():.0f} s left, ~{estimate:.0f} s needed"})
+            continue
+        rc2, line2 = _run_ranks(n_gpus, argv + extra + ["--no-cpu-baseline"], min(t_try, left()), env)
         if rc2 == 0:
             lines.append(json.loads(line2))
         else:
@@ -217,7 +247,9 @@ def launch_ranks(n_gpus, argv):
     if best.get("cpu_baseline") is None:
         best["cpu_baseline"] = lines[0].get("cpu_baseline")      # timed once, in the first group (same box, same workload)
     best["other_schedules"] = others
-    print(json.dumps(best), flush=True)
+    best["launcher"] = {"deadline_s": deadline - t_start, "used_s": round(time.monotonic() - t_start, 1), "plain_run_s": round(t_plain, 1)}
+    if best is not lines[0] or others:
+        print(json.dumps(best), flush=True)          # last line = best valid line (the plain one again, now with `other_schedules`)
     return 0
 
 
@@ -297,7 +329,9 @@ def _pmc(files, kernel, avg_launch_ms=None, tol=0.10):
     """PMC summary of exactly `kernel` (full name with template arguments) from the newest committed profile that has it,
     accepted only when it describes the launch that was just timed: the profile records the kernel's median duration under
     the profiler, and a file whose duration differs from the HIP-event average of this run by more than `tol` is refused
-    (a kernel change would otherwise leave the roofline computed from stale fabric bytes).  Returns (entry, source, why_not)."""
+    (a kernel change would otherwise leave the roofline computed from stale fabric bytes).  A file taken on another version of
+    the kernel's source (`_meta.sources`, cuda_gcn_amd/provenance.py) is still quoted, with `stale: true`.
+    Returns (entry, source, why_not)."""
     why = "no committed PMC profile names this kernel"
     for f in files:
         p = os.path.join(ROOT, "profiles", f)
@@ -313,7 +347,10 @@ def _pmc(files, kernel, avg_launch_ms=None, tol=0.10):
             if dev > tol:
                 why = f"profiles/{f}: {kernel} took {ref_us:.0f} us under the profiler, {1e3 * avg_launch_ms:.0f} us here ({100 * dev:.0f} % apart): refused"
                 continue
-        k = dict(k, commit=doc.get("_meta", {}).get("commit"), duration_checked=bool(avg_launch_ms is not None and ref_us))
+        from cuda_gcn_amd.provenance import stale_reason
+        why_stale = stale_reason(doc.get("_meta"))      # the kernel source the counters were taken on vs this tree's
+        k = dict(k, commit=doc.get("_meta", {}).get("commit"), duration_checked=bool(avg_launch_ms is not None and ref_us),
+                 stale=why_stale is not None, stale_why=why_stale)
         return k, "profiles/" + f, None
     return None, None, why
 
@@ -451,7 +488,10 @@ def dense_leg(ds, hidden, device, iters=10):
     for fpmc in GEMM_PMC_FILES:
         pth = os.path.join(ROOT, "profiles", fpmc)
         if os.path.exists(pth):
-            pmc = {"source": "profiles/" + fpmc, "kernels": json.load(open(pth))}
+            from cuda_gcn_amd.provenance import stale_reason
+            doc = json.load(open(pth))
+            why = stale_reason(doc.get("_meta"))
+            pmc = {"source": "profiles/" + fpmc, "stale": why is not None, "stale_why": why, "kernels": doc}
             break
     return {"bound": "mfma", "method": method, "pipe": "bf16 MFMA (three-plane split of f32 operands, f32 accumulate)" if method == "bf16x3" else "f32 MFMA (exact)",
             "peak": peak, "peak_f32_mfma": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "flop_per_launch": flop,
@@ -496,6 +536,9 @@ def main():
         os.environ.setdefault("HIPGCN_SCHEDULE", args.pin_schedule)
     if args.no_extras:
         args.no_cli = True
+    hang = os.environ.get("GCN_BENCH_TEST_HANG")      # tests only: "overlap" / "lane" make the children of that optional schedule sleep
+    if hang and "WORLD_SIZE" in os.environ and ((hang == "overlap" and args.overlap == "on") or (hang == "lane" and args.eval_lane == "on")):
+        time.sleep(100000)
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -728,7 +771,14 @@ def main():
                     "what": "B_gs(d) / HIP-event launch time against the HBM peak" +
                             ("; the table is Infinity-Cache resident, so this may exceed 1 (cache-served); no PMC profile accepted for the "
                              "two-resource cache bound: " + str(pmc_why) if cache_resident else "")}
-        roof.update({"traffic_source": pmc_src if pmc else pmc_why, "traffic_commit": pmc.get("commit") if pmc else None,
+        # stored numbers quoted beside this run's live timing (fabric bytes, the measured gather ceiling): were they taken on THIS
+        # tree's kernel source?  (`_meta.sources` of the file against the sha256 of the sources here, cuda_gcn_amd/provenance.py)
+        from cuda_gcn_amd.provenance import stale_reason
+        pmc_stale = pmc.get("stale_why") if pmc else None
+        ceil_stale = stale_reason(ceil_doc.get("_meta")) if ceil_doc else None
+        roof.update({"stale": bool(pmc_stale or ceil_stale), "traffic_stale": bool(pmc_stale), "traffic_stale_why": pmc_stale,
+                     "peak_measured_gather_stale": bool(ceil_stale), "peak_measured_gather_stale_why": ceil_stale,
+                     "traffic_source": pmc_src if pmc else pmc_why, "traffic_commit": pmc.get("commit") if pmc else None,
                      "traffic_profile_duration_us": pmc.get("median_duration_us_under_pmc") if pmc else None,
                      "bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * avg_s, "launches": n_wide,
                      "table_MB": round(table_mb, 1),
@@ -811,6 +861,23 @@ def main():
         out["value_reference_op_order_all_rows"] = args.steps / d3
         m3.close()
         log(f"reference op order, all rows: {args.steps / d3:.2f} epochs/s")
+    dense_x = ds["f_indices"] is not None and ds["f_indptr"][1] == ds["input_dim"]
+    if extras and args.hidden == 128 and dense_x and not args.no_row_groups and "bf16x3" in first_layer_method(ds, args.hidden):
+        # ... and with every dense product on the exact-f32 MFMA kernels (HIPGCN_GEMM=f32: the f32 pipe, 1/16 of the bf16 rate;
+        # sequential f32 multiply-add like module.cpp:11-77) — the same model, schedule and timed region as the headline
+        os.environ["HIPGCN_GEMM"] = "f32"
+        try:
+            m4, _ = build(base_flags)
+            m4.run_epochs(args.warmup, want_trace=False)
+            d4, _tr = timed_region(m4, args.steps)
+            out["value_f32_products"] = args.steps / d4
+            m4.close()
+            log(f"f32-MFMA products (HIPGCN_GEMM=f32): {args.steps / d4:.2f} epochs/s")
+        except Exception as e:
+            out["value_f32_products"] = None
+            out["value_f32_products_error"] = repr(e)
+        finally:
+            del os.environ["HIPGCN_GEMM"]
     if extras and not args.no_structure_legs and args.dataset == "reddit-syn" and not args.no_row_groups:
         # The headline graph has planted communities (the labels).  The same shape with other structure, each on the product's default
         # path with the row schedule it times fastest at load: no planted structure at all (SURVEY 8(d)'s literal Chung-Lu graph),
@@ -846,7 +913,7 @@ def main():
                 legs[name] = {"error": repr(e)}
                 out[key] = None
         out["structure_legs"] = legs
-    if extras and args.hidden > 64 and ds["f_indices"] is not None and ds["f_indptr"][1] == ds["input_dim"]:
+    if extras and args.hidden > 64 and dense_x:
         try:
             rd = dense_leg(ds, args.hidden, device)
             # The same products inside the epoch, from the per-op HIP-event timers of this run (forward: the training and the
@@ -862,6 +929,17 @@ def main():
                                   "weight_gradient_frac_of_pipe_peak": mult * bw_tf / rd["peak"],
                                   "source": "breakdown_ms_per_epoch of this run (one-stream timers pass; every launch of the op included)"}
                 rd["frac_in_epoch"] = min(rd["in_epoch"]["forward_frac_of_pipe_peak"], rd["in_epoch"]["weight_gradient_frac_of_pipe_peak"])
+                # `frac` = the products as the epoch runs them; the back-to-back legs (one MFMA-bound launch repeated: the socket sits
+                # at its power cap and the shader clock drops) under their own name
+                rd["frac_power_capped"] = rd["frac"]
+                rd["frac"] = rd["frac_in_epoch"]
+                rd["frac_source"] = "in_epoch (per-op HIP-event timers of this run); frac_power_capped = the slowest back-to-back leg"
+            # both floors of one product: the MFMA pipe it issues on, and its compulsory bytes (X once, W1, the output) at the HBM peak
+            n_, f_ = ds["num_nodes"], ds["input_dim"]
+            bytes_ = 4.0 * (n_ * f_ + f_ * args.hidden + n_ * args.hidden)
+            rd["floors_ms"] = {"mfma_pipe": 1e3 * rd["flop_per_launch"] * (6 if rd["method"] == "bf16x3" else 1) / (rd["peak"] * 1e12),
+                               "hbm": 1e3 * bytes_ / (HBM_PEAK_GBPS * 1e9), "hbm_bytes": bytes_,
+                               "what": "per product launch: MFMA flops issued / pipe peak; (X + W1 + output) bytes / 8 TB/s"}
             out["roofline_dense"] = rd
         except Exception as e:
             out["roofline_dense"] = {"error": repr(e)}
@@ -904,7 +982,14 @@ def main():
             out["cli"] = {"error": repr(e)}
     if rank == 0:
         # rank 0, any N: the CPU path on this box's host cores (the other ranks wait at the barrier below)
-        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(ds, args.hidden)
+        # (SURVEY 8d / the bench contract: at N = 1; with several ranks only on request, GCN_BENCH_CPU_BASELINE_ANY_N=1)
+        if args.no_cpu_baseline or (world > 1 and not os.environ.get("GCN_BENCH_CPU_BASELINE_ANY_N")):
+            out["cpu_baseline"] = None
+        else:
+            try:
+                out["cpu_baseline"] = cpu_baseline(ds, args.hidden)
+            except Exception as e:      # never lose the finished line to the baseline
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

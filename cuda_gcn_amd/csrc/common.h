@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
-#include "../../include/gcnhip.h"
+#include "../../include/gcnhip_driver.h"
 #include "../../include/gcnhip_experimental.h"
 
 #define GCNHIP_TRY(expr)                                   \

@@ -980,9 +980,10 @@ static int graphsum_impl(gcnhip_ctx *c, const gcnhip_graph *g, const float *in, 
     }
     const int gl = c->opt.gs_l;                             // narrower column slices than 64 floats (8: 32 floats, 4: 16 floats), round 5
     if (in_bf) {
-    } else if (vec && !loss && (gl == 8 || gl == 4) && dim % (gl * 4) == 0 && dim / (gl * 4) > 1 && 8 % (dim / (gl * 4)) == 0) {
+    } else if (vec && !loss && (gl == 8 || (gl == 4 && !pos_bits)) && dim % (gl * 4) == 0 && dim / (gl * 4) > 1 && 8 % (dim / (gl * 4)) == 0) {
         // More slices = a smaller share of the table per XCD's L2 (what a structure-free graph's hub rows need) against more
         // re-reads of the index stream and shorter requests.  Measured per graph (tools/exp_structure.py); never the default.
+        // (16-float slices hold half a mask word per lane group: with pos_bits they fall through to the 64-float slices below)
         if (gl == 8) launch_vec<8>(a, xb, c); else launch_vec<4>(a, xb, c);
     } else if (vec && dim % 64 == 0 && 8 % (dim / 64) == 0) {
         // rows of whole 128-byte lines: 64-float (two-line) column slices, one per XCD group, so each XCD's L2 holds

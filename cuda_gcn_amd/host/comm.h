@@ -9,7 +9,7 @@
 #include <cstddef>
 #include <memory>
 #include <vector>
-#include "gcnhip.h"
+#include "gcnhip_driver.h"
 #include "partition.h"
 #include "timer.h"
 

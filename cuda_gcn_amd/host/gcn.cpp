@@ -143,7 +143,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
     //  result is not needed before the schedules are timed)
     std::future<StructureGroups> groups_search;
     if (!(flags & HIPGCN_NO_ROW_GROUPS) && !labels_assortative && n_local >= 4096 && opt.structure_groups &&
-        (opt.schedule < 0 || opt.schedule == 3))
+        (opt.schedule < 0 || opt.schedule == 3 || opt.slice_tuning))   // the slice rule reads the groups whatever picked the schedule
         groups_search = std::async(std::launch::async, [&gp, &gi, N]() { return structure_groups(gp.data(), gi.data(), N); });
     struct JoinGroups {                       // never leave the thread running over a dataset that is being torn down
         std::future<StructureGroups> &f;
@@ -444,6 +444,11 @@ void HipGCN::choose_slice_width() {
     slice_floats = 64;
     int cur_gl = 0;
     GCNHIP_CHECK(gcnhip_ctx_get_option(env.ctx, "gs_l", &cur_gl));
+    if (cur_gl == 8 || cur_gl == 4) {                      // preset (GCNHIP_GS_L): report what the launches will use; the lane mirrors it
+        const int f = cur_gl * 4;
+        if (H % f == 0 && H / f > 1 && H / f <= 8 && 8 % (H / f) == 0) slice_floats = f;
+        return;
+    }
     if (cur_gl != 0 || !opt_.slice_tuning || H % 64 != 0 || H / 32 > 8 || 8 % (H / 32) != 0) return;
     if ((size_t)N * H * sizeof(float) > ((size_t)256 << 20)) return;                 // HBM regime: wide
     // (the groups the schedule candidates were built from — labels when they are communities of the graph, else what the
@@ -741,7 +746,7 @@ void HipGCN::build_eval_lane() {
     HipSparseMatmul *lane_sm = nullptr;
     GCNHIP_CHECK(gcnhip_ctx_create(&L.env.ctx, /*device of the main context*/ device_, nullptr));
     GCNHIP_CHECK(gcnhip_ctx_set_corun(L.env.ctx, 1));           // the lane's kernels share the chip with the training pass
-    if (slice_floats == 32) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gs_l", 8));   // as tuned on the training context
+    if (slice_floats == 32 || slice_floats == 16) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gs_l", slice_floats / 4));   // as on the training context
     if (opt_.gemm >= 0) GCNHIP_CHECK(gcnhip_ctx_set_option(L.env.ctx, "gemm_bf16x3", opt_.gemm ? 2 : 0));
     L.timers.reset(new DeviceTimers(L.env.ctx));
     L.timers->enabled = timers->enabled;

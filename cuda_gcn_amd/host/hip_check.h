@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
-#include "gcnhip.h"
+#include "gcnhip_driver.h"
 
 struct GcnHipFailure : std::runtime_error {
     int code;

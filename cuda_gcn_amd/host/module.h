@@ -13,7 +13,7 @@
 #include <vector>
 #include <cstdint>
 #include "comm.h"
-#include "gcnhip.h"
+#include "gcnhip_driver.h"
 #include "gcnhip_experimental.h"   // the opt-in packed-dH1 path (HIPGCN_PACKED_DH1, experiments build only)
 #include "timer.h"
 #include "variable.h"

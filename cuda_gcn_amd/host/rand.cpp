@@ -9,7 +9,19 @@
 // weights than its peers (found in round 5: rank traces differing in the L2 term from epoch 0 on, a few runs in a hundred).
 // glibc's reentrant interface on a private 128-byte state is the same generator (TYPE_3, the default of srand / rand):
 // the same two numbers for the same t, whoever else is drawing.
+#ifndef __GLIBC__
+#include <mutex>
+static std::mutex libc_rand_mutex;       // other libcs: srand / rand under a lock (their numbers are that libc's, as the reference's would be)
+#endif
 void HostRng::seed_time(unsigned t) {
+#ifndef __GLIBC__
+    std::lock_guard<std::mutex> hold(libc_rand_mutex);
+    srand(t);
+    int x = 0, y = 0;
+    while (x == 0 || y == 0) { x = rand(); y = rand(); }
+    s[0] = (uint64_t)x;
+    s[1] = (uint64_t)y;
+#else
     struct random_data rd;
     char state[128];
     memset(&rd, 0, sizeof rd);
@@ -22,6 +34,7 @@ void HostRng::seed_time(unsigned t) {
     }
     s[0] = (uint64_t)x;
     s[1] = (uint64_t)y;
+#endif
 }
 
 uint32_t HostRng::next() {

@@ -5,7 +5,7 @@
 // resolved lazily (one synchronisation when a total is read).
 #pragma once
 #include <vector>
-#include "gcnhip.h"
+#include "gcnhip_driver.h"
 
 typedef enum {
     TMR_TRAIN = 0, TMR_TEST, TMR_MATMUL_FW, TMR_MATMUL_BW, TMR_SPMATMUL_FW, TMR_SPMATMUL_BW,

@@ -3,7 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <vector>
-#include "gcnhip.h"
+#include "gcnhip_driver.h"
 #include "partition.h"
 #include "rand.h"
 

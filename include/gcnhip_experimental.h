@@ -7,7 +7,7 @@
  */
 #ifndef GCNHIP_EXPERIMENTAL_H
 #define GCNHIP_EXPERIMENTAL_H
-#include "gcnhip.h"
+#include "gcnhip_driver.h"
 #ifdef __cplusplus
 extern "C" {
 #endif

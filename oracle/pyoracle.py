@@ -49,6 +49,9 @@ def _i(a):
     return np.ascontiguousarray(a, np.int32)
 
 
+_LIB = None
+
+
 class Oracle:
     """numpy front end of gcn_oracle.h"""
 
@@ -56,7 +59,8 @@ class Oracle:
         path = path or os.environ.get("GCN_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")   # GCN_ORACLE_LIB: the sanitizer build
         if not os.path.exists(path):
             build()
-        self.lib = L = C.CDLL(path)
+        global _LIB
+        self.lib = L = _LIB = C.CDLL(path)      # _LIB: tests/conftest.py resets the checker's process-wide switches after every test
         L.or_rand_next.restype = C.c_uint32
         L.or_rand_set_state.argtypes = [C.c_uint64, C.c_uint64]
         L.or_rand_get_state.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host preparation (full-size BASELINE configs[4] under partitioning); runs only with GCN_RUN_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("GCN_RUN_SLOW"):
+        return
+    skip = pytest.mark.skip(reason="slow: set GCN_RUN_SLOW=1 (run once per round, record under profiles/)")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")
@@ -17,6 +27,17 @@ def oracle():
     """the CPU oracle (oracle/liboracle.so), built on demand"""
     from oracle.pyoracle import Oracle
     return Oracle()
+
+
+@pytest.fixture(autouse=True)
+def _oracle_switches_do_not_leak():
+    """or_set_wide_degree is a process-wide switch of the checker (oracle/gcn_oracle.c): whatever a test did with it — and
+    however it ended — the next test starts from the reference's int product."""
+    yield
+    mod = sys.modules.get("oracle.pyoracle")
+    lib = getattr(mod, "_LIB", None) if mod else None
+    if lib is not None:
+        lib.or_set_wide_degree(0)
 
 
 @pytest.fixture(scope="session")

@@ -52,6 +52,110 @@ def test_launcher_does_not_touch_gpu_before_spawning():
     assert not any("torch" in ln or "cuda_gcn_amd" in ln or "numpy" in ln for ln in top_level_imports), top_level_imports
 
 
+
+# ---- the N > 1 launcher's deadline logic, without a GPU: _run_ranks replaced by a stand-in (verdict r05 item 3)
+def _fake_line(value, schedule):
+    return json.dumps({"metric": "epochs_per_sec", "value": value, "ms_per_step": 1e3 / value, "config": {"schedule": schedule}, "cpu_baseline": None})
+
+
+def _launcher(monkeypatch, capsys, behaviour, env):
+    """run bench.launch_ranks(8, ...) with _run_ranks(n, extra, timeout, env) -> behaviour(extra, timeout); returns (rc, stdout JSON lines, calls)"""
+    import importlib
+    import time
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    def fake(n_gpus, extra, timeout, env=None):
+        calls.append((list(extra), timeout, dict(env or {})))
+        return behaviour(extra, timeout)
+    monkeypatch.setattr(bench, "_run_ranks", fake)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("HIPGCN_EXCHANGE", raising=False)
+    monkeypatch.delenv("GCN_BENCH_TRANSPORT", raising=False)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(8, ["--gpus", "8", "--steps", "3"])
+    return rc, json_lines(capsys.readouterr().out), calls, time.monotonic() - t0
+
+
+def _kind(extra):
+    if "--selftest" in extra:
+        return "selftest"
+    if "on" in extra[extra.index("--overlap") + 1]:
+        return "overlap"
+    return "lane" if extra[extra.index("--eval-lane") + 1] == "on" else "plain"
+
+
+def test_launcher_prints_the_safe_line_first_and_the_best_line_last(monkeypatch, capsys):
+    def behaviour(extra, timeout):
+        k = _kind(extra)
+        return {"selftest": (0, json.dumps({"selftest": "ok"})), "plain": (0, _fake_line(100.0, "plain one-stream")),
+                "overlap": (0, _fake_line(120.0, "exchange overlap")), "lane": (0, _fake_line(90.0, "validation lane"))}[k]
+    rc, lines, calls, _ = _launcher(monkeypatch, capsys, behaviour, {"GCN_BENCH_DEADLINE": "420"})
+    assert rc == 0 and [_kind(c[0]) for c in calls] == ["selftest", "plain", "overlap", "lane"]
+    assert calls[1][2]["HIPGCN_EXCHANGE"] == "auto"
+    assert lines[0]["value"] == 100.0 and lines[0]["config"]["schedule"] == "plain one-stream"
+    assert lines[-1]["value"] == 120.0 and {o["value"] for o in lines[-1]["other_schedules"]} == {100.0, 90.0}
+    assert all(c[1] <= 420 for c in calls)
+
+
+def test_launcher_keeps_the_safe_line_when_an_optional_schedule_hangs(monkeypatch, capsys):
+    import time
+
+    def behaviour(extra, timeout):
+        k = _kind(extra)
+        if k == "selftest":
+            return 0, json.dumps({"selftest": "ok"})
+        if k == "plain":
+            time.sleep(0.3)
+            return 0, _fake_line(100.0, "plain one-stream")
+        if k == "overlap":                      # hangs: the stand-in returns what _run_ranks returns after killing the group
+            time.sleep(timeout)
+            return 124, None
+        return 0, _fake_line(101.0, "validation lane")
+    rc, lines, calls, wall = _launcher(monkeypatch, capsys, behaviour, {"GCN_BENCH_DEADLINE": "8", "GCN_BENCH_PLAIN_ESTIMATE": "1", "GCN_BENCH_SELFTEST_TIMEOUT": "1"})
+    assert rc == 0 and wall <= 8.5, wall
+    assert lines[0]["value"] == 100.0                              # printed before the hang
+    hung = [o for o in lines[-1]["other_schedules"] if "overlap on" in o["schedule"]]
+    assert hung and hung[0]["failed_rc"] == 124
+    lane = [o for o in lines[-1]["other_schedules"] if "eval-lane on" in str(o["schedule"])]
+    assert lane and "skipped" in lane[0]                           # nothing left of the deadline for it
+    assert lines[-1]["value"] == 100.0 and lines[-1]["launcher"]["used_s"] <= 8.5
+
+
+def test_launcher_skips_what_the_deadline_cannot_hold(monkeypatch, capsys):
+    import time
+
+    def behaviour(extra, timeout):
+        k = _kind(extra)
+        assert k == "plain", "self-test and optional schedules must be skipped with this little time"
+        time.sleep(1.0)
+        return 0, _fake_line(50.0, "plain one-stream")
+    # 7 s - 5 s margin: no room for a self-test beside the plain run's estimate, and after a 1 s plain run less than the 1.2 s
+    # an optional schedule is expected to take
+    rc, lines, calls, _ = _launcher(monkeypatch, capsys, behaviour, {"GCN_BENCH_DEADLINE": "7", "GCN_BENCH_PLAIN_ESTIMATE": "30"})
+    assert rc == 0 and len(calls) == 1 and calls[0][2]["HIPGCN_EXCHANGE"] == "allgather"       # no self-test: pinned
+    assert lines[0]["value"] == 50.0
+    assert all("skipped" in o for o in lines[-1]["other_schedules"]) and len(lines[-1]["other_schedules"]) == 2
+
+
+def test_launcher_retries_pinned_and_reports_plain_failure(monkeypatch, capsys):
+    seen = []
+
+    def behaviour(extra, timeout):
+        k = _kind(extra)
+        if k == "selftest":
+            return 0, json.dumps({"selftest": "ok"})
+        seen.append(k)
+        return (1, None) if len(seen) == 1 else (0, _fake_line(70.0, "plain one-stream"))
+    rc, lines, calls, _ = _launcher(monkeypatch, capsys, behaviour, {"GCN_BENCH_DEADLINE": "420", "GCN_BENCH_PLAIN_ESTIMATE": "1"})
+    assert rc == 0 and calls[1][2]["HIPGCN_EXCHANGE"] == "auto" and calls[2][2]["HIPGCN_EXCHANGE"] == "allgather"
+    assert lines[0]["value"] == 70.0
+    rc, lines, calls, _ = _launcher(monkeypatch, capsys, lambda e, t: (0, "{}") if "--selftest" in e else (1, None), {"GCN_BENCH_DEADLINE": "420", "GCN_BENCH_PLAIN_ESTIMATE": "1"})
+    assert rc == 1 and lines == []
+
+
 CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
 
@@ -95,12 +199,41 @@ def test_bench_extras_on_a_small_graph():
 @pytest.mark.gpu
 def test_bench_two_ranks_self_launched():
     p = run_bench(["--gpus", 2, "--dataset", "reddit-mini", "--steps", 3, "--warmup", 1, "--bursts", 0, "--no-cpu-baseline"],
-                  env={"GCN_BENCH_TRANSPORT": "host", "GCN_BENCH_DEVICE": "0", "GCN_BENCH_TIMEOUT": "600"})
+                  env={"GCN_BENCH_TRANSPORT": "host", "GCN_BENCH_DEVICE": "0", "GCN_BENCH_TIMEOUT": "600", "GCN_BENCH_DEADLINE": "600"})
     assert p.returncode == 0, p.stderr[-3000:]
     lines = json_lines(p.stdout)
-    assert len(lines) == 1, p.stdout
-    out = lines[0]
+    assert 1 <= len(lines) <= 2, p.stdout                     # the safe (plain-schedule) line at once, the best line last
+    assert lines[0]["config"]["schedule"] == "plain one-stream"
+    out = lines[-1]
+    assert out["value"] >= lines[0]["value"]
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
     assert out["config"]["parallelism"] == "row-partition x2"
     assert "comm" in out["breakdown_ms_per_epoch"]
     assert 0 < out["final"]["train_loss"] < 10
+    assert len(out["other_schedules"]) == 2 and out["launcher"]["used_s"] <= out["launcher"]["deadline_s"]
+
+
+@pytest.mark.gpu
+def test_bench_safe_line_survives_a_hung_optional_schedule():
+    """verdict r05 item 3: four ranks (host transport, all on GPU 0 — the box allows six GPU processes, so not eight), the
+    children of the `--overlap on` schedule made to hang: the plain line is out before that leg starts, the leg is killed at
+    what the deadline leaves, and the whole call ends inside the deadline with the safe line's N > 1 fields present."""
+    import time
+    deadline = 240
+    t0 = time.monotonic()
+    p = run_bench(["--gpus", 4, "--dataset", "reddit-mini", "--steps", 3, "--warmup", 1, "--bursts", 0],
+                  env={"GCN_BENCH_TRANSPORT": "host", "GCN_BENCH_DEVICE": "0", "GCN_BENCH_DEADLINE": str(deadline), "GCN_BENCH_TEST_HANG": "overlap"},
+                  timeout=deadline + 60)
+    wall = time.monotonic() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert wall <= deadline + 15, wall
+    lines = json_lines(p.stdout)
+    assert lines, p.stdout
+    safe = lines[0]
+    assert safe["n_gpus"] == 4 and safe["value"] > 0 and safe["config"]["schedule"] == "plain one-stream"
+    assert safe["config"]["transport"] == "host" and "rccl_ranks" in safe["config"]
+    assert safe["roofline"]["collectives_per_epoch"] > 0
+    assert safe["cpu_baseline"] is None                          # N > 1: the CPU baseline belongs to the N = 1 line
+    last = lines[-1]
+    hung = [o for o in last.get("other_schedules", []) if "overlap on" in str(o.get("schedule"))]
+    assert hung and hung[0]["value"] is None and (hung[0].get("failed_rc") == 124 or "skipped" in hung[0]), last.get("other_schedules")

@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cuda_gcn_amd import datagen  # noqa: E402
+from cuda_gcn_amd.provenance import source_sha  # noqa: E402
 
 LIB = os.path.join(ROOT, "build", "libgatherpeak.so")
 
@@ -109,7 +110,9 @@ def main():
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
     except Exception:
         commit = None
-    doc = {"dataset": a.dataset, "rows": n, "stored_edges": nnz, "tasks": int(e0.size), "schedule": a.schedule, "_meta": {"commit": commit},
+    doc = {"dataset": a.dataset, "rows": n, "stored_edges": nnz, "tasks": int(e0.size), "schedule": a.schedule,
+           "_meta": {"commit": commit or (open(os.path.join(ROOT, ".commit_for_profiles")).read().strip() if os.path.exists(os.path.join(ROOT, ".commit_for_profiles")) else None),
+                     "sources": source_sha(["graphsum.hip", "tools/gather_peak.hip"])},
            "kernel": "tools/gather_peak.hip: gather + sum only (no coefficient stream, no multiply, no epilogue); one wave per task, XCD-sliced like graphsum_vec_kernel",
            "unit": "GB/s of gathered row bytes = 4 * dim * edges / avg launch time", "results": []}
     sweeps_u = (4,) if a.best_only else ((2, 4) if a.quick else (1, 2, 4, 8))

@@ -14,7 +14,7 @@ for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 $PROG > "$OUT/p$i.log" 2>&1 || echo "FAILED pass $i"
 done
-python3 - "$OUT" <<'PY'
+GCN_REPO="$R" python3 - "$OUT" <<'PY'
 import csv, glob, json, os, statistics, sys, collections
 out = sys.argv[1]
 match = os.environ["PMC_MATCH"].split(",")
@@ -39,6 +39,9 @@ for k, d in agg.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_BUSY_CU_CYCLES"):
         e["mfma_pipe_busy_share"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * e["SQ_BUSY_CU_CYCLES"])
     res[k] = e
-res["_meta"] = {"commit": __import__("os").environ.get("GCN_COMMIT"), "what": os.environ.get("PMC_PROG", "tools/bench_gemm.py") + " (reddit-syn shapes)", "counters": "median per launch; one rocprofv3 --pmc pass per counter group"}
+sys.path.insert(0, os.environ["GCN_REPO"])
+from cuda_gcn_amd.provenance import source_sha
+res["_meta"] = {"commit": os.environ.get("GCN_COMMIT"), "what": os.environ.get("PMC_PROG", "tools/bench_gemm.py") + " (reddit-syn shapes)", "counters": "median per launch; one rocprofv3 --pmc pass per counter group",
+                "sources": source_sha(os.environ.get("PMC_SOURCES", "dense_bf16x3.h,bf16x3_split.h,dense_persist.h,class_bf16x3.h").split(","))}
 print(json.dumps(res, indent=1, sort_keys=True))
 PY

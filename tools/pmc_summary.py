@@ -10,6 +10,9 @@ duration does not match the launch it has just timed).
 """
 import collections, csv, glob, json, os, statistics, sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cuda_gcn_amd.provenance import source_sha  # noqa: E402
+
 root = sys.argv[1]
 match = (sys.argv[4] if len(sys.argv) > 4 else "graphsum").split(",")      # kernel-name substrings, comma separated
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -27,7 +30,10 @@ for f in glob.glob(os.path.join(root, "*", "**", "*_kernel_trace.csv"), recursiv
     for r in csv.DictReader(open(f)):
         dur[name_of(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"_meta": {"commit": sys.argv[2] if len(sys.argv) > 2 else None, "what": sys.argv[3] if len(sys.argv) > 3 else None,
-                 "counters": "median per launch; one rocprofv3 --pmc pass per counter group, --kernel-trace only"}}
+                 "counters": "median per launch; one rocprofv3 --pmc pass per counter group, --kernel-trace only",
+                 # the kernel sources this file describes (PMC_SOURCES, comma separated; default: the aggregation): bench.py marks the
+                 # file stale when one of them has changed (cuda_gcn_amd/provenance.py)
+                 "sources": source_sha(os.environ.get("PMC_SOURCES", "graphsum.hip").split(","))}}
 for k, cs in agg.items():
     if not any(m in k for m in match):
         continue
