@@ -138,6 +138,50 @@ def _free_port():
     return p
 
 
+def _descendants(pid):
+    """every live process below `pid` (children, their children, ...), from /proc: torch.distributed.run starts each rank in a
+    session of its own, so killing the launcher's process group alone leaves hung ranks behind — holding the GPU and our pipe"""
+    kids = {}
+    for d in os.listdir("/proc"):
+        if not d.isdigit():
+            continue
+        try:
+            with open(f"/proc/{d}/stat") as f:
+                st = f.read()
+            ppid = int(st[st.rindex(")") + 2:].split()[1])
+        except (OSError, ValueError, IndexError):
+            continue
+        kids.setdefault(ppid, []).append(int(d))
+    out, todo = [], [pid]
+    while todo:
+        for c in kids.get(todo.pop(), []):
+            out.append(c)
+            todo.append(c)
+    return out
+
+
+def _kill_tree(p):
+    """SIGKILL exactly the processes this parent started through `p`: the launcher's group and every descendant found under it"""
+    tree = _descendants(p.pid)
+    for target in [p.pid] + tree:
+        try:
+            os.killpg(os.getpgid(target), signal.SIGKILL) if target == p.pid else os.kill(target, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    for _ in range(20):                          # ranks started between the listing and the kill
+        more = [c for c in _descendants(p.pid) if c not in tree]
+        if not more:
+            break
+        for c in more:
+            try:
+                os.kill(c, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        tree += more
+        time.sleep(0.1)
+    return len(tree) + 1
+
+
 def _run_ranks(n_gpus, extra, timeout, env=None):
     """one group of N rank processes (children of this GPU-free parent); returns (rc, JSON line or None)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
@@ -148,12 +192,17 @@ def _run_ranks(n_gpus, extra, timeout, env=None):
         out, _ = p.communicate(timeout=timeout)
         rc = p.returncode
     except subprocess.TimeoutExpired:
-        log(f"ranks still running after {timeout:.0f} s: killing process group {p.pid}")
+        log(f"ranks still running after {timeout:.0f} s: killing the {n_gpus}-rank group under pid {p.pid}")
+        n = _kill_tree(p)                        # exactly what this parent started: the launcher's group and every rank below it
         try:
-            os.killpg(p.pid, signal.SIGKILL)       # exactly the group this parent started
-        except ProcessLookupError:
-            pass
-        out, _ = p.communicate()
+            out, _ = p.communicate(timeout=15)
+        except subprocess.TimeoutExpired:        # something still holds the pipe: do not wait for it
+            log(f"the pipe of the killed group did not close ({n} processes signalled): moving on")
+            out = ""
+            try:
+                p.stdout.close()
+            except Exception:
+                pass
         rc = 124
     line = None
     for ln in (out or "").splitlines():

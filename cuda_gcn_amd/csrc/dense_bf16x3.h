@@ -213,7 +213,8 @@ __device__ __forceinline__ void bx_ldsread16(bf16x8 &dst, uint32_t addr) {
 // share's last row and store nothing (the counted waits need every wave to issue the same operations).
 // ABL (timing experiments of tools/gemm_bf16x3.hip only; 1-8, 32 and 64 give wrong results): 1 no X loads, 2 no W DMA, 4 no split,
 // 8 no W LDS reads, 16 every wait vmcnt(0), 32 keep words loaded but not applied, 64 applied but not loaded, 128 keep word after the
-// X loads (+9 us), 256 X loads ahead of the chunk's W pieces (+40 us), 512 X loads at the top of the chunk (+9..14 us).
+// X loads (+9 us), 256 X loads ahead of the chunk's W pieces (+40 us), 512 X loads at the top of the chunk (+9..14 us),
+// 1024 no workgroup barrier (round 6: what the per-half-item barrier costs the MFMA skeleton).
 // PD_: W k-steps in flight (6..9 measure the same).
 // NW = waves per workgroup.  8: the whole-chip form (two waves per SIMD fill the CU's register file).  4 (round 5, for a context
 // that runs BESIDE another stream's kernels — the validation lane): one wave per SIMD and half the register file, so that a
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dense_fwd_bf16x3_kernel(Bx3FwdArgs
     // what the W wait allows: the younger W pieces of this wave, BX_PD - 2 k-steps of 2 (eight waves) or 3 (four waves) pieces
     static_assert(PD >= 5 && PD <= 9, "BX_WAIT_W spells the counts out");
 #define BX_WAIT_W() do { constexpr int n_ = (NW == 4 ? 3 : 2) * (PD - 2); \
+        if (ABL & 1024) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else \
         if (ABL & 16) PG_WAIT_BARRIER(0); else if (n_ == 6) PG_WAIT_BARRIER(6); else if (n_ == 8) PG_WAIT_BARRIER(8); else if (n_ == 9) PG_WAIT_BARRIER(9); \
         else if (n_ == 10) PG_WAIT_BARRIER(10); else if (n_ == 12) PG_WAIT_BARRIER(12); else if (n_ == 14) PG_WAIT_BARRIER(14); \
         else if (n_ == 15) PG_WAIT_BARRIER(15); else if (n_ == 18) PG_WAIT_BARRIER(18); else if (n_ == 21) PG_WAIT_BARRIER(21); else PG_WAIT_BARRIER(0); } while (0)

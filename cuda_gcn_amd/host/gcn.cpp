@@ -75,6 +75,7 @@ void HipGCN::init(const HipGCNOptions &opt) {
         throw GcnHipFailure(-1, "HipGCN: GCNData arrays do not match num_nodes");
     GCNHIP_CHECK(gcnhip_ctx_create(&env.ctx, opt.device, nullptr));
     if (opt.gemm >= 0) GCNHIP_CHECK(gcnhip_ctx_set_option(env.ctx, "gemm_bf16x3", opt.gemm ? 2 : 0));   // HIPGCN_GEMM; else the library's default
+    if (opt.fold_training) GCNHIP_CHECK(gcnhip_ctx_set_option(env.ctx, "gs_fold", 1));                  // (ignored by a library built without the experiments)
     timers.reset(new DeviceTimers(env.ctx));
     timers->enabled = (flags & HIPGCN_TIMERS) != 0;
     env.timers = timers.get();

@@ -98,6 +98,8 @@ struct HipGCNOptions {
     // HIPGCN_SCHEDULE=degree|label|dealt[-G]|structure: pin the aggregation's row schedule instead of timing the candidates at
     // load (-1: timed).  A pinned run launches no tuning kernels, so a kernel-trace profile of it holds the epochs' launches only.
     int schedule = -1, schedule_groups = 256;
+    bool fold_training = false;           // HIPGCN_FOLD_TRAINING (experiments build): the TRAINING context's aggregations add split rows' segments
+                                          // inside the launch (context option gs_fold) — no finalize launch to queue behind the validation lane's kernels
     bool slice_tuning = true;             // HIPGCN_NO_SLICE_TUNING clears: the hidden-width aggregation keeps 64-float column slices
                                           // (default: chosen per graph by a rule on its structure, HipGCN::choose_slice_width)
     // HIPGCN_GEMM=f32|bf16x3: arithmetic of the dense first-layer products (0: exact-f32 MFMA, 1: three-plane bf16 split on the

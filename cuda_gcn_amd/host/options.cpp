@@ -29,6 +29,7 @@ HipGCNOptions HipGCNOptions::from_environment(HipGCNOptions o) {
     if (getenv("HIPGCN_NO_LOSS_EPILOGUE")) o.loss_epilogue = false;
     if (getenv("HIPGCN_NO_EVAL_FUSION")) o.eval_fusion = false;
     if (getenv("HIPGCN_NO_SLICE_TUNING")) o.slice_tuning = false;
+    if (getenv("HIPGCN_FOLD_TRAINING")) o.fold_training = true;
     if (getenv("HIPGCN_RECORD_LAUNCH")) o.loss_records_metrics = false;
     if (const char *e = getenv("HIPGCN_BWD_CHUNKS")) o.bwd_chunks = atoi(e);
     if (const char *e = getenv("HIPGCN_READBACK_STREAM")) o.readback_stream = atoi(e) != 0;

@@ -10,16 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: minutes of host preparation (full-size BASELINE configs[4] under partitioning); runs only with GCN_RUN_SLOW=1")
-
-
-def pytest_collection_modifyitems(config, items):
-    if os.environ.get("GCN_RUN_SLOW"):
-        return
-    skip = pytest.mark.skip(reason="slow: set GCN_RUN_SLOW=1 (run once per round, record under profiles/)")
-    for it in items:
-        if "slow" in it.keywords:
-            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

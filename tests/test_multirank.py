@@ -168,11 +168,9 @@ def test_logical_ranks_as_threads_match_single_gpu(name, world, dropout, run_asy
     ("reddit-syn", 128, 0, "allgather"),                    # BASELINE configs[3] at its own size: 8 row blocks of the 233 K-node graph
     ("reddit-syn", 128, OVERLAP, "allgather"),              # ... with every exchange on its own stream beside the own-column edges
     ("rmat-20-32", 128, 0, "halo"),                         # BASELINE configs[4]'s family at 1 M nodes: per-peer halo lists
-    # BASELINE configs[4] ITSELF — 4 M nodes x 256 features — cut into its 8 row blocks (verdict r05 item 7): minutes of host
-    # preparation for eight logical ranks, so it runs on request only (GCN_RUN_SLOW=1; record: profiles/r06_rmat22_256_p8.log);
-    # rmat-21-256 is the same width at half the rows
-    pytest.param("rmat-21-256", 128, 0, "halo", marks=pytest.mark.slow),
-    pytest.param("rmat-22-256", 128, 0, "halo", marks=pytest.mark.slow),
+    # BASELINE configs[4] ITSELF — 4.2 M nodes x 256 features -> 128 -> 41 — cut into its 8 row blocks on the halo plan (verdict r05
+    # item 7): 49 s on the GPU box (round 6: gpurun_out/r6/rmat22_256_p8.log; rmat-21-256: 23 s), so it runs with the suite
+    ("rmat-22-256", 128, 0, "halo"),
 ])
 def test_full_size_eight_logical_ranks_match_single_gpu(name, hidden, flags, want_mode):
     """The N > 1 path at the BASELINE sizes, on the one GPU this pool has: 8 logical ranks (threads of this process, host-staged

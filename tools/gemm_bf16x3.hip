@@ -164,6 +164,18 @@ int main(int argc, char **argv) {
     // ---- three bf16 planes
     {
         Bx3FwdArgs a{dx, ldx, dwp, dout, p, m, K, n_chunks, n_rb, nullptr, 0};
+        if (argc > 4 && !strcmp(argv[4], "price")) {
+            // round 6: what bounds the MFMA skeleton (results wrong in every ablation; the full kernel first and last)
+            for (int rep = 0; rep < 2; rep++) {
+                printf("  full kernel, no dropout:                      %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 0><<<n_cu, 512>>>(a); }));
+                printf("  skeleton (ablation 15: MFMAs + barriers):     %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 15><<<n_cu, 512>>>(a); }));
+                printf("  skeleton without the barriers (15 + 1024):    %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 15 + 1024><<<n_cu, 512>>>(a); }));
+                printf("  full kernel without the barriers (1024):      %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 1024><<<n_cu, 512>>>(a); }));
+                printf("  no W LDS reads, no barriers (8 + 1024):       %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 8 + 1024><<<n_cu, 512>>>(a); }));
+                printf("  no split (4):                                 %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 4><<<n_cu, 512>>>(a); }));
+            }
+            return 0;
+        }
         // where the time goes: each ablation drops one cost (results wrong): 1 no X loads, 2 no W DMA, 4 no split, 8 no W LDS reads
         printf("  ablation  1 (no X loads):     %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 1><<<n_cu, 512>>>(a); }));
         printf("  ablation  2 (no W DMA):       %.4f ms\n", time_ms(iters, [&]() { dense_fwd_bf16x3_kernel<false, 6, 2><<<n_cu, 512>>>(a); }));
