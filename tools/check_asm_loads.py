@@ -41,7 +41,7 @@ def regs_of(text):
 def compile_to_asm(src):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed",
-           "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", src, "-o", out]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cuda_gcn_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", out]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return out
 
