@@ -496,6 +496,8 @@ void HipGCN::tune_schedule() {
         choose_slice_width();
         return;
     }
+    // the slice width first (a rule on the graph, not a timing): the candidates are timed with the launch the epochs will use
+    choose_slice_width();
     HipVariable *in = variables[1].get(), *out = variables[3].get();
     float *src = in->full ? in->full : in->data;
     const size_t src_elems = in->full ? in->full_elems : in->elems();
@@ -520,8 +522,11 @@ void HipGCN::tune_schedule() {
         if (!(fresh && c.mode == 0)) apply_schedule(env.ctx, g);
         fresh = false;
         float ms = 0.f;
-        for (int it = 0; it < 3; it++) {                     // first run warms the caches and sizes the scratch
-            if (it == 1) GCNHIP_CHECK(gcnhip_event_record(env.ctx, e0));
+        // two launches warm the caches, size the scratch and let the clock settle, five are timed.  (Until round 6: one and
+        // two — on reddit-syn-h0, where the candidates are 5 % apart, the driver's run picked plain degree order, 245 epochs/s,
+        // where the same tree had picked dealt-256 an hour earlier, 254.)
+        for (int it = 0; it < 7; it++) {
+            if (it == 2) GCNHIP_CHECK(gcnhip_event_record(env.ctx, e0));
             GCNHIP_CHECK(gcnhip_graphsum_ex(env.ctx, g, &gso, src, in->ld, out->data, out->ld, H));
         }
         GCNHIP_CHECK(gcnhip_event_record(env.ctx, e1));
@@ -532,7 +537,6 @@ void HipGCN::tune_schedule() {
     sched_mode = pick.mode; sched_groups = pick.groups;
     if (!(g == graph && g_has_pick)) apply_schedule(env.ctx, graph);
     if (graph_l1 && !(g == graph_l1 && g_has_pick)) apply_schedule(env.ctx, graph_l1);
-    choose_slice_width();
     gcnhip_event_destroy(e0);
     gcnhip_event_destroy(e1);
     GCNHIP_CHECK(gcnhip_memset_async(env.ctx, out->data, 0, out->elems() * sizeof(float)));
