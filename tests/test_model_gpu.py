@@ -376,10 +376,14 @@ def test_aggregate_first_eval_matches_reference_order(name, hidden):
 
 
 @pytest.mark.parametrize("name,hidden", [("reddit-mini", 128), ("cora-syn", 64)])
-def test_packed_dh1_is_bit_identical_to_dense(name, hidden, experiments):
+def test_packed_dh1_is_bit_identical_to_dense(name, hidden, experiments, monkeypatch):
     """dH1 travelling as packed rows from the Matmul backward to the hidden layer's backward aggregation changes
-    no bit of any weight or reported number"""
+    no bit of any weight or reported number.  (Both models on the exact-f32 MFMA kernels: the packed producer
+    gcnhip_matmul_bwd_packed is an f32 row-stream kernel, while the default class-layer backward has been the bf16x3 kernel
+    since round 5 — another, equally bounded, rounding of the same dH1.  Found in round 6, the first full run of the
+    experiments build since then: ten epochs of identical traces, the eleventh training loss one ulp apart.)"""
     from cuda_gcn_amd.model import HipGCNModel, PACKED_DH1, EDGE_COEF
+    monkeypatch.setenv("HIPGCN_GEMM", "f32")
     ds = datagen.make_dataset(name)
     a = HipGCNModel(ds, seed=8, flags=EDGE_COEF, hidden_dim=hidden, dropout=0.5, epochs=12)   # (packed rows imply the per-edge coefficients)
     b = HipGCNModel(ds, seed=8, flags=PACKED_DH1, hidden_dim=hidden, dropout=0.5, epochs=12)
