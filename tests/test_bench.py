@@ -245,10 +245,12 @@ def test_bench_safe_line_survives_a_hung_optional_schedule():
     children of the `--overlap on` schedule made to hang: the plain line is out before that leg starts, the leg is killed at
     what the deadline leaves, and the whole call ends inside the deadline with the safe line's N > 1 fields present."""
     import time
-    deadline = 240
+    deadline = 200
     t0 = time.monotonic()
+    # (the hung schedule's own limit, 45 s, ends it long before the deadline would: the suite need not wait for that)
     p = run_bench(["--gpus", 4, "--dataset", "reddit-mini", "--steps", 3, "--warmup", 1, "--bursts", 0],
-                  env={"GCN_BENCH_TRANSPORT": "host", "GCN_BENCH_DEVICE": "0", "GCN_BENCH_DEADLINE": str(deadline), "GCN_BENCH_TEST_HANG": "overlap"},
+                  env={"GCN_BENCH_TRANSPORT": "host", "GCN_BENCH_DEVICE": "0", "GCN_BENCH_DEADLINE": str(deadline), "GCN_BENCH_LANE_TIMEOUT": "45",
+                       "GCN_BENCH_TEST_HANG": "overlap"},
                   timeout=deadline + 60)
     wall = time.monotonic() - t0
     assert p.returncode == 0, p.stderr[-3000:]
