@@ -415,3 +415,33 @@ def test_gcn_hip_writes_the_cache_and_refuses_to_run_without_a_gpu(tmp_path):
     back = model.load_dataset(root, "tiny-syn")
     for k in ("g_indptr", "g_indices", "f_indptr", "f_indices", "f_val", "split", "label"):
         assert np.array_equal(back[k], ds[k]), k
+
+
+# ---- provenance of stored measurements (round 6): bench.py marks a quoted profile stale when the kernel source it was taken on changed
+def test_profile_provenance_hashes_and_stale_reason(tmp_path, monkeypatch):
+    from cuda_gcn_amd import provenance
+    h = provenance.source_sha(["graphsum.hip", "tools/gather_peak.hip", "no_such_file.h"])
+    assert len(h["graphsum.hip"]) == 16 and len(h["tools/gather_peak.hip"]) == 16 and h["no_such_file.h"] is None
+    assert provenance.stale_reason({"sources": {"graphsum.hip": h["graphsum.hip"]}}) is None
+    assert "graphsum.hip" in provenance.stale_reason({"sources": {"graphsum.hip": "0" * 16}})
+    assert "no source hashes" in provenance.stale_reason({"commit": "abc"}) and "no source hashes" in provenance.stale_reason(None)
+
+
+def test_bench_quotes_a_profile_of_another_tree_as_stale(tmp_path, monkeypatch):
+    """bench._pmc: a PMC file whose recorded source hash differs from the tree's is still returned (the numbers are what there is),
+    with stale = True and the reason"""
+    import importlib, json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    k, src, why = bench._pmc(bench.PMC_FILES, bench.GS_KERNEL, None)
+    assert k is not None and src.endswith("r06_graphsum_pmc.json") and isinstance(k["stale"], bool)
+    assert k["stale"] == (k["stale_why"] is not None)         # (whether it IS stale depends on the tree: a kernel edit makes it so until the file is re-taken)
+    fake = tmp_path / "profiles"
+    fake.mkdir()
+    doc = json.load(open(os.path.join(root, "profiles", "r06_graphsum_pmc.json")))
+    doc["_meta"]["sources"] = {"graphsum.hip": "0" * 16}
+    json.dump(doc, open(fake / "r06_graphsum_pmc.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    k, src, why = bench._pmc(["r06_graphsum_pmc.json"], bench.GS_KERNEL, None)
+    assert k["stale"] is True and "graphsum.hip" in k["stale_why"]
