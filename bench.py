@@ -814,6 +814,13 @@ def main():
                 roof["peak_without_store"] = ceil_doc.get("ceiling_without_store_GBps", {}).get(f"d={args.hidden}")
                 roof["peak_uniform_random_rows"] = ceil_doc.get("ceiling_uniform_random_GBps", {}).get(f"d={args.hidden}")
                 roof["measured_gather_exceeded"] = bool(gathered > ceil_gbps)     # a stale or mismatched ceiling shows here
+                # the launch's L2-MISS traffic (PMC fabric bytes / launch time) against the rate the same microbenchmark measures for
+                # uniformly random rows of the same table (~3 % L2 hits: practically all of it Infinity-Cache traffic) — the resource
+                # round 6 found the launch waits for (docs/NOTEBOOK_r6.md 1)
+                rnd = roof["peak_uniform_random_rows"]
+                if rnd and traffic:
+                    roof["fabric_rate_GBps"] = traffic / avg_s / 1e9
+                    roof["frac_vs_measured_fabric_rate"] = traffic / avg_s / 1e9 / rnd
         else:
             roof = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": algorithmic / HBM_PEAK_GBPS, "traffic": traffic,
